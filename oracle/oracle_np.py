@@ -1,0 +1,167 @@
+"""Second, independent restatement of the index-math ops as explicit numpy /
+pure-Python loops (TEST INFRASTRUCTURE ONLY; PARITY UNPINNED, see
+oracle/__init__.py).  Written from the reference formulas, sharing no code
+with oracle_torch.py, so the two can pin each other on small cases.
+
+float32 arithmetic is done with numpy float32 scalars/arrays in the same
+operation order as the reference so results are bit-comparable.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+f32 = np.float32
+
+
+def same_pad(in_size, k, s, d=1):
+    """TF SAME padding: (before, after, out)."""
+    out = (in_size + s - 1) // s
+    total = max((out - 1) * s + (k - 1) * d + 1 - in_size, 0)
+    return total // 2, total - total // 2, out
+
+
+def conv2d_same(x, w, b=None, stride=1, dilation=1):
+    """Direct-loop SAME conv, NHWC x HWIO (tf.nn.conv2d semantics), float64
+    accumulation for use as a numerically clean reference on tiny cases."""
+    n, h, wd, ci = x.shape
+    kh, kw, _, co = w.shape
+    pt, _, oh = same_pad(h, kh, stride, dilation)
+    pl, _, ow = same_pad(wd, kw, stride, dilation)
+    y = np.zeros((n, oh, ow, co), np.float64)
+    for oy in range(oh):
+        for ox in range(ow):
+            for ky in range(kh):
+                iy = oy * stride + ky * dilation - pt
+                if iy < 0 or iy >= h:
+                    continue
+                for kx in range(kw):
+                    ix = ox * stride + kx * dilation - pl
+                    if ix < 0 or ix >= wd:
+                        continue
+                    y[:, oy, ox, :] += x[:, iy, ix, :].astype(np.float64) @ w[ky, kx].astype(np.float64)
+    if b is not None:
+        y += b.astype(np.float64)
+    return y
+
+
+def conv2d_transpose_k4s2_same(x, w, b=None):
+    """tf.layers.conv2d_transpose(k=4, s=2, 'same'); w [KH,KW,Cout,Cin];
+    scatter form: y[2*iy+ky-1, 2*ix+kx-1, co] += x[iy,ix,ci]*w[ky,kx,co,ci]."""
+    n, h, wd, ci = x.shape
+    co = w.shape[2]
+    y = np.zeros((n, 2 * h, 2 * wd, co), np.float64)
+    for iy in range(h):
+        for ix in range(wd):
+            for ky in range(4):
+                oy = 2 * iy + ky - 1
+                if oy < 0 or oy >= 2 * h:
+                    continue
+                for kx in range(4):
+                    ox = 2 * ix + kx - 1
+                    if ox < 0 or ox >= 2 * wd:
+                        continue
+                    y[:, oy, ox, :] += x[:, iy, ix, :].astype(np.float64) @ w[ky, kx].astype(np.float64).T
+    if b is not None:
+        y += b.astype(np.float64)
+    return y
+
+
+def resize_bilinear_legacy(x, oh, ow):
+    """TF-1.13 ResizeBilinear, align_corners=False (float32, reference op order:
+    top=tl+(tr-tl)*xl; bot=bl+(br-bl)*xl; out=top+(bot-top)*yl)."""
+    n, h, w, c = x.shape
+    if (h, w) == (oh, ow):
+        return x
+    x = x.astype(f32)
+    y = np.empty((n, oh, ow, c), f32)
+    sy, sx = f32(h) / f32(oh), f32(w) / f32(ow)
+    for i in range(oh):
+        src = f32(i) * sy
+        y0 = int(src)
+        y1 = min(y0 + 1, h - 1)
+        yl = f32(src - f32(y0))
+        for j in range(ow):
+            srx = f32(j) * sx
+            x0 = int(srx)
+            x1 = min(x0 + 1, w - 1)
+            xl = f32(srx - f32(x0))
+            tl, tr, bl, br = x[:, y0, x0], x[:, y0, x1], x[:, y1, x0], x[:, y1, x1]
+            top = tl + (tr - tl) * xl
+            bot = bl + (br - bl) * xl
+            y[:, i, j] = top + (bot - top) * yl
+    return y
+
+
+def resize_nearest_align_corners(x, oh, ow):
+    n, h, w, c = x.shape
+    y = np.empty((n, oh, ow, c), x.dtype)
+    sy = f32(h - 1) / f32(oh - 1) if oh > 1 else f32(0)
+    sx = f32(w - 1) / f32(ow - 1) if ow > 1 else f32(0)
+    for i in range(oh):
+        yi = min(int(np.floor(f32(i) * sy + f32(0.5))), h - 1)
+        for j in range(ow):
+            xi = min(int(np.floor(f32(j) * sx + f32(0.5))), w - 1)
+            y[:, i, j] = x[:, yi, xi]
+    return y
+
+
+def warp_indices(flow):
+    """core_warp.py:99-115,189-194: float32 query, clamped floor, clamped alpha."""
+    n, h, w, _ = flow.shape
+    fy = np.empty((n, h, w), np.int32)
+    fx = np.empty((n, h, w), np.int32)
+    ay = np.empty((n, h, w), f32)
+    ax = np.empty((n, h, w), f32)
+    fl = flow.astype(f32)
+    for b in range(n):
+        for y in range(h):
+            for x in range(w):
+                qy = f32(y) - fl[b, y, x, 0]
+                qx = f32(x) - fl[b, y, x, 1]
+                flo_y = min(max(f32(0), np.floor(qy)), f32(h - 2))
+                flo_x = min(max(f32(0), np.floor(qx)), f32(w - 2))
+                fy[b, y, x] = int(flo_y)
+                fx[b, y, x] = int(flo_x)
+                ay[b, y, x] = min(max(f32(0), f32(qy - flo_y)), f32(1))
+                ax[b, y, x] = min(max(f32(0), f32(qx - flo_x)), f32(1))
+    return fy, fx, ay, ax
+
+
+def dense_image_warp(image, flow):
+    """core_warp.py:139-148 with the float32 op order of the reference:
+    top=ax*(tr-tl)+tl; bot=ax*(br-bl)+bl; out=ay*(bot-top)+top."""
+    n, h, w, c = image.shape
+    img = image.astype(f32)
+    fy, fx, ay, ax = warp_indices(flow)
+    out = np.empty_like(img)
+    for b in range(n):
+        for y in range(h):
+            for x in range(w):
+                y0, x0 = fy[b, y, x], fx[b, y, x]
+                tl, tr = img[b, y0, x0], img[b, y0, x0 + 1]
+                bl, br = img[b, y0 + 1, x0], img[b, y0 + 1, x0 + 1]
+                a_x, a_y = ax[b, y, x], ay[b, y, x]
+                top = a_x * (tr - tl) + tl
+                bot = a_x * (br - bl) + bl
+                out[b, y, x] = a_y * (bot - top) + top
+    return out
+
+
+def cost_volume(c1, warp, r=4):
+    """core_costvol.py:20-40 with float64 accumulation (clean reference)."""
+    n, h, w, c = c1.shape
+    d = 2 * r + 1
+    out = np.zeros((n, h, w, d * d), np.float64)
+    for y in range(h):
+        for x in range(w):
+            for dy in range(d):
+                yy = y + dy - r
+                if yy < 0 or yy >= h:
+                    continue
+                for dx in range(d):
+                    xx = x + dx - r
+                    if xx < 0 or xx >= w:
+                        continue
+                    out[:, y, x, dy * d + dx] = (c1[:, y, x].astype(np.float64) *
+                                                 warp[:, yy, xx].astype(np.float64)).sum(-1) / c
+    return np.where(out > 0, out, 0.1 * out)
