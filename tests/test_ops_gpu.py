@@ -1,0 +1,135 @@
+"""GPU parity of the single-op C-ABI entry points against the CPU oracle (same seeded inputs).
+Tolerance for floating-point results: 1e-3 (BASELINE.json north_star), tightened where the
+arithmetic allows; the warp grid-index math is checked bit-exactly."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle_torch as O  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from unsupervised_detection_amd import ops as _ops
+    return _ops
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+@pytest.mark.parametrize("n,h,w,c,scale", [(4, 12, 20, 128, 0.625), (4, 24, 40, 96, 1.25), (2, 48, 80, 64, 2.5),
+                                           (1, 96, 160, 32, 5.0), (1, 7, 9, 4, 1.0)])
+def test_warp_bit_exact(ops, n, h, w, c, scale):
+    img = rnd(n, h, w, c, seed=1)
+    flow = rnd(n, h, w, 2, seed=2, scale=3.0)
+    out, idx, alpha = ops.dense_image_warp(img.cuda(), flow.cuda(), scale, debug=True)
+    sf = flow * np.float32(scale)
+    fy, fx, ay, ax = O.warp_indices(sf)
+    assert torch.equal(idx[..., 0].cpu(), fy) and torch.equal(idx[..., 1].cpu(), fx)   # bit-exact indices
+    assert torch.equal(alpha[..., 0].cpu(), ay) and torch.equal(alpha[..., 1].cpu(), ax)  # bit-exact alphas
+    ref = O.dense_image_warp(img, sf)
+    assert torch.equal(out.cpu(), ref)  # same float32 op order, no FMA contraction -> bit-exact output
+
+
+def test_warp_border_saturation_and_identity(ops):
+    img = rnd(1, 8, 8, 4, seed=3)
+    z = torch.zeros(1, 8, 8, 2)
+    assert torch.allclose(ops.dense_image_warp(img.cuda(), z.cuda()).cpu(), img, atol=1e-6)
+    far = torch.full((1, 8, 8, 2), 100.0)
+    out = ops.dense_image_warp(img.cuda(), far.cuda()).cpu()
+    assert torch.allclose(out, img[:, :1, :1].expand_as(img), atol=1e-6)
+
+
+@pytest.mark.parametrize("n,h,w,c", [(4, 6, 10, 196), (4, 12, 20, 128), (2, 24, 40, 96), (2, 48, 80, 64),
+                                     (1, 96, 160, 32), (1, 5, 7, 4)])
+def test_cost_volume(ops, n, h, w, c):
+    c1, c2 = rnd(n, h, w, c, seed=4), rnd(n, h, w, c, seed=5)
+    out = ops.cost_volume(c1.cuda(), c2.cuda()).cpu()
+    ref = O.cost_volume(c1, c2)
+    assert out.shape == ref.shape
+    assert (out - ref).abs().max() < 1e-5
+
+
+CONV_CASES = [
+    # n,h,w,cin,cout,k,s,d,act,alpha,up
+    (2, 24, 40, 64, 128, 3, 1, 1, "leaky", 0.1, False),
+    (2, 24, 40, 120, 96, 3, 1, 1, "leaky", 0.1, False),     # Kc % 16 != 0 -> BK=8 path, BN=96
+    (1, 32, 48, 3, 16, 7, 2, 1, "leaky", 0.2, False),        # recover aconv1 (asymmetric SAME 2/3)
+    (1, 32, 48, 16, 32, 5, 2, 1, "leaky", 0.2, False),       # 5x5 s2 (1/2)
+    (1, 31, 47, 32, 64, 3, 2, 1, "leaky", 0.1, False),       # odd sizes, 3x3 s2
+    (2, 12, 24, 128, 128, 3, 1, 16, "elu", 0.0, False),      # dilation 16 (most taps culled)
+    (2, 24, 48, 128, 128, 3, 1, 4, "elu", 0.0, False),
+    (1, 12, 24, 256, 128, 4, 1, 1, "leaky", 0.2, False),     # 4x4 s1 (pad 1/2)
+    (1, 24, 48, 5, 32, 5, 1, 1, "elu", 0.0, False),          # generator conv1
+    (1, 24, 48, 128, 64, 3, 1, 1, "elu", 0.0, True),         # gen_deconv: fused NN x2
+    (1, 24, 40, 565, 2, 3, 1, 1, "none", 0.0, False),        # 2-channel flow head, ragged Cin
+    (4, 6, 10, 529, 128, 3, 1, 1, "leaky", 0.1, False),      # tiny level-6 grid -> split-K
+    (1, 48, 96, 50, 2, 5, 1, 1, "none", 0.0, False),         # recover flow1 5x5
+    (4, 6, 10, 196, 196, 3, 1, 1, "leaky", 0.1, False),      # Cout=196 (two N tiles)
+]
+
+
+def _oracle_conv(x, w, b, s, d, act, alpha, up):
+    if up:
+        x = O.resize_nearest_align_corners(x, 2 * x.shape[1], 2 * x.shape[2])
+    y = O.conv2d_same(x, w, b, s, d)
+    if act == "leaky":
+        y = O.leaky_relu(y, alpha)
+    elif act == "elu":
+        y = torch.nn.functional.elu(y)
+    return y
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_forward(ops, case):
+    n, h, w, cin, cout, k, s, d, act, alpha, up = case
+    x = rnd(n, h, w, cin, seed=6)
+    wt = rnd(k, k, cin, cout, seed=7, scale=(2.0 / (k * k * cin)) ** 0.5)
+    b = rnd(cout, seed=8, scale=0.1)
+    y = ops.conv2d(x.cuda(), wt.cuda(), b.cuda(), s, d, act, alpha, up).cpu()
+    ref = _oracle_conv(x.double(), wt.double(), b.double(), s, d, act, alpha, up).float()
+    assert y.shape == ref.shape
+    assert (y - ref).abs().max() < 1e-4 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_backward(ops, case):
+    n, h, w, cin, cout, k, s, d, act, alpha, up = case
+    x = rnd(n, h, w, cin, seed=9).double().requires_grad_(True)
+    wt = rnd(k, k, cin, cout, seed=10, scale=(2.0 / (k * k * cin)) ** 0.5).double().requires_grad_(True)
+    b = rnd(cout, seed=11, scale=0.1).double().requires_grad_(True)
+    y = _oracle_conv(x, wt, b, s, d, act, alpha, up)
+    dy = rnd(*y.shape, seed=12).double()
+    gx, gw, gb = torch.autograd.grad((y * dy).sum(), [x, wt, b])
+    ys = y.detach().float().cuda()
+    dw, db = ops.conv2d_backward_filter(x.detach().float().cuda(), dy.float().cuda(), ys, (k, k), s, d, act, alpha, up)
+    tol = lambda ref: 2e-4 * max(1.0, float(ref.abs().max()))
+    assert (dw.cpu() - gw.float()).abs().max() < tol(gw)
+    assert (db.cpu() - gb.float()).abs().max() < tol(gb)
+    if not up:
+        dx = ops.conv2d_backward_data(dy.float().cuda(), ys, wt.detach().float().cuda(), (h, w), s, d, act, alpha)
+        assert (dx.cpu() - gx.float()).abs().max() < tol(gx)
+
+
+@pytest.mark.parametrize("n,h,w,cin,cout", [(2, 6, 10, 529, 2), (1, 12, 20, 2, 2), (1, 24, 40, 64, 32)])
+def test_conv2d_transpose(ops, n, h, w, cin, cout):
+    x = rnd(n, h, w, cin, seed=13)
+    wt = rnd(4, 4, cout, cin, seed=14, scale=(1.0 / (16 * cin)) ** 0.5)
+    b = rnd(cout, seed=15, scale=0.1)
+    y = ops.conv2d_transpose4x4s2(x.cuda(), wt.cuda(), b.cuda()).cpu()
+    ref = O.conv2d_transpose_k4s2_same(x.double(), wt.double(), b.double()).float()
+    assert y.shape == ref.shape and (y - ref).abs().max() < 1e-4 * max(1.0, float(ref.abs().max()))
+
+
+def test_bad_arguments_raise(ops):
+    x = torch.zeros(1, 4, 4, 6, device="cuda")
+    with pytest.raises(ValueError):
+        ops.dense_image_warp(x, torch.zeros(1, 4, 4, 2, device="cuda"))  # C % 4 != 0
+    with pytest.raises(ValueError):
+        ops.conv2d(x, torch.zeros(3, 3, 8, 4, device="cuda"))  # channel mismatch

@@ -1,0 +1,59 @@
+"""ctypes binding of libudet.so (include/udet.h).
+
+The HIP library is the product: there is no CPU / PyTorch fallback.  Importing this
+module without a built ``libudet.so`` raises, and every call that fails raises with
+``udet_last_error()``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libudet.so")
+
+if not os.path.exists(LIB_PATH):
+    raise RuntimeError(
+        f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "(or `make -C unsupervised_detection_amd/csrc`).  There is no CPU fallback.")
+
+lib = ctypes.CDLL(LIB_PATH)
+
+c_f = ctypes.c_float
+c_i = ctypes.c_int
+c_p = ctypes.c_void_p
+c_sz = ctypes.c_size_t
+
+lib.udet_version.restype = c_i
+lib.udet_last_error.restype = ctypes.c_char_p
+
+
+def _sig(name, restype, *argtypes):
+    fn = getattr(lib, name)
+    fn.restype = restype
+    fn.argtypes = list(argtypes)
+    return fn
+
+
+_sig("udet_warp", c_i, c_p, c_p, c_f, c_p, c_i, c_i, c_i, c_i, c_p)
+_sig("udet_warp_debug", c_i, c_p, c_p, c_f, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p)
+_sig("udet_cost_volume", c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p)
+_sig("udet_conv2d_workspace_bytes", c_sz, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i)
+_sig("udet_conv2d", c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_sz, c_p)
+_sig("udet_conv2d_backward_data", c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p,
+     c_sz, c_p)
+_sig("udet_conv2d_backward_filter", c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i,
+     c_f, c_p, c_sz, c_p)
+_sig("udet_conv2d_transpose4x4s2", c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p)
+
+
+class UdetError(RuntimeError):
+    pass
+
+
+def check(status: int):
+    if status != 0:
+        msg = lib.udet_last_error().decode("utf-8", "replace")
+        if status in (-1, -2, -5):
+            raise ValueError(f"libudet error {status}: {msg}")
+        raise UdetError(f"libudet error {status}: {msg}")

@@ -1,0 +1,124 @@
+// Internal definitions shared by the HIP translation units of libudet.so.
+// gfx950 (MI355X / CDNA4) only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/udet.h"
+
+namespace udet {
+
+// ---------------------------------------------------------------- errors ----
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+#define UDET_HIP(x)                                   \
+  do {                                                \
+    hipError_t _e = (x);                              \
+    if (_e != hipSuccess) return udet::hip_fail(_e, #x); \
+  } while (0)
+#define UDET_TRY(x)            \
+  do {                         \
+    int _s = (x);              \
+    if (_s != 0) return _s;    \
+  } while (0)
+
+// ----------------------------------------------------------- activations ----
+enum Act { ACT_NONE = UDET_ACT_NONE, ACT_LEAKY = UDET_ACT_LEAKY, ACT_ELU = UDET_ACT_ELU };
+
+__device__ __forceinline__ float act_fwd(float v, int act, float alpha) {
+  if (act == ACT_LEAKY) return v > 0.f ? v : v * alpha;
+  if (act == ACT_ELU) return v > 0.f ? v : expm1f(v);
+  return v;
+}
+// derivative expressed through the saved *output* a = act(u)
+// (TF LeakyReluGrad: features>0 ? g : alpha*g; EluGrad: out<0 ? (out+1)*g : g).
+__device__ __forceinline__ float act_dfo(float a, int act, float alpha) {
+  if (act == ACT_LEAKY) return a > 0.f ? 1.f : alpha;
+  if (act == ACT_ELU) return a > 0.f ? 1.f : a + 1.f;
+  return 1.f;
+}
+
+// ------------------------------------------------ implicit-GEMM conv op ----
+// One launch computes, for every output sub-grid pixel q=(n,qy,qx) and channel co,
+//   y[n, qy*osy+ooy, qx*osx+oox, y_coff+co] (=|+=) epi( sum_t sum_k X(n, qy*isy+t.dy, qx*isx+t.dx, k) * Wp[t.widx][k][co] )
+// X(..) = x[.., x_coff+k] (zero outside the grid; optional NN x2 upsample of x; optional
+// multiplication by act'(xa[..]) for the backward-data pass).  This single form covers the
+// forward convolutions (any k/stride/dilation, TF SAME padding), stride-1 dgrad, stride-2
+// dgrad and conv2d_transpose (one launch per output parity class).
+#define UDET_MAX_TAPS 49
+struct ConvTap {
+  int dy, dx, widx;
+};
+
+struct ConvParams {
+  // A operand (input activations / output-gradients), NHWC with channel stride ldx
+  const float* x;
+  int ldx, x_coff;
+  int N, H, W;     // logical input grid (already x2 when up_shift==1)
+  int up_shift;    // 1: x is stored at (H/2,W/2) and read through nearest-neighbour x2
+  const float* xa; // optional saved activation (same layout as x) -> X *= act'(xa)
+  int xact;
+  float xalpha;
+  // B operand: packed weights [ntaps_total][Kc][ldw]
+  const float* wp;
+  int Kc, ldw;
+  const float* bias;  // [Cout] or null
+  // output
+  float* y;
+  int ldy, y_coff, Cout;
+  int OH, OW;            // full output grid
+  int OHq, OWq;          // sub-grid handled by this launch
+  int osy, osx, ooy, oox;
+  int isy, isx;
+  int ntaps;
+  ConvTap taps[UDET_MAX_TAPS];
+  // epilogue
+  int act;
+  float alpha;
+  const float* res;  // residual added after the activation (forward skip / backward skip-gradient)
+  int ldres, res_coff;
+  float* y2;  // optional second output: activation before the residual add
+  int ldy2, y2_coff;
+  int accumulate;  // y += result
+  // split-K
+  int ksplit;
+  float* partial;  // [ksplit][Mtot][ldp]
+  size_t partial_cap;  // capacity of `partial` in floats
+  int ldp;
+};
+
+int launch_conv(ConvParams& p, hipStream_t stream);
+
+// --------------------------------------------------------------- wgrad ----
+// dW[t][ci][co] = sum_q X(q@t)[ci] * (dY[q][co] * act'(ya[q][co]))
+struct WgradParams {
+  const float* x;
+  int ldx, x_coff;
+  int N, H, W, up_shift;
+  int Cin;
+  const float* dy;  // gradient wrt the layer *output* (post-activation)
+  const float* ya;  // saved activation (same layout as dy) or null
+  int ldy, y_coff, Cout;
+  int yact;
+  float yalpha;
+  int OH, OW, isy, isx;
+  int ntaps;
+  ConvTap taps[UDET_MAX_TAPS];  // widx = tap index in the HWIO weight
+  float* dw;        // [ntaps_total][Cin][Cout]  (HWIO, written, not accumulated)
+  float* db;        // [Cout] or null
+  float* partial;   // workspace
+  size_t partial_floats;
+  // generator finalisation (BN folded): dW = G*gs[co]; dgamma = c*(sum W*G + b*S); dbeta = S; db = gs*S
+  const float* w;       // HWIO weights (for dgamma)
+  const float* b;       // bias
+  const float* gamma;   // null -> plain conv
+  float* dgamma;
+  float* dbeta;
+  float bn_c;
+};
+int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream);
+size_t wgrad_partial_floats_needed(int T, int Cin, int Cout);
+
+}  // namespace udet

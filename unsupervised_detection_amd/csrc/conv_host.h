@@ -1,0 +1,19 @@
+#pragma once
+#include "common.h"
+namespace udet {
+void same_pad(int in, int k, int s, int d, int* before, int* out);
+void conv_setup_fwd(ConvParams& p, int N, int H, int W, int kh, int kw, int s, int d);
+int conv_dgrad_classes(int s);
+bool conv_setup_dgrad(ConvParams& p, int cls, int N, int H, int W, int kh, int kw, int s, int d);
+int launch_pack_weights(const float* src, float* dst, int T, int R, int C, int Kc, int ldw, int k_split, int k_gap,
+                        int mode, const float* scale, hipStream_t stream);
+int launch_fold_bn(const float* b, const float* gamma, const float* beta, float c, float* scale, float* bias_f, int n,
+                   hipStream_t stream);
+int launch_copy_channels(const float* src, int lds, int s_coff, float* dst, int ldd, int d_coff, long P, int C, float mul,
+                         float add, hipStream_t stream);
+int launch_warp(const float* img, const float* flow, int ldf, int f_coff, float flow_scale, float* out, int N, int H,
+                int W, int C, int* dbg_idx, float* dbg_alpha, hipStream_t stream);
+int launch_cost_volume(const float* c1, const float* wr, float* out, int ldo, int o_coff, int N, int H, int W, int C,
+                       hipStream_t stream);
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+}  // namespace udet

@@ -1,0 +1,160 @@
+// Host-side helpers that turn a TF-style convolution description into ConvParams
+// (tap lists, sub-grids, TF 'SAME' padding) + the weight packing kernels.
+#include "common.h"
+#include "conv_host.h"
+
+namespace udet {
+
+void same_pad(int in, int k, int s, int d, int* before, int* out) {
+  const int o = (in + s - 1) / s;
+  int total = (o - 1) * s + (k - 1) * d + 1 - in;
+  if (total < 0) total = 0;
+  *before = total / 2;
+  *out = o;
+}
+
+static inline int floordiv2(int v) { return v >= 0 ? v / 2 : -((-v + 1) / 2); }
+
+// drop taps that fall outside the input grid for every output position of the launch
+static void push_tap(ConvParams& p, int dy, int dx, int widx) {
+  const int ymax = (p.OHq - 1) * p.isy + dy, xmax = (p.OWq - 1) * p.isx + dx;
+  if (dy >= p.H || ymax < 0 || dx >= p.W || xmax < 0) return;
+  p.taps[p.ntaps].dy = dy;
+  p.taps[p.ntaps].dx = dx;
+  p.taps[p.ntaps].widx = widx;
+  ++p.ntaps;
+}
+
+void conv_setup_fwd(ConvParams& p, int N, int H, int W, int kh, int kw, int s, int d) {
+  int pt, pl, oh, ow;
+  same_pad(H, kh, s, d, &pt, &oh);
+  same_pad(W, kw, s, d, &pl, &ow);
+  p.N = N; p.H = H; p.W = W;
+  p.OH = oh; p.OW = ow; p.OHq = oh; p.OWq = ow;
+  p.osy = p.osx = 1; p.ooy = p.oox = 0;
+  p.isy = p.isx = s;
+  p.ntaps = 0;
+  for (int ky = 0; ky < kh; ++ky)
+    for (int kx = 0; kx < kw; ++kx) push_tap(p, ky * d - pt, kx * d - pl, ky * kw + kx);
+}
+
+int conv_dgrad_classes(int s) { return s == 1 ? 1 : s * s; }
+
+// Backward-data of the SAME conv (N,H,W) --k,s,d--> (N,OHf,OWf); also the forward of
+// tf.layers.conv2d_transpose (k=4,s=2,'same') when called with H=2h, W=2w.
+// The A operand lives on the (OHf,OWf) grid, the result on the (H,W) grid.
+bool conv_setup_dgrad(ConvParams& p, int cls, int N, int H, int W, int kh, int kw, int s, int d) {
+  int pt, pl, ohf, owf;
+  same_pad(H, kh, s, d, &pt, &ohf);
+  same_pad(W, kw, s, d, &pl, &owf);
+  p.N = N; p.H = ohf; p.W = owf;
+  p.OH = H; p.OW = W;
+  p.isy = p.isx = 1;
+  p.ntaps = 0;
+  if (s == 1) {
+    p.OHq = H; p.OWq = W; p.osy = p.osx = 1; p.ooy = p.oox = 0;
+    for (int ky = 0; ky < kh; ++ky)
+      for (int kx = 0; kx < kw; ++kx) push_tap(p, pt - ky * d, pl - kx * d, ky * kw + kx);
+    return p.ntaps > 0;
+  }
+  const int py = cls / s, px = cls % s;  // s == 2
+  p.osy = p.osx = s; p.ooy = py; p.oox = px;
+  p.OHq = (H - py + s - 1) / s;
+  p.OWq = (W - px + s - 1) / s;
+  if (p.OHq <= 0 || p.OWq <= 0) return false;
+  for (int ky = 0; ky < kh; ++ky) {
+    const int vy = py + pt - ky * d;
+    if (((vy % 2) + 2) % 2) continue;
+    for (int kx = 0; kx < kw; ++kx) {
+      const int vx = px + pl - kx * d;
+      if (((vx % 2) + 2) % 2) continue;
+      push_tap(p, floordiv2(vy), floordiv2(vx), ky * kw + kx);
+    }
+  }
+  return true;  // ntaps may be 0: the caller must still write zeros / bias
+}
+
+// ---------------------------------------------------------------------------
+// weight packing: src [T][R][C] (HWIO: R=Cin, C=Cout) -> dst [T][Kc][ldw]
+//   mode 0 (forward):           dst[t][kmap(r)][c] = src[t][r][c] * scale[c]
+//   mode 1 (transposed/dgrad):  dst[t][c][r]       = src[t][r][c] * scale[c]
+// kmap inserts a zero gap of k_gap rows at row k_split (slab padding channels).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ src, float* __restrict__ dst, int T,
+                                                           int R, int C, int Kc, int ldw, int k_split, int k_gap,
+                                                           int mode, const float* __restrict__ scale) {
+  const long total = (long)T * Kc * ldw;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int n = (int)(e % ldw);
+    const int k = (int)((e / ldw) % Kc);
+    const int t = (int)(e / ((long)ldw * Kc));
+    float v = 0.f;
+    if (mode == 0) {
+      int r = k;
+      if (k >= k_split) r = (k < k_split + k_gap) ? -1 : k - k_gap;
+      if (r >= 0 && r < R && n < C) {
+        v = src[((long)t * R + r) * C + n];
+        if (scale) v *= scale[n];
+      }
+    } else {
+      if (k < C && n < R) {
+        v = src[((long)t * R + n) * C + k];
+        if (scale) v *= scale[k];
+      }
+    }
+    dst[e] = v;
+  }
+}
+
+int launch_pack_weights(const float* src, float* dst, int T, int R, int C, int Kc, int ldw, int k_split, int k_gap,
+                        int mode, const float* scale, hipStream_t stream) {
+  const long total = (long)T * Kc * ldw;
+  int nb = (int)((total + 255) / 256);
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(pack_weights_kernel, dim3(nb), dim3(256), 0, stream, src, dst, T, R, C, Kc, ldw, k_split, k_gap,
+                     mode, scale);
+  UDET_HIP(hipGetLastError());
+  return UDET_OK;
+}
+
+// BN (inference, moving stats 0/1) folded into the conv:  scale = gamma*c, bias' = b*gamma*c + beta
+__global__ void fold_bn_kernel(const float* __restrict__ b, const float* __restrict__ gamma, const float* __restrict__ beta,
+                               float c, float* __restrict__ scale, float* __restrict__ bias_f, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const float s = gamma[i] * c;
+    scale[i] = s;
+    bias_f[i] = b[i] * s + beta[i];
+  }
+}
+int launch_fold_bn(const float* b, const float* gamma, const float* beta, float c, float* scale, float* bias_f, int n,
+                   hipStream_t stream) {
+  hipLaunchKernelGGL(fold_bn_kernel, dim3((n + 127) / 128), dim3(128), 0, stream, b, gamma, beta, c, scale, bias_f, n);
+  UDET_HIP(hipGetLastError());
+  return UDET_OK;
+}
+
+// strided channel copy: dst[p][d_coff + c] = src[p][s_coff + c] * mul, c < C
+__global__ __launch_bounds__(256) void copy_channels_kernel(const float* __restrict__ src, int lds, int s_coff,
+                                                            float* __restrict__ dst, int ldd, int d_coff, long P, int C,
+                                                            float mul, float add) {
+  const long total = P * C;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long pix = e / C;
+    const int c = (int)(e - pix * C);
+    dst[pix * ldd + d_coff + c] = src[pix * lds + s_coff + c] * mul + add;
+  }
+}
+int launch_copy_channels(const float* src, int lds, int s_coff, float* dst, int ldd, int d_coff, long P, int C, float mul,
+                         float add, hipStream_t stream) {
+  const long total = P * C;
+  int nb = (int)((total + 255) / 256);
+  if (nb > 4096) nb = 4096;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(copy_channels_kernel, dim3(nb), dim3(256), 0, stream, src, lds, s_coff, dst, ldd, d_coff, P, C, mul,
+                     add);
+  UDET_HIP(hipGetLastError());
+  return UDET_OK;
+}
+
+}  // namespace udet

@@ -1,0 +1,175 @@
+// Bandwidth-bound PWC-Net kernels: dense backward warp and the 81-channel cost volume.
+#include "common.h"
+
+namespace udet {
+
+// ---------------------------------------------------------------------------
+// dense_image_warp  (models/PWCNet/core_warp.py:153-202, _interpolate_bilinear :42-150)
+// One thread per (pixel, 4 channels).  The grid-index math is done with explicitly
+// rounded fp32 operations (no FMA contraction) so that floor/ceil indices and alphas
+// are bit-identical to the reference's float32 graph:
+//   q = grid - flow*scale ; floor = min(max(0,floor(q)), size-2) ; alpha = clamp(q-floor,0,1)
+//   top = ax*(tr-tl)+tl ; bot = ax*(br-bl)+bl ; out = ay*(bot-top)+top
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float lerp_rn(float a, float lo, float hi) {
+  return __fadd_rn(__fmul_rn(a, __fsub_rn(hi, lo)), lo);
+}
+
+__global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ img, const float* __restrict__ flow, int ldf,
+                                                   int f_coff, float flow_scale, float* __restrict__ out, int N, int H,
+                                                   int W, int C, int* __restrict__ dbg_idx, float* __restrict__ dbg_alpha) {
+  const int c4n = C >> 2;
+  const long total = (long)N * H * W * c4n;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int c4 = (int)(e % c4n);
+    const long pix = e / c4n;
+    const int x = (int)(pix % W);
+    const int y = (int)((pix / W) % H);
+    const int n = (int)(pix / ((long)W * H));
+    const float* f = flow + pix * ldf + f_coff;
+    const float fy = __fmul_rn(f[0], flow_scale), fx = __fmul_rn(f[1], flow_scale);
+    const float qy = __fsub_rn((float)y, fy), qx = __fsub_rn((float)x, fx);
+    const float flo_y = fminf(fmaxf(0.f, floorf(qy)), (float)(H - 2));
+    const float flo_x = fminf(fmaxf(0.f, floorf(qx)), (float)(W - 2));
+    const int iy = (int)flo_y, ix = (int)flo_x;
+    const float ay = fminf(fmaxf(0.f, __fsub_rn(qy, flo_y)), 1.f);
+    const float ax = fminf(fmaxf(0.f, __fsub_rn(qx, flo_x)), 1.f);
+    if (dbg_idx && c4 == 0) {
+      dbg_idx[pix * 2 + 0] = iy;
+      dbg_idx[pix * 2 + 1] = ix;
+      dbg_alpha[pix * 2 + 0] = ay;
+      dbg_alpha[pix * 2 + 1] = ax;
+    }
+    const float* base = img + (((long)n * H + iy) * W + ix) * C + c4 * 4;
+    const float4 tl = *reinterpret_cast<const float4*>(base);
+    const float4 tr = *reinterpret_cast<const float4*>(base + C);
+    const float4 bl = *reinterpret_cast<const float4*>(base + (long)W * C);
+    const float4 br = *reinterpret_cast<const float4*>(base + (long)W * C + C);
+    float4 o;
+    o.x = lerp_rn(ay, lerp_rn(ax, tl.x, tr.x), lerp_rn(ax, bl.x, br.x));
+    o.y = lerp_rn(ay, lerp_rn(ax, tl.y, tr.y), lerp_rn(ax, bl.y, br.y));
+    o.z = lerp_rn(ay, lerp_rn(ax, tl.z, tr.z), lerp_rn(ax, bl.z, br.z));
+    o.w = lerp_rn(ay, lerp_rn(ax, tl.w, tr.w), lerp_rn(ax, bl.w, br.w));
+    *reinterpret_cast<float4*>(out + pix * C + c4 * 4) = o;
+  }
+}
+
+int launch_warp(const float* img, const float* flow, int ldf, int f_coff, float flow_scale, float* out, int N, int H,
+                int W, int C, int* dbg_idx, float* dbg_alpha, hipStream_t stream) {
+  if (C % 4 != 0 || H < 2 || W < 2) {
+    set_error("warp: C=%d must be a multiple of 4 and H,W >= 2 (got %dx%d)", C, H, W);
+    return UDET_ERR_SHAPE;
+  }
+  const long total = (long)N * H * W * (C / 4);
+  int nb = (int)((total + 255) / 256);
+  if (nb > 4096) nb = 4096;
+  if (nb < 1) nb = 1;
+  hipLaunchKernelGGL(warp_kernel, dim3(nb), dim3(256), 0, stream, img, flow, ldf, f_coff, flow_scale, out, N, H, W, C,
+                     dbg_idx, dbg_alpha);
+  UDET_HIP(hipGetLastError());
+  return UDET_OK;
+}
+
+// ---------------------------------------------------------------------------
+// cost_volume  (models/PWCNet/core_costvol.py:20-40): out[.., dy*9+dx] =
+//   leaky0.1( mean_c( c1[y,x,c] * warp[y+dy-4, x+dx-4, c] ) ), zero outside.
+// One workgroup per 8x8 pixel tile: the 16x16 halo of `warp` and the 8x8 tile of c1
+// are staged through LDS in 32-channel slices (each input byte is read from HBM once,
+// the 81x re-use happens in LDS); thread (pixel, g) accumulates displacements g, g+4, ...
+// ---------------------------------------------------------------------------
+#define CV_T 8
+#define CV_R 4
+#define CV_HALO (CV_T + 2 * CV_R)
+#define CV_CS 36  // 32-channel slice + 4 pad floats: 144-B pixel stride spreads ds_read_b128 over all 16 slots
+#define CV_ND 21
+
+__global__ __launch_bounds__(256) void cost_volume_kernel(const float* __restrict__ c1, const float* __restrict__ wr,
+                                                          float* __restrict__ out, int ldo, int o_coff, int N, int H,
+                                                          int W, int C) {
+  __shared__ __attribute__((aligned(16))) float sw[CV_HALO * CV_HALO * CV_CS];
+  __shared__ __attribute__((aligned(16))) float s1[CV_T * CV_T * CV_CS];
+  const int t = threadIdx.x;
+  const int tiles_x = (W + CV_T - 1) / CV_T, tiles_y = (H + CV_T - 1) / CV_T;
+  const int bx = blockIdx.x % tiles_x, by = (blockIdx.x / tiles_x) % tiles_y, n = blockIdx.x / (tiles_x * tiles_y);
+  const int y0 = by * CV_T, x0 = bx * CV_T;
+  const int p = t & 63, g = t >> 6;
+  const int py = p >> 3, px = p & 7;
+  float acc[CV_ND];
+#pragma unroll
+  for (int j = 0; j < CV_ND; ++j) acc[j] = 0.f;
+
+  for (int cb = 0; cb < C; cb += 32) {
+    const int cw = min(32, C - cb);  // multiple of 4
+    // stage the halo of warp: 256 pixels x 8 float4
+    for (int e = t; e < CV_HALO * CV_HALO * 8; e += 256) {
+      const int c4 = e & 7, hp = e >> 3;
+      const int hy = hp / CV_HALO, hx = hp - hy * CV_HALO;
+      const int yy = y0 + hy - CV_R, xx = x0 + hx - CV_R;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c4 * 4 < cw && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
+        v = *reinterpret_cast<const float4*>(wr + (((long)n * H + yy) * W + xx) * C + cb + c4 * 4);
+      *reinterpret_cast<float4*>(&sw[hp * CV_CS + c4 * 4]) = v;
+    }
+    for (int e = t; e < CV_T * CV_T * 8; e += 256) {
+      const int c4 = e & 7, tp = e >> 3;
+      const int yy = y0 + (tp >> 3), xx = x0 + (tp & 7);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c4 * 4 < cw && yy < H && xx < W)
+        v = *reinterpret_cast<const float4*>(c1 + (((long)n * H + yy) * W + xx) * C + cb + c4 * 4);
+      *reinterpret_cast<float4*>(&s1[tp * CV_CS + c4 * 4]) = v;
+    }
+    __syncthreads();
+    float4 a[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a[q] = *reinterpret_cast<const float4*>(&s1[p * CV_CS + q * 4]);
+#pragma unroll
+    for (int j = 0; j < CV_ND; ++j) {
+      const int d = g + 4 * j;
+      if (d < 81) {
+        const int dy = d / 9, dx = d - dy * 9;
+        const float* wp = &sw[((py + dy) * CV_HALO + px + dx) * CV_CS];
+        float s = acc[j];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float4 b = *reinterpret_cast<const float4*>(wp + q * 4);
+          s = fmaf(a[q].x, b.x, s);
+          s = fmaf(a[q].y, b.y, s);
+          s = fmaf(a[q].z, b.z, s);
+          s = fmaf(a[q].w, b.w, s);
+        }
+        acc[j] = s;
+      }
+    }
+    __syncthreads();
+  }
+  // results -> LDS [64][81] -> coalesced 81-float rows
+  float* so = sw;  // reuse (64*81 floats < halo buffer)
+#pragma unroll
+  for (int j = 0; j < CV_ND; ++j) {
+    const int d = g + 4 * j;
+    if (d < 81) {
+      float v = acc[j] / (float)C;
+      so[p * 81 + d] = v > 0.f ? v : 0.1f * v;
+    }
+  }
+  __syncthreads();
+  for (int e = t; e < 64 * 81; e += 256) {
+    const int tp = e / 81, d = e - tp * 81;
+    const int yy = y0 + (tp >> 3), xx = x0 + (tp & 7);
+    if (yy < H && xx < W) out[(((long)n * H + yy) * W + xx) * ldo + o_coff + d] = so[e];
+  }
+}
+
+int launch_cost_volume(const float* c1, const float* wr, float* out, int ldo, int o_coff, int N, int H, int W, int C,
+                       hipStream_t stream) {
+  if (C % 4 != 0) {
+    set_error("cost_volume: C=%d must be a multiple of 4", C);
+    return UDET_ERR_SHAPE;
+  }
+  const int tiles = ((W + CV_T - 1) / CV_T) * ((H + CV_T - 1) / CV_T) * N;
+  hipLaunchKernelGGL(cost_volume_kernel, dim3(tiles), dim3(256), 0, stream, c1, wr, out, ldo, o_coff, N, H, W, C);
+  UDET_HIP(hipGetLastError());
+  return UDET_OK;
+}
+
+}  // namespace udet
