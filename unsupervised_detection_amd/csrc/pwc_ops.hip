@@ -11,8 +11,13 @@ namespace udet {
 //   q = grid - flow*scale ; floor = min(max(0,floor(q)), size-2) ; alpha = clamp(q-floor,0,1)
 //   top = ax*(tr-tl)+tl ; bot = ax*(br-bl)+bl ; out = ay*(bot-top)+top
 // ---------------------------------------------------------------------------
+// This translation unit is compiled with -ffp-contract=off (see Makefile): every * + - below
+// rounds separately, exactly like the reference's float32 TF graph.
 __device__ __forceinline__ float lerp_rn(float a, float lo, float hi) {
-  return __fadd_rn(__fmul_rn(a, __fsub_rn(hi, lo)), lo);
+#pragma clang fp contract(off)
+  const float d = hi - lo;
+  const float m = a * d;
+  return m + lo;
 }
 
 __global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ img, const float* __restrict__ flow, int ldf,
@@ -27,13 +32,13 @@ __global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ img
     const int y = (int)((pix / W) % H);
     const int n = (int)(pix / ((long)W * H));
     const float* f = flow + pix * ldf + f_coff;
-    const float fy = __fmul_rn(f[0], flow_scale), fx = __fmul_rn(f[1], flow_scale);
-    const float qy = __fsub_rn((float)y, fy), qx = __fsub_rn((float)x, fx);
+    const float fy = f[0] * flow_scale, fx = f[1] * flow_scale;
+    const float qy = (float)y - fy, qx = (float)x - fx;
     const float flo_y = fminf(fmaxf(0.f, floorf(qy)), (float)(H - 2));
     const float flo_x = fminf(fmaxf(0.f, floorf(qx)), (float)(W - 2));
     const int iy = (int)flo_y, ix = (int)flo_x;
-    const float ay = fminf(fmaxf(0.f, __fsub_rn(qy, flo_y)), 1.f);
-    const float ax = fminf(fmaxf(0.f, __fsub_rn(qx, flo_x)), 1.f);
+    const float ay = fminf(fmaxf(0.f, (qy - flo_y)), 1.f);
+    const float ax = fminf(fmaxf(0.f, (qx - flo_x)), 1.f);
     if (dbg_idx && c4 == 0) {
       dbg_idx[pix * 2 + 0] = iy;
       dbg_idx[pix * 2 + 1] = ix;
