@@ -69,6 +69,71 @@ int udet_conv2d_backward_filter(const float* x, const float* dy, const float* y_
 int udet_conv2d_transpose4x4s2(const float* x, const float* w_hwoi, const float* bias, float* y, int n, int h, int w,
                                int cin, int cout, void* workspace, size_t workspace_bytes, void* stream);
 
+
+/* ---- the step plan ------------------------------------------------------------------------
+ * One plan = one (batch, shapes, flags) specialisation of the graph assembled by
+ * AdversarialLearner.build_train_graph / build_test_graph / build_aug_test_graph
+ * (models/adversarial_learner.py:72-258, 450-523, 525-592).  The caller owns one workspace of
+ * udet_workspace_bytes() bytes (256-byte aligned) that holds packed weights, every activation,
+ * every activation-gradient and all scratch; udet_buffer_info() names its regions so the host
+ * wrapper can view them as tensors without copies.  Weights, gradients and Adam slots are flat
+ * fp32 buffers per network in TF variable order (udet_param_info), owned by the caller; the
+ * gradient buffers are the RCCL all-reduce payload.
+ * net / which: 0 = pwcnet (frozen), 1 = generator "MaskNet", 2 = recover "FlownetS"; which=3 both. */
+typedef struct udet_plan udet_plan;
+typedef struct {
+  int batch;                 /* frame pairs per GPU (common_flags.py:8) */
+  int in_h, in_w;            /* PWC-Net input size: 384 x 640 after the readers' resize (multiples of 64) */
+  int img_h, img_w;          /* generator / recover size: flags img_height/img_width = 192 x 384 */
+  float flow_normalizer;     /* 80   (common_flags.py:10) */
+  float cbn;                 /* 0.5  (common_flags.py:17) */
+  float epsilon;             /* 75   (common_flags.py:18) */
+  float lr, beta1, beta2, adam_eps; /* 1e-4, flag beta1=0.9, 0.999, 1e-8 (adversarial_learner.py:216) */
+  float clip;                /* 0.2  (adversarial_learner.py:227,233) */
+  unsigned long long noise_seed;    /* stream of the escape-noise branch (loss_utils.py:7-10,19-26) */
+} udet_config;
+
+int udet_plan_create(const udet_config* cfg, udet_plan** out);
+void udet_plan_destroy(udet_plan* plan);
+size_t udet_workspace_bytes(const udet_plan* plan);
+/* zero-fills the workspace and uploads the static tables; call once per workspace (synchronises the stream) */
+int udet_plan_init(udet_plan* plan, void* workspace, void* stream);
+
+int udet_param_count(int net);
+size_t udet_param_total(int net);
+int udet_param_info(int net, int index, const char** name, int* rank, int* shape4, size_t* offset_floats);
+int udet_buffer_count(const udet_plan* plan);
+int udet_buffer_info(const udet_plan* plan, int index, const char** name, size_t* offset_bytes, int* dims_nhw_ld);
+
+/* re-layout of the TF-format weights for the kernels (K-padded, BN folded, transposed for dgrad).
+ * pwc: once per checkpoint; trainable: after every optimizer apply (udet_train_step does it). */
+int udet_pack_pwc(udet_plan* plan, const float* w_pwc, void* workspace, void* stream);
+int udet_pack_trainable(udet_plan* plan, const float* w_gen, const float* w_rec, void* workspace, void* stream);
+
+/* ModelPWCNet().predict_from_img_pairs(img1, img2): models/PWCNet/model_pwcnet.py:61-76 -> nn() :599-649.
+ * img1,img2 [B,in_h,in_w,3] in [-0.5,0.5]; result in buffer "flow_full" [B,in_h,in_w,2]. */
+int udet_pwc_forward(udet_plan* plan, const float* img1, const float* img2, void* workspace, void* stream);
+/* adversarial_learner.py:83-204: PWC flow, legacy resize of image/flow, flow/normalizer, generator_net,
+ * `ncalls` recover_net invocations (3 = train graph, 1 = test graph :509-513, 0 = aug-test graph :579),
+ * and (ncalls==3) the 8 entries of losses{} (:196-204) into buffer "losses".
+ * Results: buffers "image","flow","mask","pred" ([ncalls*B,...]). */
+int udet_forward(udet_plan* plan, const float* img1, const float* img2, int ncalls, void* workspace, void* stream);
+/* same but starting from caller-filled "image" and "flow" buffers (generator_net/recover_net surface, nets.py:4,45) */
+int udet_forward_from_flow(udet_plan* plan, int ncalls, void* workspace, void* stream);
+/* optimizer.compute_gradients of losses['generator'] w.r.t. MaskNet and/or losses['recover'] w.r.t. FlownetS
+ * (models/utils/loss_utils.py:18; adversarial_learner.py:211-234) into the flat gradient buffers. */
+int udet_backward(udet_plan* plan, int which, const float* w_gen, const float* w_rec, float* g_gen, float* g_rec,
+                  void* workspace, void* stream);
+/* the rest of train_op (loss_utils.py:19-32): clip +-0.2 / escape noise (generator only), Adam apply with the
+ * shared beta-power accumulators; g is overwritten with the clipped gradient. */
+int udet_apply(udet_plan* plan, int net, float* w, float* g, float* m, float* v, void* workspace, void* stream);
+long udet_get_adam_step(const udet_plan* plan);
+void udet_set_adam_step(udet_plan* plan, long t);
+/* pack + forward + backward + apply for `which` on one GPU (no gradient exchange) */
+int udet_train_step(udet_plan* plan, int which, const float* img1, const float* img2, float* w_gen, float* w_rec,
+                    float* g_gen, float* g_rec, float* m_gen, float* v_gen, float* m_rec, float* v_rec, void* workspace,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

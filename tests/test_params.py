@@ -1,0 +1,60 @@
+"""CPU: libudet.so loads, exports every symbol include/udet.h declares, and its parameter tables agree with the
+oracle's independent restatement of the reference's variable lists."""
+import ctypes
+import os
+import re
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from unsupervised_detection_amd import _ffi
+    hdr = open(os.path.join(ROOT, "include", "udet.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(udet_[a-z0-9_]+)\s*\(", hdr))
+    assert len(names) >= 25
+    for n in sorted(names):
+        assert hasattr(_ffi.lib, n), f"libudet.so does not export {n}"
+    assert _ffi.lib.udet_version() >= 100
+
+
+def test_param_tables_match_oracle():
+    from oracle import oracle_torch as O
+    from unsupervised_detection_amd import weights as W
+    for net, specs in ((W.NET_PWC, O.pwc_param_specs()), (W.NET_GEN, O.generator_param_specs()), (W.NET_REC, O.recover_param_specs())):
+        tab = W.param_table(net)
+        assert [(n, tuple(s)) for n, s, _ in tab] == [(n, tuple(s)) for n, s, _ in specs]
+        off = 0
+        for n, s, o in tab:
+            assert o == off
+            off += int(np.prod(s))
+        assert off == W.param_total(net)
+    assert W.param_total(W.NET_PWC) == 14079050 and W.param_total(W.NET_GEN) == 1451062 and W.param_total(W.NET_REC) == 3388610
+
+
+def test_init_families():
+    from unsupervised_detection_amd import weights as W
+    g = W.as_dict(W.init_flat(W.NET_GEN), W.NET_GEN)
+    assert float(g["MaskNet/conv1/bn/gamma"].min()) == 1.0 and float(g["MaskNet/conv1/bias"].abs().max()) == 0.0
+    k = g["MaskNet/conv5/kernel"]
+    lim = (6.0 / (9 * 128 + 9 * 128)) ** 0.5
+    assert float(k.abs().max()) <= lim and float(k.abs().max()) > 0.9 * lim
+    p = W.as_dict(W.init_flat(W.NET_PWC), W.NET_PWC)
+    k = p["pwcnet/featpyr/conv3aa/kernel"]
+    std = (2.0 / (9 * 64)) ** 0.5 / 0.87962566103423978
+    assert float(k.abs().max()) <= 2 * std + 1e-6 and abs(float(k.std()) - (2.0 / (9 * 64)) ** 0.5) < 0.1 * std
+
+
+def test_plan_rejects_bad_config_without_gpu():
+    from unsupervised_detection_amd import _ffi, engine
+    c = engine._Cfg(4, 100, 640, 192, 384, 80, .5, 75, 1e-4, .9, .999, 1e-8, .2, 1)
+    h = ctypes.c_void_p()
+    assert _ffi.lib.udet_plan_create(ctypes.byref(c), ctypes.byref(h)) != 0
+    assert b"multiples of 64" in _ffi.lib.udet_last_error()
+    c = engine._Cfg(4, 384, 640, 192, 384, 80, .5, 75, 1e-4, .9, .999, 1e-8, .2, 1)
+    assert _ffi.lib.udet_plan_create(ctypes.byref(c), ctypes.byref(h)) == 0
+    gb = _ffi.lib.udet_workspace_bytes(h) / 2 ** 30
+    assert 0.5 < gb < 16, gb
+    _ffi.lib.udet_plan_destroy(h)

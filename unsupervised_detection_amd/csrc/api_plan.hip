@@ -1,0 +1,95 @@
+// extern "C" plan-level surface of libudet.so (see include/udet.h).
+#include <string.h>
+
+#include "plan.h"
+
+using namespace udet;
+
+struct udet_plan {
+  Plan* p;
+};
+
+extern "C" {
+
+int udet_plan_create(const udet_config* c, udet_plan** out) {
+  if (!c || !out) { set_error("plan_create: null argument"); return UDET_ERR_ARG; }
+  Config k;
+  k.batch = c->batch; k.in_h = c->in_h; k.in_w = c->in_w; k.img_h = c->img_h; k.img_w = c->img_w;
+  k.flow_normalizer = c->flow_normalizer; k.cbn = c->cbn; k.epsilon = c->epsilon;
+  k.lr = c->lr; k.beta1 = c->beta1; k.beta2 = c->beta2; k.adam_eps = c->adam_eps; k.clip = c->clip;
+  k.noise_seed = c->noise_seed;
+  Plan* P = plan_build(k);
+  if (!P) return UDET_ERR_SHAPE;
+  *out = new udet_plan{P};
+  return UDET_OK;
+}
+void udet_plan_destroy(udet_plan* h) {
+  if (h) { delete h->p; delete h; }
+}
+size_t udet_workspace_bytes(const udet_plan* h) { return h->p->arena_floats * sizeof(float); }
+int udet_plan_init(udet_plan* h, void* ws, void* stream) { return plan_init_workspace(h->p, (float*)ws, (hipStream_t)stream); }
+
+int udet_param_count(int net) { return (net < 0 || net > 2) ? 0 : (int)net_params(net).p.size(); }
+size_t udet_param_total(int net) { return (net < 0 || net > 2) ? 0 : net_params(net).total; }
+int udet_param_info(int net, int i, const char** name, int* rank, int* shape, size_t* offset) {
+  if (net < 0 || net > 2 || i < 0 || i >= (int)net_params(net).p.size()) { set_error("param_info: out of range"); return UDET_ERR_ARG; }
+  const ParamDesc& d = net_params(net).p[i];
+  *name = d.name.c_str(); *rank = d.rank; *offset = d.offset;
+  for (int k = 0; k < 4; ++k) shape[k] = d.shape[k];
+  return UDET_OK;
+}
+int udet_buffer_count(const udet_plan* h) { return (int)h->p->bufs.size(); }
+int udet_buffer_info(const udet_plan* h, int i, const char** name, size_t* offset_bytes, int* dims) {
+  if (i < 0 || i >= (int)h->p->bufs.size()) { set_error("buffer_info: out of range"); return UDET_ERR_ARG; }
+  const Buf& b = h->p->bufs[i];
+  *name = b.name.c_str(); *offset_bytes = b.off * sizeof(float);
+  dims[0] = b.n; dims[1] = b.h; dims[2] = b.w; dims[3] = b.ld;
+  return UDET_OK;
+}
+long udet_get_adam_step(const udet_plan* h) { return h->p->adam_t; }
+void udet_set_adam_step(udet_plan* h, long t) { h->p->adam_t = t; }
+
+int udet_pack_pwc(udet_plan* h, const float* w_pwc, void* ws, void* stream) {
+  return plan_pack_pwc(h->p, w_pwc, (float*)ws, (hipStream_t)stream);
+}
+int udet_pack_trainable(udet_plan* h, const float* w_gen, const float* w_rec, void* ws, void* stream) {
+  return plan_pack_trainable(h->p, w_gen, w_rec, (float*)ws, (hipStream_t)stream);
+}
+int udet_pwc_forward(udet_plan* h, const float* img1, const float* img2, void* ws, void* stream) {
+  return plan_pwc_forward(h->p, img1, img2, (float*)ws, (hipStream_t)stream);
+}
+int udet_forward_from_flow(udet_plan* h, int ncalls, void* ws_, void* stream) {
+  float* ws = (float*)ws_;
+  hipStream_t s = (hipStream_t)stream;
+  if (ncalls < 0 || ncalls > 3) { set_error("forward: ncalls must be 0..3"); return UDET_ERR_ARG; }
+  UDET_TRY(plan_generator_forward(h->p, ws, s));
+  UDET_TRY(plan_recover_forward(h->p, ncalls, ws, s));
+  if (ncalls == 3) UDET_TRY(plan_losses(h->p, ws, s));
+  return UDET_OK;
+}
+int udet_forward(udet_plan* h, const float* img1, const float* img2, int ncalls, void* ws, void* stream) {
+  UDET_TRY(plan_pwc_forward(h->p, img1, img2, (float*)ws, (hipStream_t)stream));
+  UDET_TRY(plan_prepare(h->p, img1, (float*)ws, (hipStream_t)stream));
+  return udet_forward_from_flow(h, ncalls, ws, stream);
+}
+int udet_backward(udet_plan* h, int which, const float* w_gen, const float* w_rec, float* g_gen, float* g_rec, void* ws,
+                  void* stream) {
+  if (which < 1 || which > 3) { set_error("backward: which must be 1 (generator), 2 (recover) or 3 (both)"); return UDET_ERR_ARG; }
+  if (which & 2) UDET_TRY(plan_backward_recover(h->p, w_rec, g_rec, (float*)ws, (hipStream_t)stream));
+  if (which & 1) UDET_TRY(plan_backward_generator(h->p, w_gen, g_gen, (float*)ws, (hipStream_t)stream));
+  return UDET_OK;
+}
+int udet_apply(udet_plan* h, int net, float* w, float* g, float* m, float* v, void* ws, void* stream) {
+  return plan_apply(h->p, net, w, g, m, v, (float*)ws, (hipStream_t)stream);
+}
+int udet_train_step(udet_plan* h, int which, const float* img1, const float* img2, float* w_gen, float* w_rec, float* g_gen,
+                    float* g_rec, float* m_gen, float* v_gen, float* m_rec, float* v_rec, void* ws, void* stream) {
+  UDET_TRY(udet_pack_trainable(h, w_gen, w_rec, ws, stream));
+  UDET_TRY(udet_forward(h, img1, img2, 3, ws, stream));
+  UDET_TRY(udet_backward(h, which, w_gen, w_rec, g_gen, g_rec, ws, stream));
+  if (which & 1) UDET_TRY(udet_apply(h, NET_GEN, w_gen, g_gen, m_gen, v_gen, ws, stream));
+  if (which & 2) UDET_TRY(udet_apply(h, NET_REC, w_rec, g_rec, m_rec, v_rec, ws, stream));
+  return UDET_OK;
+}
+
+}  // extern "C"

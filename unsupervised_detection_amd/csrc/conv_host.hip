@@ -89,18 +89,12 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
     const int k = (int)((e / ldw) % Kc);
     const int t = (int)(e / ((long)ldw * Kc));
     float v = 0.f;
-    if (mode == 0) {
-      int r = k;
-      if (k >= k_split) r = (k < k_split + k_gap) ? -1 : k - k_gap;
-      if (r >= 0 && r < R && n < C) {
-        v = src[((long)t * R + r) * C + n];
-        if (scale) v *= scale[n];
-      }
-    } else {
-      if (k < C && n < R) {
-        v = src[((long)t * R + n) * C + k];
-        if (scale) v *= scale[k];
-      }
+    int ks = k;  // source index of packed row k (-1 inside the zero gap)
+    if (k >= k_split) ks = (k < k_split + k_gap) ? -1 : k - k_gap;
+    const int r = mode == 0 ? ks : n, c = mode == 0 ? n : ks;
+    if (r >= 0 && r < R && c >= 0 && c < C) {
+      v = src[((long)t * R + r) * C + c];
+      if (scale) v *= scale[c];
     }
     dst[e] = v;
   }

@@ -1,0 +1,28 @@
+#pragma once
+#include "common.h"
+namespace udet {
+int launch_resize_bilinear_fwd(const float* x, int ldx, int x_coff, int N, int H, int W, float* y, int ldy, int y_coff,
+                               int OH, int OW, int C, float mul, float div, hipStream_t s);
+int launch_resize_bilinear_bwd(const float* dy, int ldy, int y_coff, int N, int OH, int OW, float* dx, int ldx, int x_coff,
+                               int H, int W, int C, int accumulate, hipStream_t s);
+int launch_pool2x2_sum(const float* du, float* dx, int N, int H, int W, int C, hipStream_t s);
+int launch_pack_pwc_input(const float* i1, const float* i2, float* x8, long P, hipStream_t s);
+int launch_gen_input(const float* img, const float* f, double* part, float* gin, int B, long HW, hipStream_t s);
+size_t flow_stats_doubles(int B);
+int launch_mask_rec_inputs(const float* logits, const float* img, const float* f, float* mask, float* fin, float* imgin,
+                           long P, int ncalls, hipStream_t s);
+int launch_losses(const float* f, const float* mask, const float* pred, long HW, int B, float cbn, float eps,
+                  float num_pixels, float* part, float* losses, float* coef, float* sums, hipStream_t s);
+size_t loss_part_floats(int B);
+int launch_rec_loss_bwd(const float* f, const float* mask, const float* pred, float* dpred, long BHW, float cbn,
+                        float inv_np, hipStream_t s);
+int launch_gen_loss_bwd(const float* f, const float* mask, const float* pred, const float* coef, float* dpred,
+                        float* dmask, long HW, int B, float cbn, hipStream_t s);
+int launch_mask_bwd(const float* dmask, const float* dfin, const float* f, const float* mask, float* dlogits, long P,
+                    hipStream_t s);
+int launch_grad_absmean(const float* g, const long* seg_off, const long* seg_len, int nvars, float* vmean, float thresh,
+                        float* out, hipStream_t s);
+int launch_adam(float* w, float* g, float* m, float* v, long n, float lr_t, float b1, float b2, float eps, float clip,
+                const float* flag, uint64_t seed, uint64_t step, hipStream_t s);
+int launch_axpy(const float* x, float* y, long n, float a, int accumulate, hipStream_t s);
+}  // namespace udet

@@ -1,0 +1,97 @@
+// The step plan: static, shape-specialised description of the hot path
+// (PWC-Net forward -> resize -> generator -> 3x recover -> losses -> two backward passes -> clipped Adam)
+// over one pre-laid-out workspace.  See DESIGN.md.
+#pragma once
+#include <map>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace udet {
+
+struct ParamDesc {
+  std::string name;
+  int rank;
+  int shape[4];
+  size_t offset, count;  // in floats, inside the net's flat weight buffer
+};
+struct NetParams {
+  std::vector<ParamDesc> p;
+  size_t total = 0;
+  int add(const std::string& name, int a, int b = 0, int c = 0, int d = 0);
+  int find(const std::string& name) const;
+};
+enum { NET_PWC = 0, NET_GEN = 1, NET_REC = 2 };
+const NetParams& net_params(int net);
+
+struct Buf {
+  std::string name;
+  size_t off;  // floats from the workspace base
+  int n, h, w, ld;
+  size_t floats() const { return (size_t)n * h * w * ld; }
+};
+
+struct Layer {
+  std::string name;
+  int net;
+  int kh, kw, cin, cout, stride, dil;
+  bool transposed = false;  // tf.layers.conv2d_transpose (k4 s2)
+  bool up = false;          // NN x2 upsample fused into the loader
+  int act = ACT_NONE;
+  float alpha = 0.f;
+  int w_idx = -1, b_idx = -1, g_idx = -1, be_idx = -1;
+  // forward packing
+  int Kc = 0, ldw = 0, k_split = 0, k_gap = 0;
+  size_t wp_off = 0;
+  // transposed packing for the backward-data pass (trainable nets)
+  int KcT = 0, ldwT = 0;
+  size_t wpT_off = 0;
+  size_t bias_f_off = 0, scale_off = 0;  // BN-folded bias / per-channel scale (generator)
+  // tensors
+  int x = -1, x_coff = 0, y = -1, y_coff = 0;
+  int res = -1, res_coff = 0, y2 = -1;
+  int H = 0, W = 0;  // stored input grid
+};
+
+struct Config {
+  int batch, in_h, in_w, img_h, img_w;
+  float flow_normalizer, cbn, epsilon;
+  float lr, beta1, beta2, adam_eps, clip;
+  unsigned long long noise_seed;
+};
+
+struct Plan {
+  Config cfg;
+  std::vector<Buf> bufs;
+  std::map<std::string, int> buf_by_name;
+  std::vector<Layer> pwc, gen, rec;
+  size_t packed_floats = 0;      // packed-weight region (start of the workspace)
+  size_t arena_floats = 0;       // everything
+  size_t scratch_off = 0, scratch_floats = 0;   // split-K slabs
+  size_t wgrad_off = 0, wgrad_floats = 0;       // wgrad partials
+  size_t small_off = 0;          // losses, coefficients, flags, reduction partials
+  size_t seg_off[3] = {0, 0, 0}; // per-variable (offset,len) tables on device (as long)
+  long adam_t = 0;               // number of optimizer applies so far (shared beta powers)
+  bool pwc_packed = false;
+  int add_buf(const std::string& name, int n, int h, int w, int ld);
+  const Buf& buf(int id) const { return bufs[id]; }
+  int bid(const std::string& name) const;
+};
+
+Plan* plan_build(const Config& cfg);
+
+// execution (all asynchronous on `s`)
+int plan_init_workspace(Plan* P, float* ws, hipStream_t s);
+int plan_pack_pwc(Plan* P, const float* w_pwc, float* ws, hipStream_t s);
+int plan_pack_trainable(Plan* P, const float* w_gen, const float* w_rec, float* ws, hipStream_t s);
+int plan_pwc_forward(Plan* P, const float* img1, const float* img2, float* ws, hipStream_t s);
+int plan_prepare(Plan* P, const float* img1, float* ws, hipStream_t s);
+int plan_generator_forward(Plan* P, float* ws, hipStream_t s);
+int plan_recover_forward(Plan* P, int ncalls, float* ws, hipStream_t s);
+int plan_losses(Plan* P, float* ws, hipStream_t s);
+int plan_backward_recover(Plan* P, const float* w_rec, float* g_rec, float* ws, hipStream_t s);
+int plan_backward_generator(Plan* P, const float* w_gen, float* g_gen, float* ws, hipStream_t s);
+int plan_apply(Plan* P, int net, float* w, float* g, float* m, float* v, float* ws, hipStream_t s);
+
+}  // namespace udet

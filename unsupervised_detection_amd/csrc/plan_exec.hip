@@ -1,0 +1,402 @@
+// Plan execution: enqueues the kernels of one step on the caller's stream.
+//
+// Reference being replaced: the single sess.run of models/adversarial_learner.py:396 over the graph
+// built by build_train_graph (:72-258) / build_test_graph (:450-523).
+#include <math.h>
+#include <string.h>
+
+#include "conv_host.h"
+#include "elementwise.h"
+#include "plan.h"
+
+namespace udet {
+
+static const float BN_C = 0.99950037468777316f;  // 1/sqrt(1+1e-3): inference-mode BN with moving stats (0,1)
+
+static const Layer* find_layer(const std::vector<Layer>& v, const std::string& name) {
+  for (const auto& L : v)
+    if (L.name == name) return &L;
+  return nullptr;
+}
+static std::string S(const char* fmt, int a, int b = 0) {
+  char buf[128];
+  snprintf(buf, sizeof(buf), fmt, a, b);
+  return buf;
+}
+
+// ------------------------------------------------------------- runners ----
+static void fill_common(Plan* P, ConvParams& p, float* ws) {
+  p.partial = ws + P->scratch_off;
+  p.partial_cap = P->scratch_floats;
+}
+
+static int run_fwd(Plan* P, const Layer& L, int N, float* ws, hipStream_t s, size_t x_extra = 0, size_t y_extra = 0) {
+  const Buf &bx = P->buf(L.x), &by = P->buf(L.y);
+  const int ncls = L.transposed ? 4 : 1;
+  for (int cls = 0; cls < ncls; ++cls) {
+    ConvParams p;
+    memset(&p, 0, sizeof(p));
+    if (L.transposed) {
+      if (!conv_setup_dgrad(p, cls, N, 2 * L.H, 2 * L.W, L.kh, L.kw, 2, 1)) continue;
+    } else {
+      conv_setup_fwd(p, N, L.H << (L.up ? 1 : 0), L.W << (L.up ? 1 : 0), L.kh, L.kw, L.stride, L.dil);
+      p.up_shift = L.up ? 1 : 0;
+    }
+    p.x = ws + bx.off + x_extra; p.ldx = bx.ld; p.x_coff = L.x_coff;
+    p.wp = ws + L.wp_off; p.Kc = L.Kc; p.ldw = L.ldw; p.bias = ws + L.bias_f_off;
+    p.y = ws + by.off + y_extra; p.ldy = by.ld; p.y_coff = L.y_coff; p.Cout = L.cout;
+    p.act = L.act; p.alpha = L.alpha;
+    if (L.res >= 0) { p.res = ws + P->buf(L.res).off; p.ldres = P->buf(L.res).ld; p.res_coff = L.res_coff; }
+    if (L.y2 >= 0) { p.y2 = ws + P->buf(L.y2).off; p.ldy2 = P->buf(L.y2).ld; p.y2_coff = 0; }
+    fill_common(P, p, ws);
+    UDET_TRY(launch_conv(p, s));
+  }
+  return UDET_OK;
+}
+
+// gradient w.r.t. the layer input: dX(dx buffer) (=|+=) conv_T(dY * act'(saved output)) [+ res]
+static int run_dgrad(Plan* P, const Layer& L, int N, int dy, int dx, int dx_coff, int accumulate, int res, float* ws,
+                     hipStream_t s) {
+  const int act_buf = L.y2 >= 0 ? L.y2 : L.y;
+  const Buf &bdy = P->buf(dy), &bdx = P->buf(dx), &ba = P->buf(act_buf);
+  if (ba.ld != bdy.ld) {
+    set_error("dgrad(%s): gradient/activation layout mismatch (%d vs %d)", L.name.c_str(), bdy.ld, ba.ld);
+    return UDET_ERR_SHAPE;
+  }
+  const int up = L.up ? 1 : 0;
+  for (int cls = 0; cls < conv_dgrad_classes(L.stride); ++cls) {
+    ConvParams p;
+    memset(&p, 0, sizeof(p));
+    if (!conv_setup_dgrad(p, cls, N, L.H << up, L.W << up, L.kh, L.kw, L.stride, L.dil)) continue;
+    p.x = ws + bdy.off; p.ldx = bdy.ld; p.x_coff = L.y_coff;
+    if (L.act != ACT_NONE) { p.xa = ws + ba.off; p.xact = L.act; p.xalpha = L.alpha; }
+    p.wp = ws + L.wpT_off; p.Kc = L.KcT; p.ldw = L.ldwT;
+    p.y = ws + bdx.off; p.ldy = bdx.ld; p.y_coff = dx_coff; p.Cout = L.cin;
+    p.accumulate = accumulate;
+    if (res >= 0) { p.res = ws + P->buf(res).off; p.ldres = P->buf(res).ld; p.res_coff = 0; }
+    fill_common(P, p, ws);
+    UDET_TRY(launch_conv(p, s));
+  }
+  return UDET_OK;
+}
+
+static int run_wgrad(Plan* P, const Layer& L, int N, int dy, const float* w_flat, float* g_flat, float* ws, hipStream_t s) {
+  const NetParams& np = net_params(L.net);
+  const int act_buf = L.y2 >= 0 ? L.y2 : L.y;
+  const Buf &bx = P->buf(L.x), &bdy = P->buf(dy), &ba = P->buf(act_buf);
+  const int up = L.up ? 1 : 0;
+  ConvParams g;
+  memset(&g, 0, sizeof(g));
+  conv_setup_fwd(g, N, L.H << up, L.W << up, L.kh, L.kw, L.stride, L.dil);
+  WgradParams q;
+  memset(&q, 0, sizeof(q));
+  q.x = ws + bx.off; q.ldx = bx.ld; q.x_coff = L.x_coff;
+  q.N = N; q.H = L.H << up; q.W = L.W << up; q.up_shift = up; q.Cin = L.cin;
+  q.dy = ws + bdy.off; q.ldy = bdy.ld; q.y_coff = L.y_coff; q.Cout = L.cout;
+  if (L.act != ACT_NONE) { q.ya = ws + ba.off; q.yact = L.act; q.yalpha = L.alpha; }
+  q.OH = g.OH; q.OW = g.OW; q.isy = q.isx = L.stride;
+  q.ntaps = g.ntaps;
+  memcpy(q.taps, g.taps, sizeof(g.taps));
+  q.dw = g_flat + np.p[L.w_idx].offset;
+  q.db = g_flat + np.p[L.b_idx].offset;
+  q.partial = ws + P->wgrad_off;
+  q.partial_floats = P->wgrad_floats;
+  if (L.g_idx >= 0) {
+    q.w = w_flat + np.p[L.w_idx].offset;
+    q.b = w_flat + np.p[L.b_idx].offset;
+    q.gamma = w_flat + np.p[L.g_idx].offset;
+    q.dgamma = g_flat + np.p[L.g_idx].offset;
+    q.dbeta = g_flat + np.p[L.be_idx].offset;
+    q.bn_c = BN_C;
+  }
+  return launch_wgrad_T(q, L.kh * L.kw, s);
+}
+
+// ------------------------------------------------------- init / packing ----
+int plan_init_workspace(Plan* P, float* ws, hipStream_t s) {
+  UDET_HIP(hipMemsetAsync(ws, 0, P->arena_floats * sizeof(float), s));
+  for (int net = 1; net <= 2; ++net) {
+    const NetParams& np = net_params(net);
+    std::vector<long> tab(2 * np.p.size());
+    for (size_t i = 0; i < np.p.size(); ++i) {
+      tab[i] = (long)np.p[i].offset;
+      tab[np.p.size() + i] = (long)np.p[i].count;
+    }
+    UDET_HIP(hipMemcpyAsync(ws + P->seg_off[net], tab.data(), tab.size() * sizeof(long), hipMemcpyHostToDevice, s));
+    UDET_HIP(hipStreamSynchronize(s));  // `tab` is a host temporary
+  }
+  P->pwc_packed = false;
+  return UDET_OK;
+}
+
+static int pack_layer(const Layer& L, const float* w_flat, float* ws, const float* scale, bool trainable, hipStream_t s) {
+  const NetParams& np = net_params(L.net);
+  const float* w = w_flat + np.p[L.w_idx].offset;
+  const int T = L.kh * L.kw;
+  if (L.transposed)  // weights are [t][cout][cin]
+    UDET_TRY(launch_pack_weights(w, ws + L.wp_off, T, L.cout, L.cin, L.Kc, L.ldw, L.k_split, L.k_gap, 1, nullptr, s));
+  else
+    UDET_TRY(launch_pack_weights(w, ws + L.wp_off, T, L.cin, L.cout, L.Kc, L.ldw, L.k_split, L.k_gap, 0, scale, s));
+  if (trainable)
+    UDET_TRY(launch_pack_weights(w, ws + L.wpT_off, T, L.cin, L.cout, L.KcT, L.ldwT, L.KcT, 0, 1, scale, s));
+  return UDET_OK;
+}
+
+int plan_pack_pwc(Plan* P, const float* w, float* ws, hipStream_t s) {
+  const NetParams& np = net_params(NET_PWC);
+  for (const auto& L : P->pwc) {
+    UDET_TRY(pack_layer(L, w, ws, nullptr, false, s));
+    UDET_TRY(launch_copy_channels(w + np.p[L.b_idx].offset, L.cout, 0, ws + L.bias_f_off, L.cout, 0, 1, L.cout, 1.f, 0.f, s));
+  }
+  P->pwc_packed = true;
+  return UDET_OK;
+}
+
+int plan_pack_trainable(Plan* P, const float* w_gen, const float* w_rec, float* ws, hipStream_t s) {
+  if (w_gen) {
+    const NetParams& np = net_params(NET_GEN);
+    for (const auto& L : P->gen) {
+      UDET_TRY(launch_fold_bn(w_gen + np.p[L.b_idx].offset, w_gen + np.p[L.g_idx].offset, w_gen + np.p[L.be_idx].offset, BN_C,
+                              ws + L.scale_off, ws + L.bias_f_off, L.cout, s));
+      UDET_TRY(pack_layer(L, w_gen, ws, ws + L.scale_off, true, s));
+    }
+  }
+  if (w_rec) {
+    const NetParams& np = net_params(NET_REC);
+    for (const auto& L : P->rec) {
+      UDET_TRY(pack_layer(L, w_rec, ws, nullptr, true, s));
+      UDET_TRY(launch_copy_channels(w_rec + np.p[L.b_idx].offset, L.cout, 0, ws + L.bias_f_off, L.cout, 0, 1, L.cout, 1.f, 0.f, s));
+    }
+  }
+  return UDET_OK;
+}
+
+// ------------------------------------------------------------ PWC-Net ----
+static const int PWC_CH[7] = {0, 16, 32, 64, 96, 128, 196};
+
+int plan_pwc_forward(Plan* P, const float* img1, const float* img2, float* ws, hipStream_t s) {
+  if (!P->pwc_packed) {
+    set_error("pwc_forward: call udet_pack_pwc first");
+    return UDET_ERR_ARG;
+  }
+  const Config& c = P->cfg;
+  const int B = c.batch;
+  UDET_TRY(launch_pack_pwc_input(img1, img2, ws + P->buf(P->bid("pwc.x8")).off, (long)B * c.in_h * c.in_w, s));
+  // siamese feature pyramid on the 2B stacked images (model_pwcnet.py:149-168)
+  for (int l = 1; l <= 6; ++l)
+    for (const char* suf : {"a", "aa", "b"}) {
+      char nm[64];
+      snprintf(nm, sizeof(nm), "pwcnet/featpyr/conv%d%s", l, suf);
+      UDET_TRY(run_fwd(P, *find_layer(P->pwc, nm), 2 * B, ws, s));
+    }
+  for (int l = 6; l >= 2; --l) {
+    const int h = c.in_h >> l, w = c.in_w >> l, C = PWC_CH[l];
+    const Buf& cb = P->buf(P->bid(S("pwc.c%d", l)));
+    const Buf& slab = P->buf(P->bid(S("pwc.slab%d", l)));
+    const float* c1 = ws + cb.off;
+    const float* c2 = ws + cb.off + (size_t)B * h * w * C;
+    const float* second = c2;
+    if (l != 6) {
+      // warp(c2, up_flow * 20/2^l)  (model_pwcnet.py:616-617)
+      float* wr = ws + P->buf(P->bid(S("pwc.warp%d", l))).off;
+      UDET_TRY(launch_warp(c2, ws + slab.off, slab.ld, 532 + C, 20.0f / (float)(1 << l), wr, B, h, w, C, nullptr, nullptr, s));
+      second = wr;
+      UDET_TRY(launch_copy_channels(c1, C, 0, ws + slab.off, slab.ld, 532, (long)B * h * w, C, 1.f, 0.f, s));
+    }
+    UDET_TRY(launch_cost_volume(c1, second, ws + slab.off, slab.ld, 448, B, h, w, C, s));
+    for (int i = 0; i < 5; ++i) UDET_TRY(run_fwd(P, *find_layer(P->pwc, S("pwcnet/predict_flow/conv%d_%d", l, i)), B, ws, s));
+    UDET_TRY(run_fwd(P, *find_layer(P->pwc, S("pwcnet/predict_flow/flow%d", l)), B, ws, s));
+    for (int i = 1; i <= 7; ++i) UDET_TRY(run_fwd(P, *find_layer(P->pwc, S("pwcnet/ctxt/dc_conv%d%d", l, i)), B, ws, s));
+    if (l != 2) {
+      UDET_TRY(run_fwd(P, *find_layer(P->pwc, S("pwcnet/upsample/up_flow%d", l)), B, ws, s));
+      UDET_TRY(run_fwd(P, *find_layer(P->pwc, S("pwcnet/upsample/up_feat%d", l)), B, ws, s));
+    }
+  }
+  // flow_pred = resize_bilinear(flow2, x4) * 4   (model_pwcnet.py:641-646)
+  const Buf& fr = P->buf(P->bid("pwc.rflow2"));
+  const Buf& ff = P->buf(P->bid("flow_full"));
+  return launch_resize_bilinear_fwd(ws + fr.off, fr.ld, 0, B, fr.h, fr.w, ws + ff.off, 2, 0, c.in_h, c.in_w, 2, 4.0f, 1.f, s);
+}
+
+// image/flow -> img_h x img_w, flow / flow_normalizer  (adversarial_learner.py:87-97)
+int plan_prepare(Plan* P, const float* img1, float* ws, hipStream_t s) {
+  const Config& c = P->cfg;
+  const Buf& ff = P->buf(P->bid("flow_full"));
+  UDET_TRY(launch_resize_bilinear_fwd(img1, 3, 0, c.batch, c.in_h, c.in_w, ws + P->buf(P->bid("image")).off, 3, 0, c.img_h,
+                                      c.img_w, 3, 1.f, 1.f, s));
+  return launch_resize_bilinear_fwd(ws + ff.off, 2, 0, c.batch, c.in_h, c.in_w, ws + P->buf(P->bid("flow")).off, 2, 0, c.img_h,
+                                    c.img_w, 2, 1.f, c.flow_normalizer, s);
+}
+
+// --------------------------------------------------- generator / recover ----
+int plan_generator_forward(Plan* P, float* ws, hipStream_t s) {
+  const Config& c = P->cfg;
+  const long HW = (long)c.img_h * c.img_w;
+  double* part = reinterpret_cast<double*>(ws + P->small_off + 4096);
+  UDET_TRY(launch_gen_input(ws + P->buf(P->bid("image")).off, ws + P->buf(P->bid("flow")).off, part,
+                            ws + P->buf(P->bid("gen.in")).off, c.batch, HW, s));
+  for (const auto& L : P->gen) UDET_TRY(run_fwd(P, L, c.batch, ws, s));
+  return UDET_OK;
+}
+
+static int rec_resize(Plan* P, const char* src, const char* dst, int N, float* ws, hipStream_t s) {
+  const Buf &a = P->buf(P->bid(src)), &b = P->buf(P->bid(dst));
+  return launch_resize_bilinear_fwd(ws + a.off, a.ld, 0, N, a.h, a.w, ws + b.off, b.ld, 0, b.h, b.w, a.ld, 1.f, 1.f, s);
+}
+
+// mask, recover inputs, `ncalls` batched recover invocations (nets.py:45-110; adversarial_learner.py:107-131)
+int plan_recover_forward(Plan* P, int ncalls, float* ws, hipStream_t s) {
+  const Config& c = P->cfg;
+  const int B = c.batch, N = ncalls * B;
+  const long Ppix = (long)B * c.img_h * c.img_w;
+  UDET_TRY(launch_mask_rec_inputs(ws + P->buf(P->bid("gen.a17")).off, ws + P->buf(P->bid("image")).off,
+                                  ws + P->buf(P->bid("flow")).off, ws + P->buf(P->bid("mask")).off,
+                                  ws + P->buf(P->bid("rec.fin")).off, ws + P->buf(P->bid("rec.imgin")).off, Ppix, ncalls, s));
+  if (ncalls < 1) return UDET_OK;
+  const char* enc[9] = {"conv1", "conv2", "conv3", "conv31", "conv4", "conv41", "conv5", "conv51", "conv6"};
+  for (const char* e : {"a", "b"})
+    for (int i = 0; i < 9; ++i) UDET_TRY(run_fwd(P, *find_layer(P->rec, std::string(e) + enc[i]), N, ws, s));
+  for (int k = 5; k >= 1; --k) {
+    UDET_TRY(rec_resize(P, k == 5 ? "rec.conv6" : S("rec.concat%d", k + 1).c_str(), S("rec.r%d", k + 1).c_str(), N, ws, s));
+    UDET_TRY(run_fwd(P, *find_layer(P->rec, S("deconv%d", k)), N, ws, s));
+    if (k < 5) {
+      UDET_TRY(rec_resize(P, S("rec.flow%d", k + 1).c_str(), S("rec.rf%d", k + 1).c_str(), N, ws, s));
+      UDET_TRY(run_fwd(P, *find_layer(P->rec, S("upflow%d", k)), N, ws, s));
+    }
+    UDET_TRY(run_fwd(P, *find_layer(P->rec, S("flow%d", k)), N, ws, s));
+  }
+  const Buf& f1 = P->buf(P->bid("rec.flow1"));
+  return launch_resize_bilinear_fwd(ws + f1.off, f1.ld, 0, N, f1.h, f1.w, ws + P->buf(P->bid("pred")).off, 2, 0, c.img_h,
+                                    c.img_w, 2, 1.f, 1.f, s);
+}
+
+// small region layout (floats from small_off): [0,8) losses, [16,16+4B) coef, [256,258) noise flag,
+// [512,..) per-variable |g| means, [1024,1024+5B) sums, [4096,..) flow-stat partials (doubles), [8192,..) loss partials
+int plan_losses(Plan* P, float* ws, hipStream_t s) {
+  const Config& c = P->cfg;
+  float* sm = ws + P->small_off;
+  const long HW = (long)c.img_h * c.img_w;
+  return launch_losses(ws + P->buf(P->bid("flow")).off, ws + P->buf(P->bid("mask")).off, ws + P->buf(P->bid("pred")).off, HW,
+                       c.batch, c.cbn, c.epsilon, (float)(c.img_w * c.img_h * c.batch), sm + 8192, sm, sm + 16, sm + 1024, s);
+}
+
+// ------------------------------------------------------------ backward ----
+// Recover decoder/encoder backward for the first N samples of the batched calls, seeded by d.pred.
+// with_wgrad: also produce parameter gradients into g_rec.  need_dfin: propagate to the b-encoder input.
+static int rec_backward(Plan* P, int N, bool with_wgrad, bool need_dfin, const float* w_rec, float* g_rec, float* ws,
+                        hipStream_t s) {
+  const Config& c = P->cfg;
+  auto B_ = [&](const std::string& n) { return P->bid(n); };
+  auto Lr = [&](const std::string& n) { return find_layer(P->rec, n); };
+  // pred = resize(flow1)
+  {
+    const Buf& df1 = P->buf(B_("rec.d.flow1"));
+    UDET_TRY(launch_resize_bilinear_bwd(ws + P->buf(B_("d.pred")).off, 2, 0, N, c.img_h, c.img_w, ws + df1.off, df1.ld, 0, df1.h,
+                                        df1.w, 2, 0, s));
+  }
+  for (int k = 1; k <= 5; ++k) {
+    const int dconcat = B_(S("rec.d.concat%d", k));
+    const Layer* fl = Lr(S("flow%d", k));
+    // concat_k feeds flow_k (and, for k<5 .. handled below, the resize of the next finer level wrote it first)
+    UDET_TRY(run_dgrad(P, *fl, N, B_(S("rec.d.flow%d", k)), dconcat, 0, k == 1 ? 0 : 1, -1, ws, s));
+    if (with_wgrad) UDET_TRY(run_wgrad(P, *fl, N, B_(S("rec.d.flow%d", k)), w_rec, g_rec, ws, s));
+    if (k < 5) {
+      const Layer* uf = Lr(S("upflow%d", k));
+      if (with_wgrad) UDET_TRY(run_wgrad(P, *uf, N, dconcat, w_rec, g_rec, ws, s));
+      UDET_TRY(run_dgrad(P, *uf, N, dconcat, B_(S("rec.d.rf%d", k + 1)), 0, 0, -1, ws, s));
+      const Buf &drf = P->buf(B_(S("rec.d.rf%d", k + 1))), &dfn = P->buf(B_(S("rec.d.flow%d", k + 1)));
+      UDET_TRY(launch_resize_bilinear_bwd(ws + drf.off, drf.ld, 0, N, drf.h, drf.w, ws + dfn.off, dfn.ld, 0, dfn.h, dfn.w, 2, 0, s));
+    }
+    const Layer* dc = Lr(S("deconv%d", k));
+    if (with_wgrad) UDET_TRY(run_wgrad(P, *dc, N, dconcat, w_rec, g_rec, ws, s));
+    const int dr = B_(S("rec.d.r%d", k + 1));
+    UDET_TRY(run_dgrad(P, *dc, N, dconcat, dr, 0, 0, -1, ws, s));
+    const Buf& bdr = P->buf(dr);
+    const Buf& dsrc = P->buf(k == 5 ? B_("rec.d.conv6") : B_(S("rec.d.concat%d", k + 1)));
+    UDET_TRY(launch_resize_bilinear_bwd(ws + bdr.off, bdr.ld, 0, N, bdr.h, bdr.w, ws + dsrc.off, dsrc.ld, 0, dsrc.h, dsrc.w,
+                                        bdr.ld, 0, s));
+  }
+  // encoders, deepest first.  gradient buffers mirror the forward buffers of each conv's output / input.
+  const char* enc[9] = {"conv1", "conv2", "conv3", "conv31", "conv4", "conv41", "conv5", "conv51", "conv6"};
+  for (int i = 8; i >= 0; --i)
+    for (const char* e : {"a", "b"}) {
+      const Layer* L = Lr(std::string(e) + enc[i]);
+      const int dy = B_("rec.d." + P->buf(L->y).name.substr(4));
+      if (with_wgrad) UDET_TRY(run_wgrad(P, *L, N, dy, w_rec, g_rec, ws, s));
+      if (i == 0) {
+        if (e[0] == 'b' && need_dfin) UDET_TRY(run_dgrad(P, *L, N, dy, B_("rec.d.fin"), 0, 0, -1, ws, s));
+        continue;
+      }
+      const std::string xname = P->buf(L->x).name;
+      const int dx = B_("rec.d." + xname.substr(4));
+      const bool slab_in = xname.find("concat") != std::string::npos;  // slab inputs already hold the decoder's gradient
+      UDET_TRY(run_dgrad(P, *L, N, dy, dx, L->x_coff, slab_in ? 1 : 0, -1, ws, s));
+    }
+  return UDET_OK;
+}
+
+int plan_backward_recover(Plan* P, const float* w_rec, float* g_rec, float* ws, hipStream_t s) {
+  const Config& c = P->cfg;
+  const long BHW = (long)c.batch * c.img_h * c.img_w;
+  UDET_TRY(launch_rec_loss_bwd(ws + P->buf(P->bid("flow")).off, ws + P->buf(P->bid("mask")).off, ws + P->buf(P->bid("pred")).off,
+                               ws + P->buf(P->bid("d.pred")).off, BHW, c.cbn, 1.0f / (float)(c.img_w * c.img_h * c.batch), s));
+  return rec_backward(P, 3 * c.batch, true, false, w_rec, g_rec, ws, s);
+}
+
+int plan_backward_generator(Plan* P, const float* w_gen, float* g_gen, float* ws, hipStream_t s) {
+  const Config& c = P->cfg;
+  const int B = c.batch;
+  const long HW = (long)c.img_h * c.img_w;
+  float* sm = ws + P->small_off;
+  auto B_ = [&](const std::string& n) { return P->bid(n); };
+  UDET_TRY(launch_gen_loss_bwd(ws + P->buf(B_("flow")).off, ws + P->buf(B_("mask")).off, ws + P->buf(B_("pred")).off, sm + 16,
+                               ws + P->buf(B_("d.pred")).off, ws + P->buf(B_("d.mask")).off, HW, B, c.cbn, s));
+  UDET_TRY(rec_backward(P, 2 * B, false, true, nullptr, nullptr, ws, s));
+  UDET_TRY(launch_mask_bwd(ws + P->buf(B_("d.mask")).off, ws + P->buf(B_("rec.d.fin")).off, ws + P->buf(B_("flow")).off,
+                           ws + P->buf(B_("mask")).off, ws + P->buf(B_("gen.d17")).off, B * HW, s));
+  // generator, last layer first.  gen.d{k} = gradient w.r.t. layer k's (post-skip) output.
+  for (int i = 16; i >= 0; --i) {
+    const Layer& L = P->gen[i];
+    const int dy = B_(S("gen.d%d", i + 1));
+    UDET_TRY(run_wgrad(P, L, B, dy, w_gen, g_gen, ws, s));
+    if (i == 0) break;
+    // skip gradients: x2 = a6 (+ d11), x1 = a3 (+ d14), x0 = a1 (+ d15)   (nets.py:29,32,33)
+    int res = -1;
+    if (i == 6) res = B_("gen.d11");
+    if (i == 3) res = B_("gen.d14");
+    if (i == 1) res = B_("gen.d15");
+    const int dx = B_(S("gen.d%d", i));
+    if (L.up) {
+      const int dup = B_(S("gen.dup%d", i + 1));
+      UDET_TRY(run_dgrad(P, L, B, dy, dup, 0, 0, -1, ws, s));
+      const Buf& bd = P->buf(dx);
+      UDET_TRY(launch_pool2x2_sum(ws + P->buf(dup).off, ws + bd.off, B, bd.h, bd.w, bd.ld, s));
+    } else {
+      UDET_TRY(run_dgrad(P, L, B, dy, dx, 0, 0, res, ws, s));
+    }
+  }
+  return UDET_OK;
+}
+
+// ------------------------------------------------------------ optimizer ----
+int plan_apply(Plan* P, int net, float* w, float* g, float* m, float* v, float* ws, hipStream_t s) {
+  if (net != NET_GEN && net != NET_REC) {
+    set_error("apply: net must be 1 (generator) or 2 (recover)");
+    return UDET_ERR_ARG;
+  }
+  const Config& c = P->cfg;
+  const NetParams& np = net_params(net);
+  float* sm = ws + P->small_off;
+  const float* flag = nullptr;
+  if (net == NET_GEN) {  // can_change=True (adversarial_learner.py:224-228)
+    const long* tab = reinterpret_cast<const long*>(ws + P->seg_off[net]);
+    UDET_TRY(launch_grad_absmean(g, tab, tab + np.p.size(), (int)np.p.size(), sm + 512, 1e-5f, sm + 256, s));
+    flag = sm + 256;
+  }
+  const long t = ++P->adam_t;  // ONE optimizer object: beta powers advance on every apply (:216)
+  const double lr_t = (double)c.lr * sqrt(1.0 - pow((double)c.beta2, (double)t)) / (1.0 - pow((double)c.beta1, (double)t));
+  return launch_adam(w, g, m, v, (long)np.total, (float)lr_t, c.beta1, c.beta2, c.adam_eps, c.clip, flag, c.noise_seed,
+                     (uint64_t)t, s);
+}
+
+}  // namespace udet
