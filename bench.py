@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""Benchmark of the adversarial_learner hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+One step = PWC-Net flow + mask-generator fwd + 3x recover fwd + generator-loss backward + recover-loss backward +
+both clipped-Adam updates on 4 DAVIS-480p-shaped synthetic frame pairs per GPU (BASELINE.json configs[1]/[2]).
+Inputs are resident in HBM (reader preprocessing done before the timed region).  Prints ONE JSON line."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALG_GFLOP_PER_PAIR = 217.945  # 871.78 GFLOP per 4-pair step (fwd 551.06 + gen bwd 210.35 + rec bwd 110.36)
+PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md chip table
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(batch: int, reps: int, threads: int = 0):
+    """The oracle (PyTorch-CPU restatement, oracle/oracle_torch.py) timed on the host cores: a bounded sample of
+    the same workload -- `reps` full adversarial steps (fwd + both backward + clipped Adam) at batch `batch`."""
+    from oracle import oracle_torch as O
+    from unsupervised_detection_amd import data
+    import numpy as np
+    # measured on the MI355X host (256 logical CPUs), B=1: 16 threads 2.36 pairs/s, 32 -> 1.47, 64 -> 0.59: use 16
+    cores = threads or min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    pp = O.init_params(O.pwc_param_specs(), 8964)
+    pg = O.init_params(O.generator_param_specs(), 8965)
+    pr = O.init_params(O.recover_param_specs(), 8966)
+    f1, f2 = data.synthetic_davis_pairs(batch, 8964, 384, 640)  # generated directly at the reader's output size
+    i1 = torch.from_numpy(f1.astype(np.float32) / 255.0 - 0.5)
+    i2 = torch.from_numpy(f2.astype(np.float32) / 255.0 - 0.5)
+
+    class C(O.Flags):
+        batch_size = batch
+    opt = O.TFAdam()
+    times = []
+    for r in range(reps + 1):
+        for d in (pg, pr):
+            for k in d:
+                d[k] = d[k].detach().requires_grad_(True)
+        t0 = time.time()
+        with torch.no_grad():
+            image, flow, _ = O.prepare_inputs(pp, i1, i2, C)
+        out = O.forward_from_flow(pg, pr, image, flow, C)
+        gg = O.grads_of(out["generator"], pg)
+        gr = O.grads_of(out["recover"], pr)
+        with torch.no_grad():
+            cg, _ = O.clip_or_noise(gg, 0.2, True, lambda k, s: torch.rand(s) * 0.4 - 0.2)
+            cr, _ = O.clip_or_noise(gr, 0.2, False)
+            pgd = {k: v.detach() for k, v in pg.items()}
+            prd = {k: v.detach() for k, v in pr.items()}
+            opt.apply(pgd, cg)
+            opt.apply(prd, cr)
+            pg, pr = pgd, prd
+        if r > 0:
+            times.append(time.time() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": batch / med, "unit": "frame-pairs/s", "cores": cores, "kind": "port",
+            "sample": f"{reps} full adversarial steps (PWC fwd + gen fwd + 3x recover fwd + both backward + clipped Adam) at "
+                      f"batch {batch}, 384x640 -> 192x384, median; PyTorch-CPU oracle with {cores} threads "
+                      "(TF-1.13 itself is not installable here)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=4, help="frame pairs per GPU (BASELINE.json: 4)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-reps", type=int, default=5)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 "
+                             "--master-port 29500 bench.py --gpus %d ..." % (args.gpus, args.gpus))
+        raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    torch.cuda.set_device(local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from unsupervised_detection_amd import data
+    from unsupervised_detection_amd.engine import BOTH, Engine, EngineConfig
+    from unsupervised_detection_amd.trainer import TrainState, train_step
+
+    eng = Engine(EngineConfig(batch_size=args.batch), device=f"cuda:{local_rank}")
+    st = TrainState(eng, seed=8964)  # identical weights on every rank
+    f1, f2 = data.synthetic_davis_pairs(args.batch, 8964 + rank)  # distinct data per rank (weak scaling)
+    img1 = data.preprocess_image(torch.from_numpy(f1).cuda())
+    img2 = data.preprocess_image(torch.from_numpy(f2).cuda())
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        train_step(st, img1, img2, BOTH)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        train_step(st, img1, img2, BOTH)
+    barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    ms = dt / args.steps * 1e3
+    pairs_per_s = args.batch * world * args.steps / dt
+    losses = eng.losses()
+
+    # per-kernel-category timing with HIP events on the launch stream (one extra, untimed step)
+    prof = eng.profile(lambda: train_step(st, img1, img2, BOTH)) if rank == 0 else None
+
+    if rank == 0:
+        conv_ms = sum(prof[c]["ms"] for c in ("conv_fwd", "conv_dgrad", "conv_wgrad"))
+        conv_groups = sum(prof[c]["groups"] for c in ("conv_fwd", "conv_dgrad", "conv_wgrad"))
+        alg_flops = ALG_GFLOP_PER_PAIR * 1e9 * args.batch
+        achieved = alg_flops / (conv_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel / conv_wgrad_kernel (v_mfma_f32_32x32x2_f32), all launches of one step",
+                    "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                    "launch_groups_per_step": int(conv_groups), "avg_group_ms": round(conv_ms / conv_groups, 4),
+                    "alg_gflop_per_step": round(alg_flops / 1e9, 2), "conv_ms_per_step": round(conv_ms, 3)}
+        hbm = {}
+        for c in ("warp", "cost_volume"):
+            p = prof[c]
+            gbs = p["bytes"] / (p["ms"] * 1e-3) / 1e9 if p["ms"] > 0 else 0.0
+            hbm[c] = {"alg_MB_per_step": round(p["bytes"] / 1e6, 2), "ms_per_step": round(p["ms"], 4), "launches": int(p["groups"]),
+                      "achieved_GBs": round(gbs, 1), "frac_of_8TBs": round(gbs / PEAK_HBM_GBS, 4)}
+        out = {
+            "metric": "frame-pairs/sec per adversarial step, DAVIS 480p batch4, 1/2/4/8 GPU",
+            "value": round(pairs_per_s, 3), "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic (DAVIS-480p-shaped pairs, reader preprocessing applied before timing; random-init weights)",
+            "config": {"workload": "BASELINE.json configs[%d]: DAVIS2016 480p -> 384x640 (PWC) -> 192x384, batch %d/GPU, "
+                                   "PWC flow + generator + 3x inpainter fwd + both backward + clipped Adam" % (1 if world == 1 else 2, args.batch),
+                       "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                       "alg_gflop_per_pair": ALG_GFLOP_PER_PAIR},
+            "step_tflops_algorithmic": round(alg_flops * world / (ms * 1e-3) / 1e12, 2),
+            "roofline": roofline, "hbm_kernels": hbm,
+            "profile_ms_per_step": {k: round(v["ms"], 3) for k, v in prof.items()},
+            "losses": {k: round(v, 5) for k, v in losses.items()},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.batch, args.cpu_reps)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

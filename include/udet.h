@@ -47,6 +47,12 @@ int udet_warp_debug(const float* image, const float* flow, float flow_scale, flo
 /* cost_volume(c1, warp, search_range=4) incl. leaky 0.1: models/PWCNet/core_costvol.py:20-40. out [n,h,w,81] */
 int udet_cost_volume(const float* c1, const float* warp, float* out, int n, int h, int w, int c, void* stream);
 
+/* tf.image.resize_images(x,[oh,ow]) / tf.image.resize_bilinear, TF-1.13 legacy sampling (align_corners=False, no
+ * half-pixel centres): models/adversarial_learner.py:87-90, models/nets.py:108, models/utils/convolution_utils.py:88,
+ * data/davis2016_data_utils.py:86-91.  x [n,h,w,c] -> y [n,oh,ow,c]; bwd is its exact adjoint (dy [n,oh,ow,c] -> dx). */
+int udet_resize_bilinear_legacy_fwd(const float* x, float* y, int n, int h, int w, int c, int oh, int ow, void* stream);
+int udet_resize_bilinear_legacy_bwd(const float* dy, float* dx, int n, int h, int w, int c, int oh, int ow, void* stream);
+
 /* tf.nn.conv2d / tf.layers.conv2d, padding='SAME', + bias + activation
  * (models/utils/convolution_utils.py:46,81-84; models/PWCNet/model_pwcnet.py:161-165,484-504,562-574).
  * upsample2x != 0 first applies tf.image.resize_nearest_neighbor(x2, align_corners=True)
@@ -133,6 +139,12 @@ void udet_set_adam_step(udet_plan* plan, long t);
 int udet_train_step(udet_plan* plan, int which, const float* img1, const float* img2, float* w_gen, float* w_rec,
                     float* g_gen, float* g_rec, float* m_gen, float* v_gen, float* m_rec, float* v_rec, void* workspace,
                     void* stream);
+
+/* Measurement aid (bench.py): between begin/end every convolution / warp / cost-volume launch group is
+ * bracketed by HIP events on the launch stream.  out[cat*4 + {0,1,2,3}] = {groups, total ms, algorithmic
+ * FLOPs, algorithmic bytes} for cat 0 conv fwd, 1 conv dgrad, 2 conv wgrad, 3 warp, 4 cost volume. */
+int udet_profile_begin(udet_plan* plan);
+int udet_profile_end(udet_plan* plan, double* out, int ncat, void* stream);
 
 #ifdef __cplusplus
 }

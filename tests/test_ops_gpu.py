@@ -133,3 +133,17 @@ def test_bad_arguments_raise(ops):
         ops.dense_image_warp(x, torch.zeros(1, 4, 4, 2, device="cuda"))  # C % 4 != 0
     with pytest.raises(ValueError):
         ops.conv2d(x, torch.zeros(3, 3, 8, 4, device="cuda"))  # channel mismatch
+
+
+@pytest.mark.parametrize("h,w,oh,ow,c", [(384, 640, 192, 384, 3), (96, 160, 384, 640, 2), (6, 12, 12, 24, 8), (7, 9, 11, 5, 3),
+                                         (480, 854, 384, 640, 3)])
+def test_resize_bilinear_legacy(ops, h, w, oh, ow, c):
+    x = rnd(2, h, w, c, seed=20)
+    y = ops.resize_bilinear_legacy(x.cuda(), oh, ow).cpu()
+    ref = O.resize_bilinear_legacy(x, oh, ow)
+    assert torch.equal(y, ref)  # same float32 op order, no contraction -> bit-exact
+    xd = x.double().requires_grad_(True)
+    dy = rnd(2, oh, ow, c, seed=21)
+    (O.resize_bilinear_legacy(xd, oh, ow) * dy.double()).sum().backward()
+    dx = ops.resize_bilinear_legacy_backward(dy.cuda(), h, w).cpu()
+    assert (dx - xd.grad.float()).abs().max() < 1e-5

@@ -38,6 +38,8 @@ def _sig(name, restype, *argtypes):
 _sig("udet_warp", c_i, c_p, c_p, c_f, c_p, c_i, c_i, c_i, c_i, c_p)
 _sig("udet_warp_debug", c_i, c_p, c_p, c_f, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p)
 _sig("udet_cost_volume", c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p)
+_sig("udet_resize_bilinear_legacy_fwd", c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p)
+_sig("udet_resize_bilinear_legacy_bwd", c_i, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p)
 _sig("udet_conv2d_workspace_bytes", c_sz, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i)
 _sig("udet_conv2d", c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_sz, c_p)
 _sig("udet_conv2d_backward_data", c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p,

@@ -5,6 +5,7 @@
 #include "../../include/udet.h"
 #include "common.h"
 #include "conv_host.h"
+#include "elementwise.h"
 
 namespace udet {
 static thread_local char g_err[512] = "";
@@ -53,6 +54,15 @@ int udet_warp_debug(const float* image, const float* flow, float flow_scale, flo
 }
 int udet_cost_volume(const float* c1, const float* warp, float* out, int n, int h, int w, int c, void* stream) {
   return launch_cost_volume(c1, warp, out, 81, 0, n, h, w, c, (hipStream_t)stream);
+}
+
+int udet_resize_bilinear_legacy_fwd(const float* x, float* y, int n, int h, int w, int c, int oh, int ow, void* stream) {
+  if (n < 1 || h < 1 || w < 1 || c < 1 || oh < 1 || ow < 1) { set_error("resize: bad shape"); return UDET_ERR_SHAPE; }
+  return launch_resize_bilinear_fwd(x, c, 0, n, h, w, y, c, 0, oh, ow, c, 1.f, 1.f, (hipStream_t)stream);
+}
+int udet_resize_bilinear_legacy_bwd(const float* dy, float* dx, int n, int h, int w, int c, int oh, int ow, void* stream) {
+  if (n < 1 || h < 1 || w < 1 || c < 1 || oh < 1 || ow < 1) { set_error("resize: bad shape"); return UDET_ERR_SHAPE; }
+  return launch_resize_bilinear_bwd(dy, c, 0, n, oh, ow, dx, c, 0, h, w, c, 0, (hipStream_t)stream);
 }
 
 size_t udet_conv2d_workspace_bytes(int n, int h, int w, int cin, int cout, int kh, int kw, int upsample2x) {

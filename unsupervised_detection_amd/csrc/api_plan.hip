@@ -92,4 +92,32 @@ int udet_train_step(udet_plan* h, int which, const float* img1, const float* img
   return UDET_OK;
 }
 
+/* profiling: per-category HIP-event timing of the conv / warp / cost-volume launches */
+int udet_profile_begin(udet_plan* h) {
+  h->p->prof.clear();
+  h->p->profiling = true;
+  return UDET_OK;
+}
+/* out[cat][4] = {launch groups, total ms, algorithmic flops, algorithmic bytes}; synchronises the stream */
+int udet_profile_end(udet_plan* h, double* out, int ncat, void* stream) {
+  Plan* P = h->p;
+  P->profiling = false;
+  UDET_HIP(hipStreamSynchronize((hipStream_t)stream));
+  for (int i = 0; i < ncat * 4; ++i) out[i] = 0.0;
+  for (auto& r : P->prof) {
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, r.a, r.b);
+    if (r.cat < ncat) {
+      out[r.cat * 4 + 0] += 1.0;
+      out[r.cat * 4 + 1] += ms;
+      out[r.cat * 4 + 2] += r.flops;
+      out[r.cat * 4 + 3] += r.bytes;
+    }
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  P->prof.clear();
+  return UDET_OK;
+}
+
 }  // extern "C"

@@ -24,6 +24,31 @@ static std::string S(const char* fmt, int a, int b = 0) {
   return buf;
 }
 
+// ------------------------------------------------------------ profiling ----
+void prof_begin(Plan* P, int cat, double flops, double bytes, hipStream_t s) {
+  if (!P->profiling) return;
+  Plan::ProfRec r;
+  r.cat = cat; r.flops = flops; r.bytes = bytes;
+  (void)hipEventCreate(&r.a);
+  (void)hipEventCreate(&r.b);
+  (void)hipEventRecord(r.a, s);
+  P->prof.push_back(r);
+}
+void prof_end(Plan* P, hipStream_t s) {
+  if (!P->profiling) return;
+  (void)hipEventRecord(P->prof.back().b, s);
+}
+// algorithmic FLOPs of the convolution a layer stands for (2*MACs, unpadded channels)
+static double layer_flops(const Layer& L, int N) {
+  const int up = L.up ? 1 : 0;
+  double oh, ow;
+  if (L.transposed) { oh = 2.0 * L.H; ow = 2.0 * L.W; }
+  else { oh = (double)(((L.H << up) + L.stride - 1) / L.stride); ow = (double)(((L.W << up) + L.stride - 1) / L.stride); }
+  double taps = (double)L.kh * L.kw;
+  if (L.transposed) taps /= 4.0;  // each output pixel of a k4 s2 transposed conv sees 2x2 taps
+  return 2.0 * N * oh * ow * L.cout * L.cin * taps;
+}
+
 // ------------------------------------------------------------- runners ----
 static void fill_common(Plan* P, ConvParams& p, float* ws) {
   p.partial = ws + P->scratch_off;
@@ -33,6 +58,7 @@ static void fill_common(Plan* P, ConvParams& p, float* ws) {
 static int run_fwd(Plan* P, const Layer& L, int N, float* ws, hipStream_t s, size_t x_extra = 0, size_t y_extra = 0) {
   const Buf &bx = P->buf(L.x), &by = P->buf(L.y);
   const int ncls = L.transposed ? 4 : 1;
+  prof_begin(P, PROF_CONV_FWD, layer_flops(L, N), 0, s);
   for (int cls = 0; cls < ncls; ++cls) {
     ConvParams p;
     memset(&p, 0, sizeof(p));
@@ -51,6 +77,7 @@ static int run_fwd(Plan* P, const Layer& L, int N, float* ws, hipStream_t s, siz
     fill_common(P, p, ws);
     UDET_TRY(launch_conv(p, s));
   }
+  prof_end(P, s);
   return UDET_OK;
 }
 
@@ -64,6 +91,7 @@ static int run_dgrad(Plan* P, const Layer& L, int N, int dy, int dx, int dx_coff
     return UDET_ERR_SHAPE;
   }
   const int up = L.up ? 1 : 0;
+  prof_begin(P, PROF_CONV_DGRAD, layer_flops(L, N), 0, s);
   for (int cls = 0; cls < conv_dgrad_classes(L.stride); ++cls) {
     ConvParams p;
     memset(&p, 0, sizeof(p));
@@ -77,6 +105,7 @@ static int run_dgrad(Plan* P, const Layer& L, int N, int dy, int dx, int dx_coff
     fill_common(P, p, ws);
     UDET_TRY(launch_conv(p, s));
   }
+  prof_end(P, s);
   return UDET_OK;
 }
 
@@ -109,7 +138,10 @@ static int run_wgrad(Plan* P, const Layer& L, int N, int dy, const float* w_flat
     q.dbeta = g_flat + np.p[L.be_idx].offset;
     q.bn_c = BN_C;
   }
-  return launch_wgrad_T(q, L.kh * L.kw, s);
+  prof_begin(P, PROF_CONV_WGRAD, layer_flops(L, N), 0, s);
+  const int rc = launch_wgrad_T(q, L.kh * L.kw, s);
+  prof_end(P, s);
+  return rc;
 }
 
 // ------------------------------------------------------- init / packing ----
@@ -199,11 +231,15 @@ int plan_pwc_forward(Plan* P, const float* img1, const float* img2, float* ws, h
     if (l != 6) {
       // warp(c2, up_flow * 20/2^l)  (model_pwcnet.py:616-617)
       float* wr = ws + P->buf(P->bid(S("pwc.warp%d", l))).off;
+      prof_begin(P, PROF_WARP, 0, (double)B * h * w * (2.0 * C + 2.0) * 4.0, s);  // read c2 + flow, write warped
       UDET_TRY(launch_warp(c2, ws + slab.off, slab.ld, 532 + C, 20.0f / (float)(1 << l), wr, B, h, w, C, nullptr, nullptr, s));
+      prof_end(P, s);
       second = wr;
       UDET_TRY(launch_copy_channels(c1, C, 0, ws + slab.off, slab.ld, 532, (long)B * h * w, C, 1.f, 0.f, s));
     }
+    prof_begin(P, PROF_CORR, 2.0 * B * h * w * 81.0 * C, (double)B * h * w * (2.0 * C + 81.0) * 4.0, s);  // read c1 + warped, write 81 ch
     UDET_TRY(launch_cost_volume(c1, second, ws + slab.off, slab.ld, 448, B, h, w, C, s));
+    prof_end(P, s);
     for (int i = 0; i < 5; ++i) UDET_TRY(run_fwd(P, *find_layer(P->pwc, S("pwcnet/predict_flow/conv%d_%d", l, i)), B, ws, s));
     UDET_TRY(run_fwd(P, *find_layer(P->pwc, S("pwcnet/predict_flow/flow%d", l)), B, ws, s));
     for (int i = 1; i <= 7; ++i) UDET_TRY(run_fwd(P, *find_layer(P->pwc, S("pwcnet/ctxt/dc_conv%d%d", l, i)), B, ws, s));

@@ -42,6 +42,11 @@ for _n, _a in (("udet_pack_pwc", [c_p, c_p, c_p, c_p]), ("udet_pack_trainable", 
     getattr(lib, _n).restype = c_i
     getattr(lib, _n).argtypes = _a
 
+lib.udet_profile_begin.restype = c_i
+lib.udet_profile_begin.argtypes = [c_p]
+lib.udet_profile_end.restype = c_i
+lib.udet_profile_end.argtypes = [c_p, ctypes.POINTER(ctypes.c_double), c_i, c_p]
+
 GEN, REC, BOTH = 1, 2, 3
 LOSS_KEYS = ("generator", "recover", "red_rate", "red_rate_compl", "reconstruction_loss", "reconstruction_compl_loss",
              "denominator_red_rate", "denominator_red_rate_compl")  # models/adversarial_learner.py:196-204
@@ -150,6 +155,17 @@ class Engine:
     def train_step(self, which, img1, img2, w_gen, w_rec, g_gen, g_rec, m_gen, v_gen, m_rec, v_rec):
         check(lib.udet_train_step(self._h, which, _ptr(img1), _ptr(img2), _ptr(w_gen), _ptr(w_rec), _ptr(g_gen), _ptr(g_rec),
                                   _ptr(m_gen), _ptr(v_gen), _ptr(m_rec), _ptr(v_rec), self.ws.data_ptr(), self._stream()))
+
+    def profile(self, fn):
+        """Run fn() with per-category HIP-event timing (udet_profile_begin/end). Returns {category: {...}}."""
+        cats = ("conv_fwd", "conv_dgrad", "conv_wgrad", "warp", "cost_volume")
+        check(lib.udet_profile_begin(self._h))
+        try:
+            fn()
+        finally:
+            out = (ctypes.c_double * (4 * len(cats)))()
+            check(lib.udet_profile_end(self._h, out, len(cats), self._stream()))
+        return {c: dict(groups=out[4 * i], ms=out[4 * i + 1], flops=out[4 * i + 2], bytes=out[4 * i + 3]) for i, c in enumerate(cats)}
 
     @property
     def adam_step(self):

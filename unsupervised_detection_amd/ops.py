@@ -123,3 +123,22 @@ def conv2d_transpose4x4s2(x, w_hwoi, bias=None):
     check(lib.udet_conv2d_transpose4x4s2(x.data_ptr(), w_hwoi.data_ptr(), bias.data_ptr() if bias is not None else None,
                                          y.data_ptr(), n, h, w, cin, cout, ws.data_ptr(), ws.numel(), _stream()))
     return y
+
+
+def resize_bilinear_legacy(x, out_h: int, out_w: int):
+    """tf.image.resize_images(x, [out_h, out_w]) with TF-1.13 legacy bilinear sampling."""
+    _chk(x, "x")
+    n, h, w, c = x.shape
+    if (h, w) == (out_h, out_w):
+        return x
+    y = torch.empty((n, out_h, out_w, c), dtype=torch.float32, device=x.device)
+    check(lib.udet_resize_bilinear_legacy_fwd(x.data_ptr(), y.data_ptr(), n, h, w, c, out_h, out_w, _stream()))
+    return y
+
+
+def resize_bilinear_legacy_backward(dy, in_h: int, in_w: int):
+    _chk(dy, "dy")
+    n, oh, ow, c = dy.shape
+    dx = torch.empty((n, in_h, in_w, c), dtype=torch.float32, device=dy.device)
+    check(lib.udet_resize_bilinear_legacy_bwd(dy.data_ptr(), dx.data_ptr(), n, in_h, in_w, c, oh, ow, _stream()))
+    return dx

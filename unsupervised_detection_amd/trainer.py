@@ -1,0 +1,65 @@
+"""Device-side training state + the data-parallel step.
+
+One process per GPU.  Every op of the path is per-sample except the two batch means of the losses
+(models/adversarial_learner.py:167-172,184,191), so grad(global batch B*R) = mean_r grad(local batch B):
+the only exchange is one all-reduce(avg) per network over its flat gradient buffer (RCCL over xGMI when
+the process group backend is "nccl"; gloo in the CPU tests of the host logic), followed by the identical
+clip / escape-noise / Adam on every rank (noise from a counter-based stream keyed by (seed, step, index))."""
+from __future__ import annotations
+
+import torch
+
+from . import weights as W
+from .engine import BOTH, GEN, REC, Engine, EngineConfig
+
+
+class TrainState:
+    """Flat fp32 parameter / gradient / Adam-slot buffers of the two trainable networks + frozen PWC-Net."""
+
+    def __init__(self, engine: Engine, seed: int = 8964, w_pwc=None, w_gen=None, w_rec=None):
+        dev = engine.device
+        self.engine = engine
+        self.w_pwc = (w_pwc if w_pwc is not None else W.init_flat(W.NET_PWC, seed)).to(dev)
+        self.w_gen = (w_gen if w_gen is not None else W.init_flat(W.NET_GEN, seed)).to(dev)
+        self.w_rec = (w_rec if w_rec is not None else W.init_flat(W.NET_REC, seed)).to(dev)
+        self.g_gen, self.g_rec = torch.zeros_like(self.w_gen), torch.zeros_like(self.w_rec)
+        self.m_gen, self.v_gen = torch.zeros_like(self.w_gen), torch.zeros_like(self.w_gen)
+        self.m_rec, self.v_rec = torch.zeros_like(self.w_rec), torch.zeros_like(self.w_rec)
+        engine.pack_pwc(self.w_pwc)
+        engine.pack_trainable(self.w_gen, self.w_rec)
+
+
+def allreduce_mean_(t: torch.Tensor, group=None, async_op=False):
+    """In-place mean over the data-parallel group (no-op without an initialised process group)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return None
+    if dist.get_backend(group) == "nccl":
+        return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group, async_op=async_op)
+    work = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=False)
+    t.div_(dist.get_world_size(group))
+    return work if async_op else None
+
+
+def train_step(st: TrainState, img1, img2, which: int = BOTH, group=None):
+    """One adversarial step on this rank's frame pairs: PWC flow + generator fwd + 3x recover fwd + the
+    backward pass(es) of `which` + gradient all-reduce + clipped Adam.
+    which=REC / GEN reproduce train_recover_op / train_generator_op (adversarial_learner.py:224-234);
+    which=BOTH computes both gradients from one forward (the benchmark's "both backward" step)."""
+    e = st.engine
+    e.pack_trainable(st.w_gen if which & GEN else None, st.w_rec if which & REC else None)
+    e.forward(img1, img2, 3)
+    works = []
+    if which & REC:
+        e.backward(REC, st.w_gen, st.w_rec, st.g_gen, st.g_rec)
+        works.append(allreduce_mean_(st.g_rec, group, async_op=True))  # overlaps the generator backward
+    if which & GEN:
+        e.backward(GEN, st.w_gen, st.w_rec, st.g_gen, st.g_rec)
+        works.append(allreduce_mean_(st.g_gen, group, async_op=True))
+    for wk in works:
+        if wk is not None:
+            wk.wait()
+    if which & GEN:
+        e.apply(W.NET_GEN, st.w_gen, st.g_gen, st.m_gen, st.v_gen)
+    if which & REC:
+        e.apply(W.NET_REC, st.w_rec, st.g_rec, st.m_rec, st.v_rec)
