@@ -126,6 +126,12 @@ int udet_pwc_forward(udet_plan* plan, const float* img1, const float* img2, void
 int udet_forward(udet_plan* plan, const float* img1, const float* img2, int ncalls, void* workspace, void* stream);
 /* same but starting from caller-filled "image" and "flow" buffers (generator_net/recover_net surface, nets.py:4,45) */
 int udet_forward_from_flow(udet_plan* plan, int ncalls, void* workspace, void* stream);
+/* generator_net(images, flows) alone (models/nets.py:4-42): reads "image","flow", writes "mask" (flow standardisation
+ * of models/utils/flow_utils.py:5-12 included). */
+int udet_generator_forward(udet_plan* plan, void* workspace, void* stream);
+/* recover_net(img1, flow_masked, mask) alone (models/nets.py:45-110) on n*B samples whose inputs the caller packed into
+ * "rec.imgin" ([.,.,.,8]: image, 0..) and "rec.fin" ([.,.,.,8]: flow_masked(2), 1, 1-mask, 0..); writes "pred". */
+int udet_recover_forward(udet_plan* plan, int n, void* workspace, void* stream);
 /* optimizer.compute_gradients of losses['generator'] w.r.t. MaskNet and/or losses['recover'] w.r.t. FlownetS
  * (models/utils/loss_utils.py:18; adversarial_learner.py:211-234) into the flat gradient buffers. */
 int udet_backward(udet_plan* plan, int which, const float* w_gen, const float* w_rec, float* g_gen, float* g_rec,

@@ -1,0 +1,89 @@
+"""GPU: the reference's Python surface (AdversarialLearner / functional API) over libudet.so."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle_torch as O  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return True
+
+
+class _Src:
+    def __init__(self, batch, n, hw=(128, 192)):
+        self.batch, self.n, self.hw = batch, n, hw
+
+    def __iter__(self):
+        g = torch.Generator().manual_seed(1)
+        for i in range(self.n):
+            a = torch.rand(self.batch, *self.hw, 3, generator=g) - 0.5
+            b = torch.rand(self.batch, *self.hw, 3, generator=g) - 0.5
+            yield {"img1": a.cuda(), "img2": b.cuda(), "gt_mask": None, "fname": [b"f%d" % (i * self.batch + j) for j in range(self.batch)]}
+
+
+def _cfg(**kw):
+    from unsupervised_detection_amd.config import default_flags
+    c = default_flags()
+    c.img_height, c.img_width, c.batch_size = 64, 128, 2
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+def test_inference_dict_contract(gpu, monkeypatch):
+    from unsupervised_detection_amd import learner as Lr
+    monkeypatch.setattr(Lr, "_engine_config", lambda config, batch=None, in_hw=(128, 192): Lr.EngineConfig(
+        batch_size=batch or config.batch_size, in_height=128, in_width=192, img_height=config.img_height, img_width=config.img_width))
+    lr = Lr.AdversarialLearner()
+    lr.setup_inference(_cfg(data_source=_Src(2, 2)), aug_test=False)
+    out = lr.inference(None)
+    assert set(out) == {"gen_masks", "pred_flow", "input_image", "gt_flow", "gt_masks", "img_fname"}
+    assert out["gen_masks"].shape == (2, 64, 128, 1) and out["pred_flow"].shape == (2, 64, 128, 2)
+    assert out["input_image"].shape == (2, 64, 128, 3) and out["gt_flow"].shape == (2, 64, 128, 2)
+    assert out["gen_masks"].min() >= 0 and out["gen_masks"].max() <= 1 and isinstance(out["gen_masks"], np.ndarray)
+    lr.inference(None)
+    with pytest.raises(StopIteration):
+        lr.inference(None)
+    # augmented graph: 4 crops, batch 1, generator only
+    lr2 = Lr.AdversarialLearner()
+    lr2.setup_inference(_cfg(data_source=_Src(1, 1)), aug_test=True)
+    out = lr2.inference(None)
+    assert lr2.test_crops == [0.85, 0.9, 0.95, 1.0]
+    assert set(out["outs"]) == {"pred_masks", "gt_masks", "img_1s"} and set(out["outs"]["pred_masks"]) == set(lr2.test_crops)
+    assert out["outs"]["pred_masks"][0.9].shape == (64, 128, 1) and out["outs"]["img_1s"][1.0].shape == (64, 128, 3)
+
+
+def test_train_loop_runs_and_learns_schedule(gpu, monkeypatch, capsys):
+    from unsupervised_detection_amd import learner as Lr
+    monkeypatch.setattr(Lr, "_engine_config", lambda config, batch=None, in_hw=(128, 192): Lr.EngineConfig(
+        batch_size=batch or config.batch_size, in_height=128, in_width=192, img_height=config.img_height, img_width=config.img_width))
+    lr = Lr.AdversarialLearner()
+    lr.train(_cfg(data_source=_Src(2, 8), num_samples_train=16, max_epochs=1, summary_freq=4))
+    assert lr.engine.adam_step == 8 and lr.global_step == 2  # one apply per step; global_step ticks every 4 steps
+    txt = capsys.readouterr().out
+    assert "Training 1 Recover and 3 Generator" in txt and "loss_generator" in txt
+    L = lr.engine.losses()
+    assert all(np.isfinite(v) for v in L.values())
+
+
+def test_functional_surface_matches_oracle(gpu):
+    from unsupervised_detection_amd import weights as W
+    from unsupervised_detection_amd.learner import HotPath
+    pg, pr = O.init_params(O.generator_param_specs(), 3), O.init_params(O.recover_param_specs(), 4)
+    hp = HotPath(2, (64, 128), (128, 192), w_gen=W.from_dict(pg, W.NET_GEN), w_rec=W.from_dict(pr, W.NET_REC))
+    g = torch.Generator().manual_seed(2)
+    image = torch.rand(2, 64, 128, 3, generator=g) - 0.5
+    flow = torch.randn(2, 64, 128, 2, generator=g) * 0.1
+    m = hp.generator_net(image.cuda(), flow.cuda(), scope="MaskNet/").cpu()
+    mref = O.generator_net(pg, image, O.preprocess_flow_batch(flow))
+    assert (m - mref).abs().max() < 1e-3
+    fm = flow * (1 - mref)
+    pred = hp.recover_net(image.cuda(), fm.cuda(), mref.cuda(), scope="FlownetS/").cpu()
+    ref = O.recover_net(pr, image, fm, mref)
+    assert (pred - ref).abs().max() < 1e-3 * max(1.0, float(ref.abs().max()))

@@ -67,6 +67,14 @@ int udet_forward_from_flow(udet_plan* h, int ncalls, void* ws_, void* stream) {
   if (ncalls == 3) UDET_TRY(plan_losses(h->p, ws, s));
   return UDET_OK;
 }
+int udet_generator_forward(udet_plan* h, void* ws, void* stream) {
+  UDET_TRY(plan_generator_forward(h->p, (float*)ws, (hipStream_t)stream));
+  return plan_recover_forward(h->p, 0, (float*)ws, (hipStream_t)stream);  // ncalls=0: only the mask is produced
+}
+int udet_recover_forward(udet_plan* h, int n, void* ws, void* stream) {
+  if (n < 1 || n > 3) { set_error("recover_forward: n must be 1..3 (multiples of the plan batch)"); return UDET_ERR_ARG; }
+  return plan_recover_forward(h->p, n, (float*)ws, (hipStream_t)stream, true);
+}
 int udet_forward(udet_plan* h, const float* img1, const float* img2, int ncalls, void* ws, void* stream) {
   UDET_TRY(plan_pwc_forward(h->p, img1, img2, (float*)ws, (hipStream_t)stream));
   UDET_TRY(plan_prepare(h->p, img1, (float*)ws, (hipStream_t)stream));

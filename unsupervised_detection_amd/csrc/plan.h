@@ -92,7 +92,7 @@ int plan_pack_trainable(Plan* P, const float* w_gen, const float* w_rec, float* 
 int plan_pwc_forward(Plan* P, const float* img1, const float* img2, float* ws, hipStream_t s);
 int plan_prepare(Plan* P, const float* img1, float* ws, hipStream_t s);
 int plan_generator_forward(Plan* P, float* ws, hipStream_t s);
-int plan_recover_forward(Plan* P, int ncalls, float* ws, hipStream_t s);
+int plan_recover_forward(Plan* P, int ncalls, float* ws, hipStream_t s, bool inputs_prepacked = false);
 int plan_losses(Plan* P, float* ws, hipStream_t s);
 int plan_backward_recover(Plan* P, const float* w_rec, float* g_rec, float* ws, hipStream_t s);
 int plan_backward_generator(Plan* P, const float* w_gen, float* g_gen, float* ws, hipStream_t s);

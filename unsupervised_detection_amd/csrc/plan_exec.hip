@@ -281,10 +281,11 @@ static int rec_resize(Plan* P, const char* src, const char* dst, int N, float* w
 }
 
 // mask, recover inputs, `ncalls` batched recover invocations (nets.py:45-110; adversarial_learner.py:107-131)
-int plan_recover_forward(Plan* P, int ncalls, float* ws, hipStream_t s) {
+int plan_recover_forward(Plan* P, int ncalls, float* ws, hipStream_t s, bool inputs_prepacked) {
   const Config& c = P->cfg;
   const int B = c.batch, N = ncalls * B;
   const long Ppix = (long)B * c.img_h * c.img_w;
+  if (!inputs_prepacked)
   UDET_TRY(launch_mask_rec_inputs(ws + P->buf(P->bid("gen.a17")).off, ws + P->buf(P->bid("image")).off,
                                   ws + P->buf(P->bid("flow")).off, ws + P->buf(P->bid("mask")).off,
                                   ws + P->buf(P->bid("rec.fin")).off, ws + P->buf(P->bid("rec.imgin")).off, Ppix, ncalls, s));

@@ -35,7 +35,8 @@ lib.udet_set_adam_step.restype = None
 lib.udet_set_adam_step.argtypes = [c_p, ctypes.c_long]
 for _n, _a in (("udet_pack_pwc", [c_p, c_p, c_p, c_p]), ("udet_pack_trainable", [c_p, c_p, c_p, c_p, c_p]),
                ("udet_pwc_forward", [c_p, c_p, c_p, c_p, c_p]), ("udet_forward", [c_p, c_p, c_p, c_i, c_p, c_p]),
-               ("udet_forward_from_flow", [c_p, c_i, c_p, c_p]),
+               ("udet_forward_from_flow", [c_p, c_i, c_p, c_p]), ("udet_generator_forward", [c_p, c_p, c_p]),
+               ("udet_recover_forward", [c_p, c_i, c_p, c_p]),
                ("udet_backward", [c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
                ("udet_apply", [c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
                ("udet_train_step", [c_p, c_i] + [c_p] * 12)):

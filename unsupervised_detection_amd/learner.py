@@ -1,0 +1,232 @@
+"""The reference's Python surface for the hot path, backed by libudet.so.
+
+Mirrors (same names, argument meaning, return contract) what the three entry scripts of the reference use:
+  AdversarialLearner.train(config)                     models/adversarial_learner.py:312
+  AdversarialLearner.setup_inference(config, aug_test) models/adversarial_learner.py:594
+  AdversarialLearner.inference(sess)                   models/adversarial_learner.py:606
+  attributes test_iterator / test_samples / test_crops test_generator.py:60,62; test_generator_ensemble.py:30
+and the functional sub-surface generator_net / recover_net / ModelPWCNet.predict_from_img_pairs /
+charbonnier_loss / preprocess_flow_batch on PyTorch-ROCm NHWC float32 tensors.
+
+`config` is any object with the attribute names of common_flags.py (config.FLAGS restates the defaults).
+Dataset readers are outside this path: batches come from `config.data_source`, an
+iterable of dicts {"img1","img2"[, "gt_mask","fname"]} holding reader-preprocessed tensors [B,384,640,3]
+in [-0.5,0.5]; without one, synthetic DAVIS-shaped pairs are used (there is no dataset on this machine)."""
+from __future__ import annotations
+
+import math
+import time
+from itertools import count
+
+import numpy as np
+import torch
+
+from . import data as _data
+from . import weights as W
+from .engine import BOTH, GEN, REC, Engine, EngineConfig
+from .trainer import TrainState, train_step
+
+TEST_CROPS = [0.85, 0.9, 0.95, 1.0]  # adversarial_learner.py:531
+
+
+def _engine_config(config, batch=None, in_hw=(384, 640)):
+    g = lambda k, d: getattr(config, k, d)
+    return EngineConfig(batch_size=batch or g("batch_size", 16), in_height=in_hw[0], in_width=in_hw[1],
+                        img_height=g("img_height", 192), img_width=g("img_width", 384), flow_normalizer=g("flow_normalizer", 80.0),
+                        cbn=g("cbn", 0.5), epsilon=g("epsilon", 75.0), beta1=g("beta1", 0.9))
+
+
+class _SyntheticSource:
+    def __init__(self, batch, n_batches, seed=8964):
+        self.batch, self.n, self.seed = batch, n_batches, seed
+
+    def __iter__(self):
+        for i in range(self.n):
+            f1, f2 = _data.synthetic_davis_pairs(self.batch, self.seed + i)
+            yield {"img1": _data.preprocess_image(torch.from_numpy(f1).cuda()),
+                   "img2": _data.preprocess_image(torch.from_numpy(f2).cuda()),
+                   "gt_mask": None, "fname": [b"synthetic_%05d" % (i * self.batch + j) for j in range(self.batch)]}
+
+
+class AdversarialLearner(object):
+    def __init__(self):
+        self.engine = None
+        self.state = None
+
+    # ------------------------------------------------------------------ training ----
+    def _load_weights(self, config):
+        """Checkpoint policy of train() (:339-360): PWC weights are mandatory in the reference; here synthetic
+        weights with the reference's initializers stand in when no flat-weight file is given (README.md:59-64
+        checkpoints are external downloads).  Files are torch.save'd dicts {tf_name: tensor}."""
+        import os
+        out = {}
+        for key, flag, net in (("w_pwc", "flow_ckpt", W.NET_PWC), ("w_rec", "recover_ckpt", W.NET_REC), ("w_gen", "full_model_ckpt", W.NET_GEN)):
+            path = getattr(config, flag, "")
+            if path and os.path.isfile(path):
+                d = torch.load(path, map_location="cpu")
+                out[key] = W.from_dict(d, net)
+                print("{} loaded from {}".format(flag, path))
+            elif path:
+                raise IOError("Could not find {} file {}. Aborting.".format(flag, path))
+        return out
+
+    def train(self, config):
+        """High level train function (adversarial_learner.py:312-420): alternates `iters_rec` recover steps and
+        `iters_gen` generator steps (step % (iters_rec+iters_gen) < iters_rec -> recover), each on a new batch."""
+        self.config = config
+        B = config.batch_size
+        self.engine = Engine(_engine_config(config, B))
+        self.state = TrainState(self.engine, seed=getattr(config, "seed", 8964), **self._load_weights(config))
+        n_params = sum(W.param_total(n) for n in (W.NET_PWC, W.NET_GEN, W.NET_REC))
+        print("Number of params: {}".format(n_params))
+        self.train_steps_per_epoch = int(math.ceil(config.num_samples_train / config.batch_size))
+        iters_rec, iters_gen = config.iters_rec, config.iters_gen
+        print("-------------------------------------")
+        print("Training {} Recover and {} Generator".format(iters_rec, iters_gen))
+        print("-------------------------------------")
+        sum_iters = iters_rec + iters_gen
+        max_steps = self.train_steps_per_epoch * config.max_epochs
+        source = getattr(config, "data_source", None) or _SyntheticSource(B, max_steps)
+        self.global_step = 0
+        it = iter(source)
+        for step in count(start=1):
+            try:
+                batch = next(it)
+            except StopIteration:
+                break
+            start_time = time.time()
+            if step % sum_iters == 0:
+                self.global_step += 1
+            which = REC if (step % sum_iters) < iters_rec else GEN
+            train_step(self.state, batch["img1"], batch["img2"], which)
+            if step % config.summary_freq == 0:
+                L = self.engine.losses()
+                train_epoch = math.ceil(step / self.train_steps_per_epoch)
+                train_step_ = step - (train_epoch - 1) * self.train_steps_per_epoch
+                print("Epoch: [%2d] [%5d/%5d] time: %4.4f/it loss_generator: %4.4f loss_recover %4.4f"
+                      % (train_epoch, train_step_, self.train_steps_per_epoch, time.time() - start_time, L["generator"], L["recover"]))
+            if step % self.train_steps_per_epoch == 0:
+                train_epoch = int(step / self.train_steps_per_epoch)
+                self.epoch_end_callback(train_epoch)
+                if train_epoch == config.max_epochs:
+                    print("-------------------------------")
+                    print("Training completed successfully")
+                    print("-------------------------------")
+                    break
+
+    def epoch_end_callback(self, epoch_num):
+        """Checkpointing of :443-448 (trainable variables only; Adam slots are not saved by the reference)."""
+        import os
+        ckdir = getattr(self.config, "checkpoint_dir", "")
+        if ckdir and epoch_num % getattr(self.config, "save_freq", 5) == 0:
+            os.makedirs(ckdir, exist_ok=True)
+            self.save(ckdir, epoch_num)
+
+    def save(self, checkpoint_dir, step):
+        import os
+        print(" [*] Saving checkpoint to {}/model-{}".format(checkpoint_dir, step))
+        d = {}
+        d.update(W.as_dict(self.state.w_gen.cpu(), W.NET_GEN))
+        d.update(W.as_dict(self.state.w_rec.cpu(), W.NET_REC))
+        d["global_step"] = torch.tensor(self.global_step)
+        name = "model.best" if step == "best" else "model-{}".format(step)
+        torch.save({k: v.clone() for k, v in d.items()}, os.path.join(checkpoint_dir, name))
+
+    # ----------------------------------------------------------------- inference ----
+    def setup_inference(self, config, aug_test=False):
+        """Sets up the inference graph (:594-604): test graph (batch_size, one recover call) or the augmented
+        4-crop graph (batch 1, generator only, :525-592)."""
+        self.config = config
+        self.aug_test = aug_test
+        B = 1 if aug_test else config.batch_size
+        self.engine = Engine(_engine_config(config, B))
+        self.state = TrainState(self.engine, seed=getattr(config, "seed", 8964), **self._load_weights(config))
+        source = getattr(config, "data_source", None) or _SyntheticSource(B, 4)
+        self.test_iterator = iter(source)
+        self.test_samples = getattr(source, "n", 4) * B
+        if aug_test:
+            self.test_crops = TEST_CROPS
+            print("Evaluating the following crops {}".format(TEST_CROPS))
+
+    def _central_crop_resize(self, img, frac):
+        """tf.image.central_crop + resize back to 384x640 (data/davis2016_data_utils.py:129-133,328-354)."""
+        n, h, w, c = img.shape
+        if frac >= 1.0:
+            return img
+        oy, ox = int((h - h * frac) / 2), int((w - w * frac) / 2)
+        crop = img[:, oy:h - oy, ox:w - ox].contiguous()
+        from . import ops
+        return ops.resize_bilinear_legacy(crop, h, w)
+
+    def inference(self, sess=None):
+        """Outputs a dictionary with the results of the required operations (:606-623).  `sess` is accepted and
+        ignored.  Raises StopIteration at the end of the data (the reference raises tf.errors.OutOfRangeError)."""
+        batch = next(self.test_iterator)
+        e = self.engine
+        if self.aug_test:
+            outs = {"pred_masks": {}, "gt_masks": {}, "img_1s": {}}
+            for crop in self.test_crops:
+                i1 = self._central_crop_resize(batch["img1"], crop)
+                i2 = self._central_crop_resize(batch["img2"], crop)
+                e.forward(i1, i2, 0)
+                outs["pred_masks"][crop] = e.buffer("mask")[0].cpu().numpy()
+                outs["img_1s"][crop] = e.buffer("image")[0].cpu().numpy()
+                gt = batch.get("gt_mask")
+                outs["gt_masks"][crop] = None if gt is None else gt[0].cpu().numpy()
+            return {"outs": outs, "img_fname": batch["fname"][0]}
+        e.forward(batch["img1"], batch["img2"], 1)
+        B = e.cfg.batch_size
+        gt = batch.get("gt_mask")
+        return {"gen_masks": e.buffer("mask").cpu().numpy(), "pred_flow": e.buffer("pred")[:B].cpu().numpy(),
+                "input_image": e.buffer("image").cpu().numpy(), "gt_flow": e.buffer("flow").cpu().numpy(),
+                "gt_masks": None if gt is None else gt.cpu().numpy(), "img_fname": np.array(batch["fname"])}
+
+
+# ---------------------------------------------------------------- functional API ----
+class HotPath:
+    """Functional sub-surface bound to one set of weights and one shape (engine plans are shape-specialised)."""
+
+    def __init__(self, batch, img_hw=(192, 384), in_hw=(384, 640), w_pwc=None, w_gen=None, w_rec=None, seed=8964, **flags):
+        self.engine = Engine(EngineConfig(batch_size=batch, in_height=in_hw[0], in_width=in_hw[1], img_height=img_hw[0],
+                                          img_width=img_hw[1], **flags))
+        self.state = TrainState(self.engine, seed, w_pwc, w_gen, w_rec)
+
+    def predict_from_img_pairs(self, img1s, img2s):
+        """ModelPWCNet().predict_from_img_pairs (models/PWCNet/model_pwcnet.py:61-76)."""
+        return self.engine.pwc_forward(img1s, img2s).clone()
+
+    def generator_net(self, images, flows, scope=None, reuse=None, training=True):
+        """models/nets.py:4.  NOTE: like the reference's call site (adversarial_learner.py:99-105) `flows` is the
+        normalised flow *before* preprocess_flow_batch; the standardisation is fused into the input packer."""
+        from ._ffi import check, lib
+        e = self.engine
+        e.buffer("image").copy_(images)
+        e.buffer("flow").copy_(flows)
+        check(lib.udet_generator_forward(e._h, e.ws.data_ptr(), e._stream()))
+        return e.buffer("mask").clone()
+
+    def recover_net(self, img1, flow_masked, mask, scope=None, reuse=None, f=0.25, training=True):
+        """models/nets.py:45."""
+        from ._ffi import check, lib
+        e = self.engine
+        B = e.cfg.batch_size
+        fin, imgin = e.buffer("rec.fin"), e.buffer("rec.imgin")
+        fin[:B, ..., 0:2] = flow_masked
+        fin[:B, ..., 2:3] = 1.0
+        fin[:B, ..., 3:4] = 1.0 - mask
+        imgin[:B, ..., 0:3] = img1
+        check(lib.udet_recover_forward(e._h, 1, e.ws.data_ptr(), e._stream()))
+        return e.buffer("pred")[:B].clone()
+
+
+def preprocess_flow_batch(flow):
+    """models/utils/flow_utils.py:5-12 (torch ops; the fused device version lives in the generator input packer)."""
+    mean = flow.mean(dim=(1, 2), keepdim=True)
+    var = ((flow - mean) ** 2).mean(dim=(1, 2), keepdim=True)
+    return (flow - mean) / torch.sqrt(var)
+
+
+def charbonnier_loss(gt_flows, pred_flows, masks, cbn=0.5):
+    """models/utils/loss_utils.py:34-51 (torch ops on device; the training path uses the fused HIP reductions)."""
+    lp = torch.pow((gt_flows - pred_flows) ** 2 + 0.001 ** 2, cbn) * masks
+    return lp.sum(dim=(1, 2, 3))
