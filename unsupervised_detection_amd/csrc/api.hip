@@ -41,7 +41,8 @@ using namespace udet;
 
 extern "C" {
 
-int udet_version(void) { return 100; }
+int udet_version(void) { return 101; }
+void udet_debug_force_conv(int bm, int bn, int ks) { conv_force_config(bm, bn, ks); }
 const char* udet_last_error(void) { return g_err; }
 
 int udet_warp(const float* image, const float* flow, float flow_scale, float* out, int n, int h, int w, int c,
@@ -73,7 +74,7 @@ size_t udet_conv2d_workspace_bytes(int n, int h, int w, int cin, int cout, int k
   b += gran(pix_in * round_up(cin, 8));                          // channel-padded x
   b += 2 * gran(pix_out * round_up(cout, 8));                    // channel-padded dy / y_saved
   b += gran(SPLITK_FLOATS);                                      // split-K partials
-  b += gran(wgrad_partial_floats_needed(kh * kw, cin, cout) + 63 * (size_t)kh * kw * cin * cout);
+  b += gran(64 * wgrad_partial_floats_needed(kh * kw, cin, cout));
   return b + 4096;
 }
 
@@ -133,7 +134,7 @@ int udet_conv2d_transpose4x4s2(const float* x, const float* w_hwoi, const float*
   if (!wp || !part) { set_error("conv2d_transpose: workspace too small"); return UDET_ERR_ARG; }
   // w is [t][cout][cin]; B operand wants [t][k=cin][n=cout]  -> mode 1 with (R=cout, C=cin)
   UDET_TRY(launch_pack_weights(w_hwoi, wp, 16, cout, cin, kc, ldw, kc, 0, 1, nullptr, stream));
-  for (int cls = 0; cls < 4; ++cls) {
+  for (int cls = 0; cls < conv_dgrad_classes(2, 2 * h, 2 * w); ++cls) {
     ConvParams p;
     memset(&p, 0, sizeof(p));
     if (!conv_setup_dgrad(p, cls, n, 2 * h, 2 * w, 4, 4, 2, 1)) continue;
@@ -176,7 +177,7 @@ int udet_conv2d_backward_data(const float* dy, const float* y_saved, const float
   float* part = ar.take(SPLITK_FLOATS);
   if (!wp || !part) { set_error("conv2d_backward_data: workspace too small"); return UDET_ERR_ARG; }
   UDET_TRY(launch_pack_weights(w_hwio, wp, kh * kw, cin, cout, kc, ldw, kc, 0, 1, nullptr, stream));
-  for (int cls = 0; cls < conv_dgrad_classes(stride); ++cls) {
+  for (int cls = 0; cls < conv_dgrad_classes(stride, h, w); ++cls) {
     ConvParams p;
     memset(&p, 0, sizeof(p));
     if (!conv_setup_dgrad(p, cls, n, h, w, kh, kw, stride, dilation)) continue;
@@ -229,7 +230,7 @@ int udet_conv2d_backward_filter(const float* x, const float* dy, const float* y_
     }
     ldy = cout8;
   }
-  const size_t pf = wgrad_partial_floats_needed(kh * kw, cin, cout) + 63 * (size_t)kh * kw * cin * cout;
+  const size_t pf = 64 * wgrad_partial_floats_needed(kh * kw, cin, cout);
   size_t avail = (ar.cap - ar.used) / sizeof(float);
   if (avail > 256) avail -= 256;
   const size_t takef = pf < avail ? pf : avail;

@@ -1,4 +1,5 @@
 // extern "C" plan-level surface of libudet.so (see include/udet.h).
+#include <stdlib.h>
 #include <string.h>
 
 #include "plan.h"
@@ -112,9 +113,12 @@ int udet_profile_end(udet_plan* h, double* out, int ncat, void* stream) {
   P->profiling = false;
   UDET_HIP(hipStreamSynchronize((hipStream_t)stream));
   for (int i = 0; i < ncat * 4; ++i) out[i] = 0.0;
+  FILE* dump = nullptr;  // UDET_PROF_DUMP=<file>: one CSV line per launch group (category,name,ms,algorithmic GFLOP,MB)
+  if (const char* path = getenv("UDET_PROF_DUMP")) dump = fopen(path, "a");
   for (auto& r : P->prof) {
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, r.a, r.b);
+    if (dump) fprintf(dump, "%d,%s,%.4f,%.4f,%.4f\n", r.cat, r.name.c_str(), ms, r.flops * 1e-9, r.bytes * 1e-6);
     if (r.cat < ncat) {
       out[r.cat * 4 + 0] += 1.0;
       out[r.cat * 4 + 1] += ms;
@@ -124,6 +128,7 @@ int udet_profile_end(udet_plan* h, double* out, int ncat, void* stream) {
     (void)hipEventDestroy(r.a);
     (void)hipEventDestroy(r.b);
   }
+  if (dump) fclose(dump);
   P->prof.clear();
   return UDET_OK;
 }

@@ -52,6 +52,24 @@ struct ConvTap {
   int dy, dx, widx;
 };
 
+// n / d for 0 <= n < 2^31 with one multiply-high (d >= 1), built on the host
+struct FastDiv {
+  unsigned d, mul, sh;
+};
+inline FastDiv make_fastdiv(unsigned d) {
+  FastDiv f;
+  f.d = d; f.mul = 0; f.sh = 0;
+  if (d > 1) {
+    unsigned l = 0;
+    while ((1u << l) < d) ++l;  // ceil(log2 d)
+    const unsigned long long pw = 1ull << (31 + l);
+    f.mul = (unsigned)((pw + d - 1) / d);
+    f.sh = l - 1;
+  }
+  return f;
+}
+__device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) { return f.d == 1 ? n : (__umulhi(n, f.mul) >> f.sh); }
+
 struct ConvParams {
   // A operand (input activations / output-gradients), NHWC with channel stride ldx
   const float* x;
@@ -74,6 +92,12 @@ struct ConvParams {
   int isy, isx;
   int ntaps;
   ConvTap taps[UDET_MAX_TAPS];
+  // Output-parity classes merged into one launch (stride-2 dgrad / conv2d_transpose): class c = (py,px) = (c>>1, c&1)
+  // owns taps [cls_tap[c], cls_tap[c+1]) and writes y[.., qy*2+py, qx*2+px, ..].  ncls == 1: one class, all taps,
+  // (ooy,oox) as given.
+  int ncls;
+  int cls_tap[5];
+  FastDiv fd_ohw, fd_ow;  // filled by launch_conv
   // epilogue
   int act;
   float alpha;
@@ -110,6 +134,10 @@ struct WgradParams {
   float* db;        // [Cout] or null
   float* partial;   // workspace
   size_t partial_floats;
+  // filled by launch_wgrad_T
+  int Cin4, Mpad;
+  float* pbias;
+  FastDiv fd_ohw, fd_ow;
   // generator finalisation (BN folded): dW = G*gs[co]; dgamma = c*(sum W*G + b*S); dbeta = S; db = gs*S
   const float* w;       // HWIO weights (for dgamma)
   const float* b;       // bias

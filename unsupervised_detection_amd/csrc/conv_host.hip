@@ -38,11 +38,15 @@ void conv_setup_fwd(ConvParams& p, int N, int H, int W, int kh, int kw, int s, i
     for (int kx = 0; kx < kw; ++kx) push_tap(p, ky * d - pt, kx * d - pl, ky * kw + kx);
 }
 
-int conv_dgrad_classes(int s) { return s == 1 ? 1 : s * s; }
+// Number of launches the backward-data pass of a stride-s SAME conv over an (H,W) input needs: stride 2 on an even
+// grid runs its four output-parity classes as ONE launch (ConvParams::ncls = 4); odd grids fall back to one launch
+// per class.
+int conv_dgrad_classes(int s, int H, int W) { return s == 1 ? 1 : ((H % 2 == 0 && W % 2 == 0) ? 1 : s * s); }
 
 // Backward-data of the SAME conv (N,H,W) --k,s,d--> (N,OHf,OWf); also the forward of
 // tf.layers.conv2d_transpose (k=4,s=2,'same') when called with H=2h, W=2w.
 // The A operand lives on the (OHf,OWf) grid, the result on the (H,W) grid.
+// `cls` indexes the launches of conv_dgrad_classes(s,H,W).
 bool conv_setup_dgrad(ConvParams& p, int cls, int N, int H, int W, int kh, int kw, int s, int d) {
   int pt, pl, ohf, owf;
   same_pad(H, kh, s, d, &pt, &ohf);
@@ -51,27 +55,43 @@ bool conv_setup_dgrad(ConvParams& p, int cls, int N, int H, int W, int kh, int k
   p.OH = H; p.OW = W;
   p.isy = p.isx = 1;
   p.ntaps = 0;
+  p.ncls = 1;
   if (s == 1) {
     p.OHq = H; p.OWq = W; p.osy = p.osx = 1; p.ooy = p.oox = 0;
     for (int ky = 0; ky < kh; ++ky)
       for (int kx = 0; kx < kw; ++kx) push_tap(p, pt - ky * d, pl - kx * d, ky * kw + kx);
     return p.ntaps > 0;
   }
-  const int py = cls / s, px = cls % s;  // s == 2
-  p.osy = p.osx = s; p.ooy = py; p.oox = px;
-  p.OHq = (H - py + s - 1) / s;
-  p.OWq = (W - px + s - 1) / s;
-  if (p.OHq <= 0 || p.OWq <= 0) return false;
-  for (int ky = 0; ky < kh; ++ky) {
-    const int vy = py + pt - ky * d;
-    if (((vy % 2) + 2) % 2) continue;
-    for (int kx = 0; kx < kw; ++kx) {
-      const int vx = px + pl - kx * d;
-      if (((vx % 2) + 2) % 2) continue;
-      push_tap(p, floordiv2(vy), floordiv2(vx), ky * kw + kx);
+  const bool merged = (H % 2 == 0 && W % 2 == 0);  // s == 2
+  p.osy = p.osx = s;
+  const int c_lo = merged ? 0 : cls, c_hi = merged ? 4 : cls + 1;
+  for (int c = c_lo; c < c_hi; ++c) {
+    const int py = c / s, px = c % s;
+    p.ooy = py; p.oox = px;
+    p.OHq = (H - py + s - 1) / s;
+    p.OWq = (W - px + s - 1) / s;
+    if (merged) p.cls_tap[c] = p.ntaps;
+    if (p.OHq <= 0 || p.OWq <= 0) {
+      if (!merged) return false;
+      continue;
+    }
+    for (int ky = 0; ky < kh; ++ky) {
+      const int vy = py + pt - ky * d;
+      if (((vy % 2) + 2) % 2) continue;
+      for (int kx = 0; kx < kw; ++kx) {
+        const int vx = px + pl - kx * d;
+        if (((vx % 2) + 2) % 2) continue;
+        push_tap(p, floordiv2(vy), floordiv2(vx), ky * kw + kx);
+      }
     }
   }
-  return true;  // ntaps may be 0: the caller must still write zeros / bias
+  if (merged) {
+    p.ncls = 4;
+    p.cls_tap[4] = p.ntaps;
+    p.ooy = p.oox = 0;
+    p.OHq = H / 2; p.OWq = W / 2;
+  }
+  return true;  // a class may have no taps: the kernel still writes zeros / bias for it
 }
 
 // ---------------------------------------------------------------------------

@@ -1,13 +1,17 @@
 // Implicit-GEMM convolution on the fp32 matrix cores of gfx950
 // (v_mfma_f32_32x32x2_f32: exact f32, 64 FLOP/clk/SIMD).
 //
-//   M = output pixels (n,qy,qx)   N = output channels   K = taps x input channels
+//   M = output pixels (n,qy,qx)   N = output channels   K = (tap, input channel) flattened
 //
-// 256-thread workgroups (4 wave64), BM x BN output tile, BK input channels of one
-// tap per LDS stage, double-buffered LDS, register-staged global->LDS copies.
-// A tile is stored K-major in LDS ([BK][BM+pad]) so that the MFMA A fragment
-// (lane l -> row l&31, k = l>>5) is a conflict-free ds_read_b32; the B tile
-// ([BK][BN]) is the packed-weight layout itself.
+// 256-thread workgroups (4 wave64), BM x BN output tile.  K is ONE flat axis over the launch's tap list
+// (k = tap*Kc + c): a BK-wide LDS stage may straddle taps, so 7x7/5x5 convolutions over 4..16 channels and
+// the ragged PWC slab windows run the same BK=32 pipeline as the 128-channel 3x3 layers; the tail of the
+// last stage is zero-filled.  Double-buffered LDS, register-staged global->LDS copies (one barrier per stage).
+// The A tile is stored K-major in LDS ([BK][BM+pad], pad chosen so that the transposing ds_write_b32 are
+// conflict-free) which makes the MFMA A fragment (lane l -> row l&31, k = l>>5) a conflict-free ds_read_b32;
+// the B tile ([BK][BN]) is the packed-weight layout itself.
+// Stride-2 backward-data / conv2d_transpose: the four output-parity classes are ONE launch (each workgroup
+// belongs to one class and walks only that class's taps: no multiplications by structural zeros).
 //
 // Replaces the TF-1.13 Conv2D / Conv2DBackpropInput kernels the reference calls through
 // tf.layers.conv2d / tf.nn.conv2d / tf.layers.conv2d_transpose
@@ -24,19 +28,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   static_assert(TM * 32 == WTM && TN * 32 == WTN, "wave tile must be a multiple of 32");
-  constexpr int APAD = (BK == 8) ? 4 : 2;
-  constexpr int LDA = BM + APAD;
-  constexpr int LDB = BN;
-  constexpr int A_F4_PER_ROW = BK / 4;
-  constexpr int A_ROWS_PER_PASS = 256 / A_F4_PER_ROW;
-  constexpr int A_LD = (BM + A_ROWS_PER_PASS - 1) / A_ROWS_PER_PASS;
-  constexpr int B_F4_PER_ROW = BN / 4;
-  constexpr int B_F4 = BK * B_F4_PER_ROW;
-  constexpr int B_LD = (B_F4 + 255) / 256;
+  constexpr int KQ = BK / 4;                // float4 per A row per stage
+  constexpr int LDA = BM + 32 / BK;         // 4*LDA == 32/KQ (mod 32): conflict-free transposing stores
+  constexpr int A_ROWS = 256 / KQ;          // A rows staged per pass
+  constexpr int A_LD = BM / A_ROWS;
+  static_assert(A_LD * A_ROWS == BM, "BM must be a multiple of 256/(BK/4)");
+  constexpr int B_F4_ROW = BN / 4;
+  constexpr int B_LD = BK * B_F4_ROW / 256;
+  static_assert(B_LD * 256 == BK * B_F4_ROW, "BK*BN/4 must be a multiple of 256");
 
   __shared__ float As[2][BK][LDA];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDB];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
   __shared__ int rowoff[BM];
+  __shared__ int2 tap_yx[UDET_MAX_TAPS];
+  __shared__ int tap_w[UDET_MAX_TAPS];
 
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
@@ -50,31 +55,40 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
   const int OHWq = p.OHq * p.OWq;
-  const int Mtot = p.N * OHWq;
-  const int m0 = bid * BM;
+  const int Mtot = p.N * OHWq;  // per class
+  const int mtiles = (Mtot + BM - 1) / BM;
+  const int cls = bid / mtiles;
+  const int m0 = (bid - cls * mtiles) * BM;
   const int n0 = blockIdx.y * BN;
+  const int tap0 = p.cls_tap[cls];
+  const int ntc = p.cls_tap[cls + 1] - tap0;
+  const int ooy = p.ncls > 1 ? (cls >> 1) : p.ooy, oox = p.ncls > 1 ? (cls & 1) : p.oox;
   const int Hs = p.H >> p.up_shift, Ws = p.W >> p.up_shift;
 
-  // ---- per-row bookkeeping ------------------------------------------------
+  // ---- per-block tables -----------------------------------------------------
+  for (int i = t; i < ntc; i += 256) {
+    tap_yx[i] = make_int2(p.taps[tap0 + i].dy, p.taps[tap0 + i].dx);
+    tap_w[i] = p.taps[tap0 + i].widx;
+  }
   for (int r = t; r < BM; r += 256) {
     const int m = m0 + r;
     int off = -1;
     if (m < Mtot) {
-      const int n = m / OHWq, rem = m - n * OHWq;
-      const int qy = rem / p.OWq, qx = rem - qy * p.OWq;
-      off = p.ksplit > 1 ? m : (n * p.OH + qy * p.osy + p.ooy) * p.OW + qx * p.osx + p.oox;
+      const int n = (int)fdiv(m, p.fd_ohw), rem = m - n * OHWq;
+      const int qy = (int)fdiv(rem, p.fd_ow), qx = rem - qy * p.OWq;
+      off = p.ksplit > 1 ? cls * Mtot + m : (n * p.OH + qy * p.osy + ooy) * p.OW + qx * p.osx + oox;
     }
     rowoff[r] = off;
   }
-  const int a_kq = t % A_F4_PER_ROW;
+  const int a_kq = t % KQ;
   int a_base[A_LD], a_iy0[A_LD], a_ix0[A_LD];
 #pragma unroll
   for (int j = 0; j < A_LD; ++j) {
-    const int r = t / A_F4_PER_ROW + j * A_ROWS_PER_PASS;
+    const int r = t / KQ + j * A_ROWS;
     const int m = m0 + r;
-    if (r < BM && m < Mtot) {
-      const int n = m / OHWq, rem = m - n * OHWq;
-      const int qy = rem / p.OWq, qx = rem - qy * p.OWq;
+    if (m < Mtot) {
+      const int n = (int)fdiv(m, p.fd_ohw), rem = m - n * OHWq;
+      const int qy = (int)fdiv(rem, p.fd_ow), qx = rem - qy * p.OWq;
       a_base[j] = n * Hs * Ws;
       a_iy0[j] = qy * p.isy;
       a_ix0[j] = qx * p.isx;
@@ -93,28 +107,46 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int kchunks = p.Kc / BK;
-  const int nchunks = p.ntaps * kchunks;
+  const int Kc = p.Kc;
+  const int nchunks = (ntc * Kc + BK - 1) / BK;
   int c_begin = 0, c_end = nchunks;
   if (p.ksplit > 1) {
     c_begin = (int)((long)nchunks * blockIdx.z / p.ksplit);
     c_end = (int)((long)nchunks * (blockIdx.z + 1) / p.ksplit);
   }
+  // flat-K cursors (tap, channel) of this thread's A float4 and of its B rows; advanced by BK per stage
+  int a_tap, a_c, b_tap[B_LD], b_c[B_LD];
+  {
+    const int kf = c_begin * BK + a_kq * 4;
+    a_tap = kf / Kc;
+    a_c = kf - a_tap * Kc;
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) {
+      const int kb = c_begin * BK + (t + j * 256) / B_F4_ROW;
+      b_tap[j] = kb / Kc;
+      b_c[j] = kb - b_tap[j] * Kc;
+    }
+  }
+  __syncthreads();  // tap tables visible
 
   float4 ra[A_LD], rb[B_LD];
-  auto load_chunk = [&](int c) {
-    const int tp = c / kchunks;
-    const int kc = (c - tp * kchunks) * BK;
-    const int dy = p.taps[tp].dy, dx = p.taps[tp].dx, widx = p.taps[tp].widx;
+  auto load_chunk = [&]() {
+    int dy = 0, dx = 0;
+    const bool a_ok = a_tap < ntc;
+    if (a_ok) {
+      const int2 yx = tap_yx[a_tap];
+      dy = yx.x;
+      dx = yx.y;
+    }
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
       int iy = a_iy0[j] + dy, ix = a_ix0[j] + dx;
-      const bool ok = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const bool ok = a_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (ok) {
         iy >>= p.up_shift;
         ix >>= p.up_shift;
-        const size_t off = (size_t)(a_base[j] + iy * Ws + ix) * p.ldx + p.x_coff + kc + a_kq * 4;
+        const size_t off = (size_t)(a_base[j] + iy * Ws + ix) * p.ldx + p.x_coff + a_c;
         v = *reinterpret_cast<const float4*>(p.x + off);
         if (p.xa) {
           const float4 a = *reinterpret_cast<const float4*>(p.xa + off);
@@ -128,46 +160,48 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     }
 #pragma unroll
     for (int j = 0; j < B_LD; ++j) {
-      const int idx = t + j * 256;
+      const int c4 = (t + j * 256) % B_F4_ROW;
+      const int n = n0 + c4 * 4;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (idx < B_F4) {
-        const int krow = idx / B_F4_PER_ROW, c4 = idx - krow * B_F4_PER_ROW;
-        const int n = n0 + c4 * 4;
-        if (n < p.ldw) v = *reinterpret_cast<const float4*>(p.wp + ((size_t)widx * p.Kc + kc + krow) * p.ldw + n);
-      }
+      if (b_tap[j] < ntc && n < p.ldw)
+        v = *reinterpret_cast<const float4*>(p.wp + ((size_t)tap_w[b_tap[j]] * Kc + b_c[j]) * p.ldw + n);
       rb[j] = v;
+    }
+    // advance the cursors to the next stage
+    a_c += BK;
+    while (a_c >= Kc) { a_c -= Kc; ++a_tap; }
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) {
+      b_c[j] += BK;
+      while (b_c[j] >= Kc) { b_c[j] -= Kc; ++b_tap[j]; }
     }
   };
   auto store_chunk = [&](int buf) {
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
-      const int r = t / A_F4_PER_ROW + j * A_ROWS_PER_PASS;
-      if (r < BM) {
-        As[buf][a_kq * 4 + 0][r] = ra[j].x;
-        As[buf][a_kq * 4 + 1][r] = ra[j].y;
-        As[buf][a_kq * 4 + 2][r] = ra[j].z;
-        As[buf][a_kq * 4 + 3][r] = ra[j].w;
-      }
+      const int r = t / KQ + j * A_ROWS;
+      As[buf][a_kq * 4 + 0][r] = ra[j].x;
+      As[buf][a_kq * 4 + 1][r] = ra[j].y;
+      As[buf][a_kq * 4 + 2][r] = ra[j].z;
+      As[buf][a_kq * 4 + 3][r] = ra[j].w;
     }
 #pragma unroll
     for (int j = 0; j < B_LD; ++j) {
       const int idx = t + j * 256;
-      if (idx < B_F4) {
-        const int krow = idx / B_F4_PER_ROW, c4 = idx - krow * B_F4_PER_ROW;
-        *reinterpret_cast<float4*>(&Bs[buf][krow][c4 * 4]) = rb[j];
-      }
+      const int krow = idx / B_F4_ROW, c4 = idx - krow * B_F4_ROW;
+      *reinterpret_cast<float4*>(&Bs[buf][krow][c4 * 4]) = rb[j];
     }
   };
 
   if (c_begin < c_end) {
-    load_chunk(c_begin);
+    load_chunk();
     store_chunk(0);
   }
   __syncthreads();
   int buf = 0;
   for (int c = c_begin; c < c_end; ++c) {
     const bool more = c + 1 < c_end;
-    if (more) load_chunk(c + 1);
+    if (more) load_chunk();
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
       float a[TM], b[TN];
@@ -198,7 +232,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         const int n = n0 + wn * WTN + j * 32 + li;
         float v = acc[i][j][r];
         if (p.ksplit > 1) {
-          if (n < p.ldp) p.partial[((size_t)blockIdx.z * Mtot + off) * p.ldp + n] = v;
+          if (n < p.ldp) p.partial[((size_t)blockIdx.z * p.ncls * Mtot + off) * p.ldp + n] = v;
           continue;
         }
         if (n >= p.Cout) continue;
@@ -218,14 +252,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const ConvParams p) {
   const int OHWq = p.OHq * p.OWq;
   const int Mtot = p.N * OHWq;
-  const long total = (long)Mtot * p.Cout;
+  const int Mall = p.ncls * Mtot;
+  const long total = (long)Mall * p.Cout;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-    const int m = (int)(e / p.Cout), n = (int)(e - (long)m * p.Cout);
+    const int ma = (int)(e / p.Cout), n = (int)(e - (long)ma * p.Cout);
     float v = 0.f;
-    for (int s = 0; s < p.ksplit; ++s) v += p.partial[((size_t)s * Mtot + m) * p.ldp + n];
-    const int nb = m / OHWq, rem = m - nb * OHWq;
-    const int qy = rem / p.OWq, qx = rem - qy * p.OWq;
-    const int off = (nb * p.OH + qy * p.osy + p.ooy) * p.OW + qx * p.osx + p.oox;
+    for (int s = 0; s < p.ksplit; ++s) v += p.partial[((size_t)s * Mall + ma) * p.ldp + n];
+    const int cls = ma / Mtot, m = ma - cls * Mtot;
+    const int ooy = p.ncls > 1 ? (cls >> 1) : p.ooy, oox = p.ncls > 1 ? (cls & 1) : p.oox;
+    const int nb = (int)fdiv(m, p.fd_ohw), rem = m - nb * OHWq;
+    const int qy = (int)fdiv(rem, p.fd_ow), qx = rem - qy * p.OWq;
+    const int off = (nb * p.OH + qy * p.osy + ooy) * p.OW + qx * p.osx + oox;
     if (p.bias) v += p.bias[n];
     v = act_fwd(v, p.act, p.alpha);
     if (p.y2) p.y2[(size_t)off * p.ldy2 + p.y2_coff + n] = v;
@@ -239,11 +276,11 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const ConvPar
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
 static int launch_cfg(const ConvParams& p, hipStream_t stream) {
   const int Mtot = p.N * p.OHq * p.OWq;
-  dim3 grid((Mtot + BM - 1) / BM, (p.Cout + BN - 1) / BN, p.ksplit > 1 ? p.ksplit : 1);
+  dim3 grid(p.ncls * ((Mtot + BM - 1) / BM), (p.Cout + BN - 1) / BN, p.ksplit > 1 ? p.ksplit : 1);
   hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N>), grid, dim3(256), 0, stream, p);
   UDET_HIP(hipGetLastError());
   if (p.ksplit > 1) {
-    const long total = (long)Mtot * p.Cout;
+    const long total = (long)p.ncls * Mtot * p.Cout;
     int nb = (int)((total + 255) / 256);
     if (nb > 2048) nb = 2048;
     hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3(nb), dim3(256), 0, stream, p);
@@ -252,23 +289,35 @@ static int launch_cfg(const ConvParams& p, hipStream_t stream) {
   return UDET_OK;
 }
 
-int conv_pick_ksplit(const ConvParams& p, int bm, int bn, int bk) {
+// ---- tile / split-K selection ---------------------------------------------------------------
+struct TileCfg { int bm, bn; };
+static long cfg_tiles(const ConvParams& p, int bm, int bn) {
   const int Mtot = p.N * p.OHq * p.OWq;
-  const long tiles = (long)((Mtot + bm - 1) / bm) * ((p.Cout + bn - 1) / bn);
-  const int nchunks = p.ntaps * (p.Kc / bk);
-  if (tiles >= 384 || !p.partial) return 1;
+  return (long)p.ncls * ((Mtot + bm - 1) / bm) * ((p.Cout + bn - 1) / bn);
+}
+static int max_class_taps(const ConvParams& p) {
+  int mx = 0;
+  for (int c = 0; c < p.ncls; ++c) mx = p.cls_tap[c + 1] - p.cls_tap[c] > mx ? p.cls_tap[c + 1] - p.cls_tap[c] : mx;
+  return mx;
+}
+static int pick_ksplit(const ConvParams& p, long tiles, int bk) {
+  if (tiles >= 256 || !p.partial) return 1;
+  const int nchunks = (max_class_taps(p) * p.Kc + bk - 1) / bk;
   int ks = (int)((512 + tiles - 1) / tiles);
-  const int maxks = nchunks / 8 > 0 ? nchunks / 8 : 1;  // keep >= 8 chunks per split
+  const int maxks = nchunks / 4 > 0 ? nchunks / 4 : 1;  // keep >= 4 stages per split
   if (ks > maxks) ks = maxks;
   if (ks > 64) ks = 64;
-  const size_t per_split = (size_t)Mtot * ((p.Cout + 3) & ~3);
+  const size_t per_split = (size_t)p.ncls * p.N * p.OHq * p.OWq * ((p.Cout + 3) & ~3);
   while (ks > 1 && per_split * ks > p.partial_cap) --ks;
   return ks < 2 ? 1 : ks;
 }
 
+static int g_force_bm = 0, g_force_bn = 0, g_force_ks = -1;
+void conv_force_config(int bm, int bn, int ks) { g_force_bm = bm; g_force_bn = bn; g_force_ks = ks; }
+
 int launch_conv(ConvParams& p, hipStream_t stream) {
-  if (p.Kc % 8 != 0 || p.ldx % 4 != 0 || p.x_coff % 4 != 0 || p.ldw % 4 != 0) {
-    set_error("conv: Kc=%d ldx=%d x_coff=%d ldw=%d violate the 8/4/4/4 alignment contract", p.Kc, p.ldx, p.x_coff, p.ldw);
+  if (p.Kc % 4 != 0 || p.ldx % 4 != 0 || p.x_coff % 4 != 0 || p.ldw % 4 != 0) {
+    set_error("conv: Kc=%d ldx=%d x_coff=%d ldw=%d violate the 4-float alignment contract", p.Kc, p.ldx, p.x_coff, p.ldw);
     return UDET_ERR_ALIGN;
   }
   if (p.ntaps < 0 || p.ntaps > UDET_MAX_TAPS) {
@@ -279,21 +328,31 @@ int launch_conv(ConvParams& p, hipStream_t stream) {
     set_error("conv: x / packed weights must be 16-byte aligned");
     return UDET_ERR_ALIGN;
   }
-  const bool k16 = (p.Kc % 16 == 0);
+  if (p.ncls != 4) {
+    p.ncls = 1;
+    p.cls_tap[0] = 0;
+    p.cls_tap[1] = p.ntaps;
+  }
+  p.fd_ohw = make_fastdiv((unsigned)(p.OHq * p.OWq));
+  p.fd_ow = make_fastdiv((unsigned)p.OWq);
+  // N tile from the channel count; M tile shrunk while the launch would leave CUs without a workgroup
   int bm, bn;
-  if (p.Cout <= 32) { bm = 256; bn = 32; }
-  else if (p.Cout <= 64) { bm = 128; bn = 64; }
-  else if (p.Cout <= 96) { bm = 128; bn = 96; }
-  else { bm = 128; bn = 128; }
-  p.ksplit = conv_pick_ksplit(p, bm, bn, k16 ? 16 : 8);
+  if (p.Cout <= 32) { bn = 32; bm = 256; if (cfg_tiles(p, 256, 32) < 384) bm = 128; }
+  else if (p.Cout <= 64) { bn = 64; bm = 128; if (cfg_tiles(p, 128, 64) < 384) bm = 64; }
+  else if (p.Cout <= 96) { bn = 96; bm = 128; }
+  else { bn = 128; bm = 128; if (cfg_tiles(p, 128, 128) < 320) { bn = 64; if (cfg_tiles(p, 128, 64) < 384) bm = 64; } }
+  if (g_force_bm) { bm = g_force_bm; bn = g_force_bn; }
+  p.ksplit = pick_ksplit(p, cfg_tiles(p, bm, bn), 32);
+  if (g_force_ks >= 0) p.ksplit = g_force_ks > 1 ? g_force_ks : 1;
   if (p.ksplit > 1) p.ldp = (p.Cout + 3) & ~3;
-#define UDET_CFG(BM_, BN_, WM_, WN_) \
-  return k16 ? launch_cfg<BM_, BN_, 16, WM_, WN_>(p, stream) : launch_cfg<BM_, BN_, 8, WM_, WN_>(p, stream)
-  if (bn == 32) { UDET_CFG(256, 32, 4, 1); }
-  if (bn == 64) { UDET_CFG(128, 64, 2, 2); }
-  if (bn == 96) { UDET_CFG(128, 96, 4, 1); }
-  UDET_CFG(128, 128, 2, 2);
-#undef UDET_CFG
+  if (bm == 256 && bn == 32) return launch_cfg<256, 32, 32, 4, 1>(p, stream);
+  if (bm == 128 && bn == 32) return launch_cfg<128, 32, 32, 4, 1>(p, stream);
+  if (bm == 128 && bn == 64) return launch_cfg<128, 64, 32, 2, 2>(p, stream);
+  if (bm == 64 && bn == 64) return launch_cfg<64, 64, 32, 2, 2>(p, stream);
+  if (bm == 128 && bn == 96) return launch_cfg<128, 96, 32, 4, 1>(p, stream);
+  if (bm == 128 && bn == 128) return launch_cfg<128, 128, 32, 2, 2>(p, stream);
+  set_error("conv: no kernel for tile %dx%d", bm, bn);
+  return UDET_ERR_UNSUPPORTED;
 }
 
 }  // namespace udet

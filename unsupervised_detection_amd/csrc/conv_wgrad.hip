@@ -1,9 +1,6 @@
 // Backward-filter (wgrad) of the convolutions on the fp32 matrix cores, plus bias / BN
-// parameter gradients.  GEMM view per filter tap t:
-//     dW[t][ci][co] = sum_q X(q@t)[ci] * dU[q][co],   dU = dY * act'(saved output)
-//   M = input channels, N = output channels, K = output pixels (split across workgroups).
-// Both operands are pixel-major in memory ([pixel][channel]) which is exactly the K-major
-// LDS image the MFMA fragments want, so staging is plain float4 copies.
+// parameter gradients:
+//     dW[t][ci][co] = sum_q X(q@t)[ci] * dU[q][co],   dU = dY * act'(saved output),   db[co] = sum_q dU[q][co]
 // Replaces TF-1.13 Conv2DBackpropFilter / BiasAddGrad / FusedBatchNormGrad(inference) reached
 // through optimizer.compute_gradients (models/utils/loss_utils.py:18).
 #include "common.h"
@@ -13,26 +10,50 @@ namespace udet {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-template <int BM, int BN, int BKP>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, int co_tiles, int nsplit, int T) {
-  constexpr int WTM = BM / 2, WTN = BN / 2;
+// One GEMM per layer:  M = (tap, input channel) flattened (m = tap*Cin4 + ci, Cin4 = Cin rounded up to 4),
+// N = output channels, K = output pixels, split across workgroups (blockIdx.y).  A 128-row M tile of a 7x7 conv
+// over 4 channels therefore holds 32 taps instead of one tap padded 16x, and every tap of a layer shares one pass
+// over dU.  Stage = 32 pixels; both operands are pixel-major in memory == the K-major LDS image the MFMA
+// fragments want, so staging is plain float4 copies (the A float4 of a thread always comes from the same tap).
+// The bias gradient (column sums of dU) is accumulated from the B stages already in LDS by the m-tile-0 workgroups.
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, int co_tiles, int nsplit) {
+  constexpr int BKP = 32;
+  constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
   constexpr int TM = WTM / 32, TN = WTN / 32;
-  constexpr int A_F4_PER_ROW = BM / 4, B_F4_PER_ROW = BN / 4;
-  constexpr int A_F4 = BKP * A_F4_PER_ROW, B_F4 = BKP * B_F4_PER_ROW;
-  constexpr int A_LD = (A_F4 + 255) / 256, B_LD = (B_F4 + 255) / 256;
+  static_assert(WAVES_M * WAVES_N == 4 && TM * 32 == WTM && TN * 32 == WTN, "tile");
+  constexpr int A_F4_ROW = BM / 4, B_F4_ROW = BN / 4;
+  constexpr int A_PIX = 256 / A_F4_ROW, B_PIX = 256 / B_F4_ROW;  // pixels staged per pass
+  constexpr int A_LD = BKP / A_PIX, B_LD = BKP / B_PIX;
+  static_assert(A_LD >= 1 && B_LD >= 1, "tile");
   __shared__ __attribute__((aligned(16))) float As[2][BKP][BM];
   __shared__ __attribute__((aligned(16))) float Bs[2][BKP][BN];
+  __shared__ int2 tap_yx[UDET_MAX_TAPS];
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
-  const int ci0 = (blockIdx.x / co_tiles) * BM, co0 = (blockIdx.x % co_tiles) * BN;
-  const ConvTap tap = p.taps[blockIdx.y];
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N, li = lane & 31, lh = lane >> 5;
+  const int mt = blockIdx.x / co_tiles;
+  const int m0 = mt * BM, co0 = (blockIdx.x - mt * co_tiles) * BN;
   const int OHW = p.OH * p.OW;
   const int Q = p.N * OHW;
   const int nchunks = (Q + BKP - 1) / BKP;
-  const int c_begin = (int)((long)nchunks * blockIdx.z / nsplit), c_end = (int)((long)nchunks * (blockIdx.z + 1) / nsplit);
+  const int c_begin = (int)((long)nchunks * blockIdx.y / nsplit), c_end = (int)((long)nchunks * (blockIdx.y + 1) / nsplit);
   const int Hs = p.H >> p.up_shift, Ws = p.W >> p.up_shift;
-  const int cin4 = (p.Cin + 3) & ~3, cout4 = (p.Cout + 3) & ~3;
+  const int cout4 = (p.Cout + 3) & ~3;
+
+  for (int i = t; i < p.ntaps; i += 256) tap_yx[i] = make_int2(p.taps[i].dy, p.taps[i].dx);
+  __syncthreads();
+  // this thread's A column group: 4 consecutive input channels of one tap
+  const int a_m4 = t % A_F4_ROW;
+  const int a_m = m0 + a_m4 * 4;
+  const int a_tap = a_m / p.Cin4, a_ci = a_m - a_tap * p.Cin4;
+  const bool a_on = a_tap < p.ntaps;
+  int a_dy = 0, a_dx = 0;
+  if (a_on) { a_dy = tap_yx[a_tap].x; a_dx = tap_yx[a_tap].y; }
+  const float* a_src = p.x + p.x_coff + a_ci;
+  const int b_c4 = t % B_F4_ROW;
+  const int b_co = co0 + b_c4 * 4;
+  const bool b_on = b_co < cout4;
 
   floatx16 acc[TM][TN];
 #pragma unroll
@@ -41,47 +62,40 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, in
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float bsum = 0.f;
 
   float4 ra[A_LD], rb[B_LD];
   auto load_chunk = [&](int c) {
     const int q0 = c * BKP;
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
-      const int idx = t + j * 256;
+      const int q = q0 + t / A_F4_ROW + j * A_PIX;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (idx < A_F4) {
-        const int kp = idx / A_F4_PER_ROW, c4 = idx - kp * A_F4_PER_ROW;
-        const int q = q0 + kp, ci = ci0 + c4 * 4;
-        if (q < Q && ci < cin4) {
-          const int n = q / OHW, rem = q - n * OHW;
-          const int oy = rem / p.OW, ox = rem - oy * p.OW;
-          int iy = oy * p.isy + tap.dy, ix = ox * p.isx + tap.dx;
-          if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
-            iy >>= p.up_shift;
-            ix >>= p.up_shift;
-            v = *reinterpret_cast<const float4*>(p.x + (size_t)((n * Hs + iy) * Ws + ix) * p.ldx + p.x_coff + ci);
-          }
+      if (a_on && q < Q) {
+        const int n = (int)fdiv(q, p.fd_ohw), rem = q - n * OHW;
+        const int oy = (int)fdiv(rem, p.fd_ow), ox = rem - oy * p.OW;
+        int iy = oy * p.isy + a_dy, ix = ox * p.isx + a_dx;
+        if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
+          iy >>= p.up_shift;
+          ix >>= p.up_shift;
+          v = *reinterpret_cast<const float4*>(a_src + (size_t)((n * Hs + iy) * Ws + ix) * p.ldx);
         }
       }
       ra[j] = v;
     }
 #pragma unroll
     for (int j = 0; j < B_LD; ++j) {
-      const int idx = t + j * 256;
+      const int q = q0 + t / B_F4_ROW + j * B_PIX;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (idx < B_F4) {
-        const int kp = idx / B_F4_PER_ROW, c4 = idx - kp * B_F4_PER_ROW;
-        const int q = q0 + kp, co = co0 + c4 * 4;
-        if (q < Q && co < cout4) {
-          const size_t off = (size_t)q * p.ldy + p.y_coff + co;
-          v = *reinterpret_cast<const float4*>(p.dy + off);
-          if (p.ya) {
-            const float4 a = *reinterpret_cast<const float4*>(p.ya + off);
-            v.x *= act_dfo(a.x, p.yact, p.yalpha);
-            v.y *= act_dfo(a.y, p.yact, p.yalpha);
-            v.z *= act_dfo(a.z, p.yact, p.yalpha);
-            v.w *= act_dfo(a.w, p.yact, p.yalpha);
-          }
+      if (b_on && q < Q) {
+        const size_t off = (size_t)q * p.ldy + p.y_coff + b_co;
+        v = *reinterpret_cast<const float4*>(p.dy + off);
+        if (p.ya) {
+          const float4 a = *reinterpret_cast<const float4*>(p.ya + off);
+          v.x *= act_dfo(a.x, p.yact, p.yalpha);
+          v.y *= act_dfo(a.y, p.yact, p.yalpha);
+          v.z *= act_dfo(a.z, p.yact, p.yalpha);
+          v.w *= act_dfo(a.w, p.yact, p.yalpha);
         }
       }
       rb[j] = v;
@@ -89,21 +103,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, in
   };
   auto store_chunk = [&](int buf) {
 #pragma unroll
-    for (int j = 0; j < A_LD; ++j) {
-      const int idx = t + j * 256;
-      if (idx < A_F4) {
-        const int kp = idx / A_F4_PER_ROW, c4 = idx - kp * A_F4_PER_ROW;
-        *reinterpret_cast<float4*>(&As[buf][kp][c4 * 4]) = ra[j];
-      }
-    }
+    for (int j = 0; j < A_LD; ++j) *reinterpret_cast<float4*>(&As[buf][t / A_F4_ROW + j * A_PIX][a_m4 * 4]) = ra[j];
 #pragma unroll
-    for (int j = 0; j < B_LD; ++j) {
-      const int idx = t + j * 256;
-      if (idx < B_F4) {
-        const int kp = idx / B_F4_PER_ROW, c4 = idx - kp * B_F4_PER_ROW;
-        *reinterpret_cast<float4*>(&Bs[buf][kp][c4 * 4]) = rb[j];
-      }
-    }
+    for (int j = 0; j < B_LD; ++j) *reinterpret_cast<float4*>(&Bs[buf][t / B_F4_ROW + j * B_PIX][b_c4 * 4]) = rb[j];
   };
 
   if (c_begin < c_end) {
@@ -127,74 +129,48 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, in
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
     }
+    if (mt == 0 && t < BN) {
+#pragma unroll
+      for (int k = 0; k < BKP; ++k) bsum += Bs[buf][k][t];
+    }
     if (more) store_chunk(buf ^ 1);
     __syncthreads();
     buf ^= 1;
   }
 
-  float* dst = p.partial + ((size_t)blockIdx.z * T + tap.widx) * p.Cin * p.Cout;
+  // partial[split][Mpad][ldn] (+ bias partials pb[split][ldn]); padding rows / columns are written too (zeros)
+  const int ldn = co_tiles * BN;
+  float* dst = p.partial + (size_t)blockIdx.y * p.Mpad * ldn;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int ci = ci0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (ci >= p.Cin) continue;
+      const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int co = co0 + wn * WTN + j * 32 + li;
-        if (co < p.Cout) dst[(size_t)ci * p.Cout + co] = acc[i][j][r];
-      }
+      for (int j = 0; j < TN; ++j) dst[(size_t)m * ldn + co0 + wn * WTN + j * 32 + li] = acc[i][j][r];
     }
+  if (mt == 0 && t < BN) p.pbias[(size_t)blockIdx.y * ldn + co0 + t] = bsum;
 }
 
-// dw[e] = sum_s partial[s][e]
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
-                                                           long n, int nsplit) {
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+// dw[widx][ci][co] = sum_s partial[s][tap*Cin4+ci][co] ; db[co] = sum_s pbias[s][co]   (deterministic order)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradParams p, int ldn, int nsplit) {
+  const int Mreal = p.ntaps * p.Cin4;
+  const long total = (long)(Mreal + 1) * p.Cout;
+  const size_t slab = (size_t)p.Mpad * ldn;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int m = (int)(e / p.Cout), co = (int)(e - (long)m * p.Cout);
     float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += partial[(size_t)k * n + e];
-    dw[e] = s;
-  }
-}
-
-// ---- bias gradient: S[co] = sum_q dY[q][co]*act'(ya[q][co]) ; two deterministic stages ----
-#define BG_BLOCKS 128
-__global__ __launch_bounds__(256) void bias_grad_stage1(const float* __restrict__ dy, const float* __restrict__ ya, int ld,
-                                                        int coff, int C, int act, float alpha, long Q,
-                                                        float* __restrict__ pb) {
-  __shared__ float red[256];
-  const int t = threadIdx.x;
-  const int cw = C < 256 ? C : 256;           // channels handled per pass
-  const int rows = 256 / cw > 0 ? 256 / cw : 1;  // pixel rows handled in parallel
-  const long q_begin = Q * blockIdx.x / gridDim.x, q_end = Q * (blockIdx.x + 1) / gridDim.x;
-  for (int cbase = 0; cbase < C; cbase += cw) {
-    const int cx = t % cw, ry = t / cw;
-    const int c = cbase + cx;
-    float s = 0.f;
-    if (ry < rows && c < C) {
-      for (long q = q_begin + ry; q < q_end; q += rows) {
-        const size_t off = (size_t)q * ld + coff + c;
-        float v = dy[off];
-        if (ya) v *= act_dfo(ya[off], act, alpha);
-        s += v;
-      }
+    if (m == Mreal) {
+      if (!p.db) continue;
+      for (int k = 0; k < nsplit; ++k) s += p.pbias[(size_t)k * ldn + co];
+      p.db[co] = s;
+      continue;
     }
-    red[t] = s;
-    __syncthreads();
-    if (ry == 0 && c < C) {
-      float tot = 0.f;
-      for (int r = 0; r < rows; ++r) tot += red[r * cw + cx];
-      pb[(size_t)blockIdx.x * C + c] = tot;
-    }
-    __syncthreads();
-  }
-}
-__global__ void bias_grad_stage2(const float* __restrict__ pb, float* __restrict__ db, int C, int nblk) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c < C) {
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += pb[(size_t)b * C + c];
-    db[c] = s;
+    const int tap = m / p.Cin4, ci = m - tap * p.Cin4;
+    if (ci >= p.Cin) continue;
+    const float* src = p.partial + (size_t)m * ldn + co;
+    for (int k = 0; k < nsplit; ++k) s += src[k * slab];
+    p.dw[((size_t)p.taps[tap].widx * p.Cin + ci) * p.Cout + co] = s;
   }
 }
 
@@ -235,14 +211,15 @@ __global__ __launch_bounds__(256) void bn_finish_kernel(float* __restrict__ dw, 
 }
 
 size_t wgrad_partial_floats_needed(int T, int Cin, int Cout) {
-  // one split of filter partials + bias-grad stage-1 partials + BN dot partials
-  return (size_t)BG_BLOCKS * Cout + (size_t)BND_SPLIT * Cout + (size_t)T * Cin * Cout;
+  // BN dot partials + one split of (bias, filter) partials at the padded tile sizes
+  const size_t cin4 = (size_t)((Cin + 3) & ~3), mpad = (T * cin4 + 127) / 128 * 128, ldn = (size_t)(Cout + 127) / 128 * 128;
+  return (size_t)BND_SPLIT * Cout + ldn + mpad * ldn + 64;
 }
 
-template <int BM, int BN>
-static void wgrad_launch(const WgradParams& p, int ci_tiles, int co_tiles, int nsplit, int T, hipStream_t stream) {
-  dim3 grid(ci_tiles * co_tiles, p.ntaps, nsplit);
-  hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, 16>), grid, dim3(256), 0, stream, p, co_tiles, nsplit, T);
+template <int BM, int BN, int WM_, int WN_>
+static void wgrad_launch(const WgradParams& p, int m_tiles, int co_tiles, int nsplit, hipStream_t stream) {
+  dim3 grid(m_tiles * co_tiles, nsplit);
+  hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM_, WN_>), grid, dim3(256), 0, stream, p, co_tiles, nsplit);
 }
 
 // p.taps must list the (non-culled) taps with widx = ky*kw+kx; T = kh*kw.
@@ -251,45 +228,48 @@ int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream) {
     set_error("wgrad: ldx=%d x_coff=%d ldy=%d y_coff=%d must be multiples of 4", p.ldx, p.x_coff, p.ldy, p.y_coff);
     return UDET_ERR_ALIGN;
   }
-  const int bm = p.Cin > 64 ? 128 : 64, bn = p.Cout > 64 ? 128 : 64;
-  const int ci_tiles = (p.Cin + bm - 1) / bm, co_tiles = (p.Cout + bn - 1) / bn;
+  const int BM = 128;
+  const int bn = p.Cout > 64 ? 128 : (p.Cout > 32 ? 64 : 32);
+  p.Cin4 = (p.Cin + 3) & ~3;
+  const int Mreal = p.ntaps * p.Cin4;
+  const int m_tiles = Mreal > 0 ? (Mreal + BM - 1) / BM : 1, co_tiles = (p.Cout + bn - 1) / bn;
+  p.Mpad = m_tiles * BM;
+  const int ldn = co_tiles * bn;
   const long Q = (long)p.N * p.OH * p.OW;
-  const int nchunks = (int)((Q + 15) / 16);
-  const size_t wsz = (size_t)T * p.Cin * p.Cout;
-  float* pb = p.partial;                                   // [BG_BLOCKS][Cout]
-  float* pd = pb + (size_t)BG_BLOCKS * p.Cout;             // [BND_SPLIT][Cout]
-  float* pw = pd + (size_t)BND_SPLIT * p.Cout;             // [nsplit][T][Cin][Cout]
-  const size_t fixed = (size_t)(pw - p.partial);
-  if (p.partial_floats < fixed + wsz) {
-    set_error("wgrad: workspace too small (%zu < %zu floats)", p.partial_floats, fixed + wsz);
+  const int nchunks = (int)((Q + 31) / 32);
+  p.fd_ohw = make_fastdiv((unsigned)(p.OH * p.OW));
+  p.fd_ow = make_fastdiv((unsigned)p.OW);
+  float* pd = p.partial;                                 // [BND_SPLIT][Cout]
+  float* base = pd + (size_t)BND_SPLIT * p.Cout;
+  base += (16 - ((uintptr_t)base / sizeof(float)) % 16) % 16;  // keep the slabs 64-byte aligned
+  const size_t fixed = (size_t)(base - p.partial);
+  const size_t per_split = (size_t)ldn + (size_t)p.Mpad * ldn;
+  if (p.partial_floats < fixed + per_split) {
+    set_error("wgrad: workspace too small (%zu < %zu floats)", p.partial_floats, fixed + per_split);
     return UDET_ERR_ARG;
   }
-  const long tiles = (long)ci_tiles * co_tiles * (p.ntaps > 0 ? p.ntaps : 1);
+  const long tiles = (long)m_tiles * co_tiles;
   int nsplit = (int)((768 + tiles - 1) / tiles);
-  if (nsplit > nchunks / 4) nsplit = nchunks / 4;
-  const size_t maxs = (p.partial_floats - fixed) / wsz;
+  if (nsplit > nchunks / 2) nsplit = nchunks / 2;
+  const size_t maxs = (p.partial_floats - fixed) / per_split;
   if ((size_t)nsplit > maxs) nsplit = (int)maxs;
   if (nsplit < 1) nsplit = 1;
-  if (p.ntaps < T) UDET_HIP(hipMemsetAsync(pw, 0, (size_t)nsplit * wsz * sizeof(float), stream));
+  const size_t wsz = (size_t)T * p.Cin * p.Cout;
+  if (p.ntaps < T) UDET_HIP(hipMemsetAsync(p.dw, 0, wsz * sizeof(float), stream));  // culled taps have zero gradient
   WgradParams q = p;
-  q.partial = pw;
-  if (p.ntaps > 0) {
-    if (bm == 128 && bn == 128) wgrad_launch<128, 128>(q, ci_tiles, co_tiles, nsplit, T, stream);
-    else if (bm == 128) wgrad_launch<128, 64>(q, ci_tiles, co_tiles, nsplit, T, stream);
-    else if (bn == 128) wgrad_launch<64, 128>(q, ci_tiles, co_tiles, nsplit, T, stream);
-    else wgrad_launch<64, 64>(q, ci_tiles, co_tiles, nsplit, T, stream);
-    UDET_HIP(hipGetLastError());
-  }
-  int nb = (int)((wsz + 255) / 256);
-  if (nb > 2048) nb = 2048;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nb), dim3(256), 0, stream, pw, p.dw, (long)wsz, nsplit);
+  q.pbias = base;                                  // [nsplit][ldn]
+  q.partial = base + (size_t)nsplit * ldn;        // [nsplit][Mpad][ldn]
+  if (bn == 128) wgrad_launch<128, 128, 2, 2>(q, m_tiles, co_tiles, nsplit, stream);
+  else if (bn == 64) wgrad_launch<128, 64, 2, 2>(q, m_tiles, co_tiles, nsplit, stream);
+  else wgrad_launch<128, 32, 4, 1>(q, m_tiles, co_tiles, nsplit, stream);
   UDET_HIP(hipGetLastError());
-  if (p.db) {
-    hipLaunchKernelGGL(bias_grad_stage1, dim3(BG_BLOCKS), dim3(256), 0, stream, p.dy, p.ya, p.ldy, p.y_coff, p.Cout,
-                       p.yact, p.yalpha, Q, pb);
-    hipLaunchKernelGGL(bias_grad_stage2, dim3((p.Cout + 127) / 128), dim3(128), 0, stream, pb, p.db, p.Cout, BG_BLOCKS);
-    UDET_HIP(hipGetLastError());
-  }
+  const long total = (long)(Mreal + 1) * p.Cout;
+  int nb = (int)((total + 255) / 256);
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nb), dim3(256), 0, stream, q, ldn, nsplit);
+  UDET_HIP(hipGetLastError());
+  int nbw = (int)((wsz + 255) / 256);
+  if (nbw > 2048) nbw = 2048;
   if (p.gamma) {
     if (!p.db || !p.dgamma || !p.dbeta || !p.w || !p.b) {
       set_error("wgrad: BN finalisation needs db, dgamma, dbeta, w and b");
@@ -297,7 +277,7 @@ int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream) {
     }
     hipLaunchKernelGGL(bn_dot_kernel, dim3((p.Cout + 63) / 64, BND_SPLIT), dim3(256), 0, stream, p.w, p.dw, T * p.Cin,
                        p.Cout, pd);
-    hipLaunchKernelGGL(bn_finish_kernel, dim3(nb), dim3(256), 0, stream, p.dw, (long)wsz, p.Cout, p.gamma, p.b, p.bn_c, pd,
+    hipLaunchKernelGGL(bn_finish_kernel, dim3(nbw), dim3(256), 0, stream, p.dw, (long)wsz, p.Cout, p.gamma, p.b, p.bn_c, pd,
                        p.db, p.dgamma, p.dbeta);
     UDET_HIP(hipGetLastError());
   }

@@ -73,7 +73,7 @@ struct Plan {
   size_t small_off = 0;          // losses, coefficients, flags, reduction partials
   size_t seg_off[3] = {0, 0, 0}; // per-variable (offset,len) tables on device (as long)
   // optional per-category timing with HIP events on the launch stream (bench.py roofline)
-  struct ProfRec { int cat; double flops, bytes; hipEvent_t a, b; };
+  struct ProfRec { int cat; double flops, bytes; hipEvent_t a, b; std::string name; };
   bool profiling = false;
   std::vector<ProfRec> prof;
   long adam_t = 0;               // number of optimizer applies so far (shared beta powers)
@@ -98,7 +98,7 @@ int plan_backward_recover(Plan* P, const float* w_rec, float* g_rec, float* ws, 
 int plan_backward_generator(Plan* P, const float* w_gen, float* g_gen, float* ws, hipStream_t s);
 int plan_apply(Plan* P, int net, float* w, float* g, float* m, float* v, float* ws, hipStream_t s);
 enum { PROF_CONV_FWD = 0, PROF_CONV_DGRAD = 1, PROF_CONV_WGRAD = 2, PROF_WARP = 3, PROF_CORR = 4, PROF_NCAT = 5 };
-void prof_begin(Plan* P, int cat, double flops, double bytes, hipStream_t s);
+void prof_begin(Plan* P, int cat, double flops, double bytes, hipStream_t s, const char* name = "");
 void prof_end(Plan* P, hipStream_t s);
 
 }  // namespace udet

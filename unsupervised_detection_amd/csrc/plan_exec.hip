@@ -25,10 +25,10 @@ static std::string S(const char* fmt, int a, int b = 0) {
 }
 
 // ------------------------------------------------------------ profiling ----
-void prof_begin(Plan* P, int cat, double flops, double bytes, hipStream_t s) {
+void prof_begin(Plan* P, int cat, double flops, double bytes, hipStream_t s, const char* name) {
   if (!P->profiling) return;
   Plan::ProfRec r;
-  r.cat = cat; r.flops = flops; r.bytes = bytes;
+  r.cat = cat; r.flops = flops; r.bytes = bytes; r.name = name ? name : "";
   (void)hipEventCreate(&r.a);
   (void)hipEventCreate(&r.b);
   (void)hipEventRecord(r.a, s);
@@ -57,8 +57,8 @@ static void fill_common(Plan* P, ConvParams& p, float* ws) {
 
 static int run_fwd(Plan* P, const Layer& L, int N, float* ws, hipStream_t s, size_t x_extra = 0, size_t y_extra = 0) {
   const Buf &bx = P->buf(L.x), &by = P->buf(L.y);
-  const int ncls = L.transposed ? 4 : 1;
-  prof_begin(P, PROF_CONV_FWD, layer_flops(L, N), 0, s);
+  const int ncls = L.transposed ? conv_dgrad_classes(2, 2 * L.H, 2 * L.W) : 1;
+  prof_begin(P, PROF_CONV_FWD, layer_flops(L, N), 0, s, L.name.c_str());
   for (int cls = 0; cls < ncls; ++cls) {
     ConvParams p;
     memset(&p, 0, sizeof(p));
@@ -91,8 +91,8 @@ static int run_dgrad(Plan* P, const Layer& L, int N, int dy, int dx, int dx_coff
     return UDET_ERR_SHAPE;
   }
   const int up = L.up ? 1 : 0;
-  prof_begin(P, PROF_CONV_DGRAD, layer_flops(L, N), 0, s);
-  for (int cls = 0; cls < conv_dgrad_classes(L.stride); ++cls) {
+  prof_begin(P, PROF_CONV_DGRAD, layer_flops(L, N), 0, s, L.name.c_str());
+  for (int cls = 0; cls < conv_dgrad_classes(L.stride, L.H << up, L.W << up); ++cls) {
     ConvParams p;
     memset(&p, 0, sizeof(p));
     if (!conv_setup_dgrad(p, cls, N, L.H << up, L.W << up, L.kh, L.kw, L.stride, L.dil)) continue;
@@ -138,7 +138,7 @@ static int run_wgrad(Plan* P, const Layer& L, int N, int dy, const float* w_flat
     q.dbeta = g_flat + np.p[L.be_idx].offset;
     q.bn_c = BN_C;
   }
-  prof_begin(P, PROF_CONV_WGRAD, layer_flops(L, N), 0, s);
+  prof_begin(P, PROF_CONV_WGRAD, layer_flops(L, N), 0, s, L.name.c_str());
   const int rc = launch_wgrad_T(q, L.kh * L.kw, s);
   prof_end(P, s);
   return rc;
