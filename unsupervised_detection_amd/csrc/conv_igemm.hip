@@ -248,16 +248,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   }
 }
 
-// second pass of a split-K launch: sum the partial slabs and run the epilogue
+// second pass of a split-K launch: sum the partial slabs and run the epilogue.  SL lanes share one output element
+// (each sums every SL-th slab, then a fixed-order shuffle tree): small outputs with many splits stay parallel.
+template <int SL>
 __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const ConvParams p) {
   const int OHWq = p.OHq * p.OWq;
   const int Mtot = p.N * OHWq;
   const int Mall = p.ncls * Mtot;
   const long total = (long)Mall * p.Cout;
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+  const int sl = threadIdx.x % SL;
+  for (long e = ((long)blockIdx.x * 256 + threadIdx.x) / SL; e < total; e += (long)gridDim.x * (256 / SL)) {
     const int ma = (int)(e / p.Cout), n = (int)(e - (long)ma * p.Cout);
     float v = 0.f;
-    for (int s = 0; s < p.ksplit; ++s) v += p.partial[((size_t)s * Mall + ma) * p.ldp + n];
+    for (int s = sl; s < p.ksplit; s += SL) v += p.partial[((size_t)s * Mall + ma) * p.ldp + n];
+#pragma unroll
+    for (int d = SL / 2; d > 0; d >>= 1) v += __shfl_xor(v, d, SL);
+    if (sl != 0) continue;
     const int cls = ma / Mtot, m = ma - cls * Mtot;
     const int ooy = p.ncls > 1 ? (cls >> 1) : p.ooy, oox = p.ncls > 1 ? (cls & 1) : p.oox;
     const int nb = (int)fdiv(m, p.fd_ohw), rem = m - nb * OHWq;
@@ -281,9 +287,13 @@ static int launch_cfg(const ConvParams& p, hipStream_t stream) {
   UDET_HIP(hipGetLastError());
   if (p.ksplit > 1) {
     const long total = (long)p.ncls * Mtot * p.Cout;
-    int nb = (int)((total + 255) / 256);
-    if (nb > 2048) nb = 2048;
-    hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3(nb), dim3(256), 0, stream, p);
+    // lanes per element: keep >= ~64k threads busy while the split count allows it
+    const int sl = (p.ksplit >= 16 && total * 16 <= 262144) ? 16 : ((p.ksplit >= 4 && total * 4 <= 262144) ? 4 : 1);
+    long nbl = (total * sl + 255) / 256;
+    const int nb = (int)(nbl > 4096 ? 4096 : nbl);
+    if (sl == 16) hipLaunchKernelGGL(conv_splitk_epilogue_kernel<16>, dim3(nb), dim3(256), 0, stream, p);
+    else if (sl == 4) hipLaunchKernelGGL(conv_splitk_epilogue_kernel<4>, dim3(nb), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(conv_splitk_epilogue_kernel<1>, dim3(nb), dim3(256), 0, stream, p);
     UDET_HIP(hipGetLastError());
   }
   return UDET_OK;

@@ -152,25 +152,30 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, in
   if (mt == 0 && t < BN) p.pbias[(size_t)blockIdx.y * ldn + co0 + t] = bsum;
 }
 
-// dw[widx][ci][co] = sum_s partial[s][tap*Cin4+ci][co] ; db[co] = sum_s pbias[s][co]   (deterministic order)
+// dw[widx][ci][co] = sum_s partial[s][tap*Cin4+ci][co] ; db[co] = sum_s pbias[s][co].  SL lanes share one element
+// (each sums every SL-th split, then a fixed-order shuffle tree): deterministic, and parallel for tiny filters.
+template <int SL>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradParams p, int ldn, int nsplit) {
   const int Mreal = p.ntaps * p.Cin4;
   const long total = (long)(Mreal + 1) * p.Cout;
   const size_t slab = (size_t)p.Mpad * ldn;
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+  const int sl = threadIdx.x % SL;
+  for (long e = ((long)blockIdx.x * 256 + threadIdx.x) / SL; e < total; e += (long)gridDim.x * (256 / SL)) {
     const int m = (int)(e / p.Cout), co = (int)(e - (long)m * p.Cout);
+    const bool is_bias = m == Mreal;
+    const float* src = is_bias ? p.pbias + co : p.partial + (size_t)m * ldn + co;
+    const size_t stride = is_bias ? (size_t)ldn : slab;
     float s = 0.f;
-    if (m == Mreal) {
-      if (!p.db) continue;
-      for (int k = 0; k < nsplit; ++k) s += p.pbias[(size_t)k * ldn + co];
-      p.db[co] = s;
+    for (int k = sl; k < nsplit; k += SL) s += src[k * stride];
+#pragma unroll
+    for (int d = SL / 2; d > 0; d >>= 1) s += __shfl_xor(s, d, SL);
+    if (sl != 0) continue;
+    if (is_bias) {
+      if (p.db) p.db[co] = s;
       continue;
     }
     const int tap = m / p.Cin4, ci = m - tap * p.Cin4;
-    if (ci >= p.Cin) continue;
-    const float* src = p.partial + (size_t)m * ldn + co;
-    for (int k = 0; k < nsplit; ++k) s += src[k * slab];
-    p.dw[((size_t)p.taps[tap].widx * p.Cin + ci) * p.Cout + co] = s;
+    if (ci < p.Cin) p.dw[((size_t)p.taps[tap].widx * p.Cin + ci) * p.Cout + co] = s;
   }
 }
 
@@ -264,9 +269,12 @@ int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream) {
   else wgrad_launch<128, 32, 4, 1>(q, m_tiles, co_tiles, nsplit, stream);
   UDET_HIP(hipGetLastError());
   const long total = (long)(Mreal + 1) * p.Cout;
-  int nb = (int)((total + 255) / 256);
-  if (nb > 2048) nb = 2048;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nb), dim3(256), 0, stream, q, ldn, nsplit);
+  const int sl = (nsplit >= 64 && total * 64 <= 262144) ? 64 : ((nsplit >= 8 && total * 8 <= 262144) ? 8 : 1);
+  const long nbl = (total * sl + 255) / 256;
+  const int nb = (int)(nbl > 4096 ? 4096 : nbl);
+  if (sl == 64) hipLaunchKernelGGL(wgrad_reduce_kernel<64>, dim3(nb), dim3(256), 0, stream, q, ldn, nsplit);
+  else if (sl == 8) hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3(nb), dim3(256), 0, stream, q, ldn, nsplit);
+  else hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(nb), dim3(256), 0, stream, q, ldn, nsplit);
   UDET_HIP(hipGetLastError());
   int nbw = (int)((wsz + 255) / 256);
   if (nbw > 2048) nbw = 2048;
