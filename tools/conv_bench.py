@@ -39,7 +39,8 @@ SHAPES = [
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--cfg", action="append", default=[], help="bm,bn,ks forced configuration (repeatable); default heuristics always run")
+    ap.add_argument("--cfg", action="append", default=[], help="bm,bn,ks forced configuration (repeatable; bm+65536 selects the non-specialised 256-thread kernel); "
+                    "the default heuristics always run")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default="")
     args = ap.parse_args()
@@ -60,7 +61,8 @@ def main():
             else:
                 lib.udet_debug_force_conv(*cfg)
             try:
-                ops.conv2d(x, wt, b, s, d, "leaky", 0.1, up)
+                for _ in range(args.reps):  # warm-up: clocks ramp over the first launches
+                    ops.conv2d(x, wt, b, s, d, "leaky", 0.1, up)
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -69,7 +71,8 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 us_ = e0.elapsed_time(e1) * 1e3 / args.reps
-                line += f" {'auto' if cfg is None else 'x'.join(map(str, cfg)):>11s}: {us_:7.1f}us {gflop / us_ * 1e-3 * 1e3:6.1f}TF |"
+                tag = "auto" if cfg is None else "x".join(map(str, (cfg[0] & 0xffff,) + cfg[1:])) + ("n" if cfg[0] >> 16 else "")
+                line += f" {tag:>11s}: {us_:7.1f}us {gflop / us_ * 1e3:6.1f}TF |"
             except Exception as ex:  # unsupported forced tile
                 line += f" {'x'.join(map(str, cfg))}: n/a |"
         print(line, flush=True)

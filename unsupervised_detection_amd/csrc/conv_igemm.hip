@@ -16,15 +16,21 @@
 // Replaces the TF-1.13 Conv2D / Conv2DBackpropInput kernels the reference calls through
 // tf.layers.conv2d / tf.nn.conv2d / tf.layers.conv2d_transpose
 // (models/utils/convolution_utils.py:46,81; models/PWCNet/model_pwcnet.py:161-165,286,484-504,562-574).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace udet {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
+// WS (wave specialisation): 512-thread workgroups; waves 0-3 only read fragments from LDS and issue MFMAs, waves
+// 4-7 only stage (global -> registers -> LDS) one stage ahead.  The matrix pipe of a SIMD is then fed by waves that
+// never wait on HBM/L2 or on address arithmetic; one raw s_barrier per stage hands the buffers over.
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool WS>
+__global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 2) void conv_igemm_kernel(const ConvParams p) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+  constexpr int NT = WS ? 512 : 256;
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
   constexpr int TM = WTM / 32, TN = WTN / 32;
   static_assert(TM * 32 == WTM && TN * 32 == WTN, "wave tile must be a multiple of 32");
@@ -43,7 +49,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   __shared__ int2 tap_yx[UDET_MAX_TAPS];
   __shared__ int tap_w[UDET_MAX_TAPS];
 
-  const int t = threadIdx.x;
+  const int tid = threadIdx.x;
+  const int role = __builtin_amdgcn_readfirstlane(tid >> 8);  // WS: 0 = MFMA waves, 1 = staging waves
+  const int t = tid & 255;                                    // index inside the role's 256 threads
   const int lane = t & 63, wave = t >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int li = lane & 31, lh = lane >> 5;
@@ -66,11 +74,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
   const int Hs = p.H >> p.up_shift, Ws = p.W >> p.up_shift;
 
   // ---- per-block tables -----------------------------------------------------
-  for (int i = t; i < ntc; i += 256) {
+  for (int i = tid; i < ntc; i += NT) {
     tap_yx[i] = make_int2(p.taps[tap0 + i].dy, p.taps[tap0 + i].dx);
     tap_w[i] = p.taps[tap0 + i].widx;
   }
-  for (int r = t; r < BM; r += 256) {
+  for (int r = tid; r < BM; r += NT) {
     const int m = m0 + r;
     int off = -1;
     if (m < Mtot) {
@@ -143,7 +151,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
       int iy = a_iy0[j] + dy, ix = a_ix0[j] + dx;
       const bool ok = a_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ok) {
+      if (ok && !(p.dbg & 1)) {
         iy >>= p.up_shift;
         ix >>= p.up_shift;
         const size_t off = (size_t)(a_base[j] + iy * Ws + ix) * p.ldx + p.x_coff + a_c;
@@ -163,7 +171,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
       const int c4 = (t + j * 256) % B_F4_ROW;
       const int n = n0 + c4 * 4;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (b_tap[j] < ntc && n < p.ldw)
+      if (b_tap[j] < ntc && n < p.ldw && !(p.dbg & 1))
         v = *reinterpret_cast<const float4*>(p.wp + ((size_t)tap_w[b_tap[j]] * Kc + b_c[j]) * p.ldw + n);
       rb[j] = v;
     }
@@ -177,6 +185,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     }
   };
   auto store_chunk = [&](int buf) {
+    if (p.dbg & 2) return;
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
       const int r = t / KQ + j * A_ROWS;
@@ -193,30 +202,78 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     }
   };
 
-  if (c_begin < c_end) {
-    load_chunk();
-    store_chunk(0);
-  }
-  __syncthreads();
-  int buf = 0;
-  for (int c = c_begin; c < c_end; ++c) {
-    const bool more = c + 1 < c_end;
-    if (more) load_chunk();
+  // MFMA stage: fragments are double-buffered in registers (reads for k-pair kk+1 are in flight while the matrix
+  // pipe works on kk), so a lone wave keeps the pipe fed without waiting out the LDS latency every 4 MFMAs.
+  auto compute_chunk = [&](int buf) {
+    float a[2][TM], b[2][TN];
+    auto frag = [&](int s, int kk) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[s][i] = As[buf][kk * 2 + lh][wm * WTM + i * 32 + li];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[s][j] = Bs[buf][kk * 2 + lh][wn * WTN + j * 32 + li];
+    };
+    frag(0, 0);
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
-      float a[TM], b[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = As[buf][kk * 2 + lh][wm * WTM + i * 32 + li];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = Bs[buf][kk * 2 + lh][wn * WTN + j * 32 + li];
+      if (kk + 1 < BK / 2) frag((kk + 1) & 1, kk + 1);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk & 1][i], b[kk & 1][j], acc[i][j], 0, 0, 0);
+      // pin the order: next k-pair's LDS reads are issued BEFORE this k-pair's MFMAs (hipcc otherwise sinks them)
+      if (kk + 1 < BK / 2) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
     }
-    if (more) store_chunk(buf ^ 1);
+  };
+
+  if constexpr (WS) {
+    // raw barriers: only LDS traffic is drained (lgkmcnt), global loads stay in flight across the hand-over
+    auto handover = [&]() {
+      if (p.dbg & 8) return;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    };
+    if (role == 1) {
+      if (c_begin < c_end) {
+        load_chunk();
+        store_chunk(0);
+        if (c_begin + 1 < c_end) load_chunk();
+      }
+      handover();
+      int buf = 0;
+      for (int c = c_begin; c < c_end; ++c) {
+        if (c + 1 < c_end) {
+          store_chunk(buf ^ 1);                  // stage c+1 (loaded during the previous iteration)
+          if (c + 2 < c_end) load_chunk();       // stage c+2 stays in flight over the barrier
+        }
+        handover();
+        buf ^= 1;
+      }
+      return;
+    }
+    handover();
+    int buf = 0;
+    for (int c = c_begin; c < c_end; ++c) {
+      compute_chunk(buf);
+      handover();
+      buf ^= 1;
+    }
+  } else {
+    if (c_begin < c_end) {
+      load_chunk();
+      store_chunk(0);
+    }
     __syncthreads();
-    buf ^= 1;
+    int buf = 0;
+    for (int c = c_begin; c < c_end; ++c) {
+      const bool more = c + 1 < c_end;
+      if (more) load_chunk();
+      compute_chunk(buf);
+      if (more) store_chunk(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
   }
 
   // ---- epilogue -------------------------------------------------------------
@@ -279,11 +336,18 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const ConvPar
   }
 }
 
+static int g_force_bm = 0, g_force_bn = 0, g_force_ks = -1, g_ws = 1;
+void conv_force_config(int bm, int bn, int ks) {
+  g_force_bm = bm & 0xffff; g_force_bn = bn; g_force_ks = ks;
+  g_ws = (bm >> 16) & 1 ? 0 : 1;  // bit 16 of bm: use the 256-thread non-specialised kernel
+}
+
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
 static int launch_cfg(const ConvParams& p, hipStream_t stream) {
   const int Mtot = p.N * p.OHq * p.OWq;
   dim3 grid(p.ncls * ((Mtot + BM - 1) / BM), (p.Cout + BN - 1) / BN, p.ksplit > 1 ? p.ksplit : 1);
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N>), grid, dim3(256), 0, stream, p);
+  if (g_ws) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, true>), grid, dim3(512), 0, stream, p);
+  else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, false>), grid, dim3(256), 0, stream, p);
   UDET_HIP(hipGetLastError());
   if (p.ksplit > 1) {
     const long total = (long)p.ncls * Mtot * p.Cout;
@@ -322,9 +386,6 @@ static int pick_ksplit(const ConvParams& p, long tiles, int bk) {
   return ks < 2 ? 1 : ks;
 }
 
-static int g_force_bm = 0, g_force_bn = 0, g_force_ks = -1;
-void conv_force_config(int bm, int bn, int ks) { g_force_bm = bm; g_force_bn = bn; g_force_ks = ks; }
-
 int launch_conv(ConvParams& p, hipStream_t stream) {
   if (p.Kc % 4 != 0 || p.ldx % 4 != 0 || p.x_coff % 4 != 0 || p.ldw % 4 != 0) {
     set_error("conv: Kc=%d ldx=%d x_coff=%d ldw=%d violate the 4-float alignment contract", p.Kc, p.ldx, p.x_coff, p.ldw);
@@ -345,6 +406,10 @@ int launch_conv(ConvParams& p, hipStream_t stream) {
   }
   p.fd_ohw = make_fastdiv((unsigned)(p.OHq * p.OWq));
   p.fd_ow = make_fastdiv((unsigned)p.OWq);
+  {
+    static const int dbg = getenv("UDET_DBG") ? atoi(getenv("UDET_DBG")) : 0;
+    p.dbg = dbg;
+  }
   // N tile from the channel count; M tile shrunk while the launch would leave CUs without a workgroup
   int bm, bn;
   if (p.Cout <= 32) { bn = 32; bm = 256; if (cfg_tiles(p, 256, 32) < 384) bm = 128; }

@@ -117,17 +117,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, in
   for (int c = c_begin; c < c_end; ++c) {
     const bool more = c + 1 < c_end;
     if (more) load_chunk(c + 1);
+    {
+      // register double-buffered fragments, order pinned (see conv_igemm.hip)
+      float a[2][TM], b[2][TN];
+      auto frag = [&](int s, int kk) {
 #pragma unroll
-    for (int kk = 0; kk < BKP / 2; ++kk) {
-      float a[TM], b[TN];
+        for (int i = 0; i < TM; ++i) a[s][i] = As[buf][kk * 2 + lh][wm * WTM + i * 32 + li];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = As[buf][kk * 2 + lh][wm * WTM + i * 32 + li];
+        for (int j = 0; j < TN; ++j) b[s][j] = Bs[buf][kk * 2 + lh][wn * WTN + j * 32 + li];
+      };
+      frag(0, 0);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = Bs[buf][kk * 2 + lh][wn * WTN + j * 32 + li];
+      for (int kk = 0; kk < BKP / 2; ++kk) {
+        if (kk + 1 < BKP / 2) frag((kk + 1) & 1, kk + 1);
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk & 1][i], b[kk & 1][j], acc[i][j], 0, 0, 0);
+        if (kk + 1 < BKP / 2) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+      }
     }
     if (mt == 0 && t < BN) {
 #pragma unroll

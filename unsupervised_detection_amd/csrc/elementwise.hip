@@ -423,21 +423,35 @@ int launch_mask_bwd(const float* dmask, const float* dfin, const float* f, const
 // ---------------------------------------------------------------------------
 // train_op (models/utils/loss_utils.py:12-32) + tf.train.AdamOptimizer apply
 // ---------------------------------------------------------------------------
-// stage 1: per-variable mean|g|
+// stage 1: per-variable sum|g|, each variable split over GA_SPLIT workgroups (deterministic two-stage reduction)
+#define GA_SPLIT 8
 __global__ __launch_bounds__(256) void grad_absmean_kernel(const float* __restrict__ g, const long* __restrict__ seg_off,
-                                                           const long* __restrict__ seg_len, float* __restrict__ vmean) {
+                                                           const long* __restrict__ seg_len, float* __restrict__ vpart) {
   __shared__ float sm[4];
   const long off = seg_off[blockIdx.x], len = seg_len[blockIdx.x];
-  float s = 0.f;
-  for (long i = threadIdx.x; i < len; i += 256) s += fabsf(g[off + i]);
-  s = block_sum(s, sm);
-  if (threadIdx.x == 0) vmean[blockIdx.x] = s / (float)len;
+  const long b = len * blockIdx.y / GA_SPLIT, e = len * (blockIdx.y + 1) / GA_SPLIT;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  long i = b + threadIdx.x;
+  for (; i + 768 < e; i += 1024) {
+    s0 += fabsf(g[off + i]);
+    s1 += fabsf(g[off + i + 256]);
+    s2 += fabsf(g[off + i + 512]);
+    s3 += fabsf(g[off + i + 768]);
+  }
+  for (; i < e; i += 256) s0 += fabsf(g[off + i]);
+  const float s = block_sum((s0 + s1) + (s2 + s3), sm);
+  if (threadIdx.x == 0) vpart[blockIdx.x * GA_SPLIT + blockIdx.y] = s;
 }
-// stage 2: mean over variables -> flag (1 = replace gradients by |U(-clip,clip)|)
-__global__ void grad_flag_kernel(const float* __restrict__ vmean, int nvars, float thresh, float* __restrict__ out /*[2]: avg, flag*/) {
+// stage 2: mean over variables of mean|g| -> flag (1 = replace gradients by |U(-clip,clip)|)
+__global__ void grad_flag_kernel(const float* __restrict__ vpart, const long* __restrict__ seg_len, int nvars, float thresh,
+                                 float* __restrict__ out /*[2]: avg, flag*/) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     float s = 0.f;
-    for (int i = 0; i < nvars; ++i) s += vmean[i];
+    for (int i = 0; i < nvars; ++i) {
+      float v = 0.f;
+      for (int j = 0; j < GA_SPLIT; ++j) v += vpart[i * GA_SPLIT + j];
+      s += v / (float)seg_len[i];
+    }
     s /= (float)nvars;
     out[0] = s;
     out[1] = s < thresh ? 1.f : 0.f;
@@ -445,8 +459,8 @@ __global__ void grad_flag_kernel(const float* __restrict__ vmean, int nvars, flo
 }
 int launch_grad_absmean(const float* g, const long* seg_off, const long* seg_len, int nvars, float* vmean, float thresh,
                         float* out, hipStream_t s) {
-  hipLaunchKernelGGL(grad_absmean_kernel, dim3(nvars), dim3(256), 0, s, g, seg_off, seg_len, vmean);
-  hipLaunchKernelGGL(grad_flag_kernel, dim3(1), dim3(64), 0, s, vmean, nvars, thresh, out);
+  hipLaunchKernelGGL(grad_absmean_kernel, dim3(nvars, GA_SPLIT), dim3(256), 0, s, g, seg_off, seg_len, vmean);
+  hipLaunchKernelGGL(grad_flag_kernel, dim3(1), dim3(64), 0, s, vmean, seg_len, nvars, thresh, out);
   UDET_HIP(hipGetLastError());
   return UDET_OK;
 }

@@ -308,7 +308,7 @@ int plan_recover_forward(Plan* P, int ncalls, float* ws, hipStream_t s, bool inp
 }
 
 // small region layout (floats from small_off): [0,8) losses, [16,16+4B) coef, [256,258) noise flag,
-// [512,..) per-variable |g| means, [1024,1024+5B) sums, [4096,..) flow-stat partials (doubles), [8192,..) loss partials
+// [2048,..) per-variable |g| partial sums, [1024,1024+5B) sums, [4096,..) flow-stat partials (doubles), [8192,..) loss partials
 int plan_losses(Plan* P, float* ws, hipStream_t s) {
   const Config& c = P->cfg;
   float* sm = ws + P->small_off;
@@ -427,7 +427,7 @@ int plan_apply(Plan* P, int net, float* w, float* g, float* m, float* v, float* 
   const float* flag = nullptr;
   if (net == NET_GEN) {  // can_change=True (adversarial_learner.py:224-228)
     const long* tab = reinterpret_cast<const long*>(ws + P->seg_off[net]);
-    UDET_TRY(launch_grad_absmean(g, tab, tab + np.p.size(), (int)np.p.size(), sm + 512, 1e-5f, sm + 256, s));
+    UDET_TRY(launch_grad_absmean(g, tab, tab + np.p.size(), (int)np.p.size(), sm + 2048, 1e-5f, sm + 256, s));
     flag = sm + 256;
   }
   const long t = ++P->adam_t;  // ONE optimizer object: beta powers advance on every apply (:216)
