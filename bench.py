@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=4, help="frame pairs per GPU (BASELINE.json: 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-autotune", action="store_true", help="use the built-in tile heuristics instead of the one-off autotune pass")
     ap.add_argument("--cpu-reps", type=int, default=5)
     args = ap.parse_args()
 
@@ -101,7 +102,7 @@ def main():
     from unsupervised_detection_amd.trainer import TrainState, train_step
 
     eng = Engine(EngineConfig(batch_size=args.batch), device=f"cuda:{local_rank}")
-    st = TrainState(eng, seed=8964)  # identical weights on every rank
+    st = TrainState(eng, seed=8964, autotune=not args.no_autotune)  # identical weights on every rank; kernels autotuned once
     f1, f2 = data.synthetic_davis_pairs(args.batch, 8964 + rank)  # distinct data per rank (weak scaling)
     img1 = data.preprocess_image(torch.from_numpy(f1).cuda())
     img2 = data.preprocess_image(torch.from_numpy(f2).cuda())

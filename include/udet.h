@@ -146,6 +146,17 @@ int udet_train_step(udet_plan* plan, int which, const float* img1, const float* 
                     float* g_gen, float* g_rec, float* m_gen, float* v_gen, float* m_rec, float* v_rec, void* workspace,
                     void* stream);
 
+/* Autotuner (the MI355X analogue of TF's cuDNN autotune the reference relies on implicitly): runs one untimed
+ * forward + both backward passes over random data; every distinct convolution problem of the plan times its candidate
+ * kernel configurations on `stream` and the fastest is cached process-wide (keyed by problem shape) for all later
+ * launches.  Needs packed weights (udet_pack_pwc / udet_pack_trainable); overwrites g_gen / g_rec and re-zeroes the
+ * activation regions of the workspace.  Optional: without it the built-in heuristics choose the configurations. */
+int udet_autotune(udet_plan* plan, const float* w_gen, const float* w_rec, float* g_gen, float* g_rec, void* workspace,
+                  void* stream);
+int udet_tuned_shapes(void);
+/* tuning hook used by tools/conv_bench.py: force (bm, bn, split-K) for every convolution launch; (0,0,-1) restores */
+void udet_debug_force_conv(int bm, int bn, int ks);
+
 /* Measurement aid (bench.py): between begin/end every convolution / warp / cost-volume launch group is
  * bracketed by HIP events on the launch stream.  out[cat*4 + {0,1,2,3}] = {groups, total ms, algorithmic
  * FLOPs, algorithmic bytes} for cat 0 conv fwd, 1 conv dgrad, 2 conv wgrad, 3 warp, 4 cost volume. */

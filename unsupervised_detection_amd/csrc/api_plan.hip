@@ -2,6 +2,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "conv_host.h"
+#include "elementwise.h"
 #include "plan.h"
 
 using namespace udet;
@@ -100,6 +102,32 @@ int udet_train_step(udet_plan* h, int which, const float* img1, const float* img
   if (which & 2) UDET_TRY(udet_apply(h, NET_REC, w_rec, g_rec, m_rec, v_rec, ws, stream));
   return UDET_OK;
 }
+
+/* autotuner: one untimed forward + both backward passes over random data during which every distinct convolution
+ * problem of the plan times its candidate kernel configurations (tile, split-K, wave specialisation, wgrad split)
+ * and caches the fastest; the activation / gradient regions of the workspace are re-zeroed afterwards. */
+int udet_autotune(udet_plan* h, const float* w_gen, const float* w_rec, float* g_gen, float* g_rec, void* ws_, void* stream) {
+  Plan* P = h->p;
+  float* ws = (float*)ws_;
+  hipStream_t s = (hipStream_t)stream;
+  if (!P->pwc_packed) { set_error("autotune: pack the PWC-Net and trainable weights first"); return UDET_ERR_ARG; }
+  const size_t lo = P->packed_floats, hi = P->small_off;
+  UDET_TRY(launch_fill_uniform(ws + lo, (long)(hi - lo), 0x5eedull, -0.5f, 0.5f, s));
+  const size_t img_floats = (size_t)P->cfg.batch * P->cfg.in_h * P->cfg.in_w * 3;
+  if (P->wgrad_floats < 2 * img_floats) { set_error("autotune: workspace too small for the probe images"); return UDET_ERR_ARG; }
+  const float* img1 = ws + P->wgrad_off;
+  const float* img2 = img1 + img_floats;
+  conv_set_tuning(1);
+  wgrad_set_tuning(1);
+  int rc = udet_forward(h, img1, img2, 3, ws_, stream);
+  if (rc == UDET_OK) rc = udet_backward(h, 3, w_gen, w_rec, g_gen, g_rec, ws_, stream);
+  conv_set_tuning(0);
+  wgrad_set_tuning(0);
+  UDET_HIP(hipMemsetAsync(ws + lo, 0, (hi - lo) * sizeof(float), s));
+  UDET_HIP(hipStreamSynchronize(s));
+  return rc;
+}
+int udet_tuned_shapes(void) { return conv_tuned_shapes() + wgrad_tuned_shapes(); }
 
 /* profiling: per-category HIP-event timing of the conv / warp / cost-volume launches */
 int udet_profile_begin(udet_plan* h) {

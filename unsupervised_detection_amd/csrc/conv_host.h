@@ -4,7 +4,12 @@ namespace udet {
 void same_pad(int in, int k, int s, int d, int* before, int* out);
 void conv_setup_fwd(ConvParams& p, int N, int H, int W, int kh, int kw, int s, int d);
 int conv_dgrad_classes(int s, int H, int W);
-void conv_force_config(int bm, int bn, int ks);  // debugging / tuning hook: bm == 0 and ks < 0 restore the heuristics
+void conv_force_config(int bm, int bn, int ks);
+void conv_set_tuning(int on);   // autotuner: while on, unseen problem shapes are timed and the best configuration cached
+int conv_tuned_shapes();
+void conv_clear_tuning();
+void wgrad_set_tuning(int on);
+int wgrad_tuned_shapes();  // debugging / tuning hook: bm == 0 and ks < 0 restore the heuristics
 bool conv_setup_dgrad(ConvParams& p, int cls, int N, int H, int W, int kh, int kw, int s, int d);
 int launch_pack_weights(const float* src, float* dst, int T, int R, int C, int Kc, int ldw, int k_split, int k_gap,
                         int mode, const float* scale, hipStream_t stream);

@@ -18,6 +18,10 @@
 // (models/utils/convolution_utils.py:46,81; models/PWCNet/model_pwcnet.py:161-165,286,484-504,562-574).
 #include <stdlib.h>
 
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
 #include "common.h"
 
 namespace udet {
@@ -336,17 +340,17 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const ConvPar
   }
 }
 
-static int g_force_bm = 0, g_force_bn = 0, g_force_ks = -1, g_ws = 1;
+static int g_force_bm = 0, g_force_bn = 0, g_force_ks = -1, g_force_ws = -1;
 void conv_force_config(int bm, int bn, int ks) {
   g_force_bm = bm & 0xffff; g_force_bn = bn; g_force_ks = ks;
-  g_ws = (bm >> 16) & 1 ? 0 : 1;  // bit 16 of bm: use the 256-thread non-specialised kernel
+  g_force_ws = (bm >> 16) & 1 ? 0 : -1;  // bit 16 of bm: use the 256-thread non-specialised kernel
 }
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
-static int launch_cfg(const ConvParams& p, hipStream_t stream) {
+static int launch_cfg(const ConvParams& p, int ws, hipStream_t stream) {
   const int Mtot = p.N * p.OHq * p.OWq;
   dim3 grid(p.ncls * ((Mtot + BM - 1) / BM), (p.Cout + BN - 1) / BN, p.ksplit > 1 ? p.ksplit : 1);
-  if (g_ws) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, true>), grid, dim3(512), 0, stream, p);
+  if (ws) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, true>), grid, dim3(512), 0, stream, p);
   else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, false>), grid, dim3(256), 0, stream, p);
   UDET_HIP(hipGetLastError());
   if (p.ksplit > 1) {
@@ -364,7 +368,7 @@ static int launch_cfg(const ConvParams& p, hipStream_t stream) {
 }
 
 // ---- tile / split-K selection ---------------------------------------------------------------
-struct TileCfg { int bm, bn; };
+struct ConvCfg { int bm, bn, ks, ws; };
 static long cfg_tiles(const ConvParams& p, int bm, int bn) {
   const int Mtot = p.N * p.OHq * p.OWq;
   return (long)p.ncls * ((Mtot + bm - 1) / bm) * ((p.Cout + bn - 1) / bn);
@@ -374,16 +378,107 @@ static int max_class_taps(const ConvParams& p) {
   for (int c = 0; c < p.ncls; ++c) mx = p.cls_tap[c + 1] - p.cls_tap[c] > mx ? p.cls_tap[c + 1] - p.cls_tap[c] : mx;
   return mx;
 }
-static int pick_ksplit(const ConvParams& p, long tiles, int bk) {
-  if (tiles >= 256 || !p.partial) return 1;
-  const int nchunks = (max_class_taps(p) * p.Kc + bk - 1) / bk;
-  int ks = (int)((512 + tiles - 1) / tiles);
-  const int maxks = nchunks / 4 > 0 ? nchunks / 4 : 1;  // keep >= 4 stages per split
-  if (ks > maxks) ks = maxks;
-  if (ks > 64) ks = 64;
+static int max_ksplit(const ConvParams& p) {  // capacity / minimum-work bound on the split count
+  if (!p.partial) return 1;
+  const int nchunks = (max_class_taps(p) * p.Kc + 31) / 32;
+  int ks = nchunks / 2 > 64 ? 64 : nchunks / 2;
   const size_t per_split = (size_t)p.ncls * p.N * p.OHq * p.OWq * ((p.Cout + 3) & ~3);
   while (ks > 1 && per_split * ks > p.partial_cap) --ks;
-  return ks < 2 ? 1 : ks;
+  return ks < 1 ? 1 : ks;
+}
+static ConvCfg heuristic_cfg(const ConvParams& p) {
+  // N tile from the channel count; M tile shrunk while the launch would leave CUs without a workgroup
+  ConvCfg c;
+  c.ws = 1;
+  if (p.Cout <= 32) { c.bn = 32; c.bm = 256; if (cfg_tiles(p, 256, 32) < 384) c.bm = 128; }
+  else if (p.Cout <= 64) { c.bn = 64; c.bm = 128; if (cfg_tiles(p, 128, 64) < 384) c.bm = 64; }
+  else if (p.Cout <= 96) { c.bn = 96; c.bm = 128; }
+  else { c.bn = 128; c.bm = 128; if (cfg_tiles(p, 128, 128) < 320) { c.bn = 64; if (cfg_tiles(p, 128, 64) < 384) c.bm = 64; } }
+  const long tiles = cfg_tiles(p, c.bm, c.bn);
+  c.ks = 1;
+  if (tiles < 256) {
+    int ks = (int)((512 + tiles - 1) / tiles);
+    const int cap = max_ksplit(p), half = cap / 2 > 0 ? cap / 2 : 1;  // keep >= 4 stages per split
+    c.ks = ks > half ? half : ks;
+  }
+  return c;
+}
+static int run_cfg(ConvParams& p, const ConvCfg& c, hipStream_t stream) {
+  p.ksplit = c.ks > 1 ? c.ks : 1;
+  if (p.ksplit > 1) p.ldp = (p.Cout + 3) & ~3;
+  if (c.bm == 256 && c.bn == 32) return launch_cfg<256, 32, 32, 4, 1>(p, c.ws, stream);
+  if (c.bm == 128 && c.bn == 32) return launch_cfg<128, 32, 32, 4, 1>(p, c.ws, stream);
+  if (c.bm == 128 && c.bn == 64) return launch_cfg<128, 64, 32, 2, 2>(p, c.ws, stream);
+  if (c.bm == 64 && c.bn == 64) return launch_cfg<64, 64, 32, 2, 2>(p, c.ws, stream);
+  if (c.bm == 128 && c.bn == 96) return launch_cfg<128, 96, 32, 4, 1>(p, c.ws, stream);
+  if (c.bm == 128 && c.bn == 128) return launch_cfg<128, 128, 32, 2, 2>(p, c.ws, stream);
+  set_error("conv: no kernel for tile %dx%d", c.bm, c.bn);
+  return UDET_ERR_UNSUPPORTED;
+}
+
+// ---- autotuner: while tuning is on, the first launch of every distinct problem shape times its candidate
+// (tile, split-K, wave-specialisation) configurations on the caller's stream and caches the fastest -------------
+static std::unordered_map<uint64_t, ConvCfg> g_cache;
+static std::mutex g_cache_mu;
+static int g_tuning = 0;
+void conv_set_tuning(int on) { g_tuning = on; }
+int conv_tuned_shapes() { std::lock_guard<std::mutex> l(g_cache_mu); return (int)g_cache.size(); }
+void conv_clear_tuning() { std::lock_guard<std::mutex> l(g_cache_mu); g_cache.clear(); }
+
+static uint64_t conv_key(const ConvParams& p) {
+  const int f[] = {p.N, p.H, p.W, p.up_shift, p.Kc, p.Cout, p.ntaps, p.ncls, p.OHq, p.OWq, p.isy, p.osy, p.xa ? 1 : 0,
+                   p.ldx, p.ldy, p.accumulate, p.res ? 1 : 0, p.y2 ? 1 : 0, p.partial ? 1 : 0, p.cls_tap[1]};
+  uint64_t h = 1469598103934665603ull;
+  for (int v : f) { h ^= (uint64_t)(uint32_t)v; h *= 1099511628211ull; }
+  return h;
+}
+static float time_cfg(ConvParams& p, const ConvCfg& c, int reps, hipStream_t stream) {
+  static hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (!e0) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); }
+  if (run_cfg(p, c, stream) != UDET_OK) return 1e30f;  // warm-up
+  (void)hipEventRecord(e0, stream);
+  for (int r = 0; r < reps; ++r) run_cfg(p, c, stream);
+  (void)hipEventRecord(e1, stream);
+  if (hipEventSynchronize(e1) != hipSuccess) return 1e30f;
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  return ms / reps;
+}
+static ConvCfg tune_cfg(ConvParams& p, hipStream_t stream) {
+  const ConvCfg h = heuristic_cfg(p);
+  std::vector<ConvCfg> cand;
+  static const int TILES[6][2] = {{256, 32}, {128, 32}, {128, 64}, {64, 64}, {128, 96}, {128, 128}};
+  const int kcap = max_ksplit(p);
+  for (auto& t : TILES) {
+    const int bm = t[0], bn = t[1];
+    // N tiles wider than needed waste MFMA columns; much narrower ones re-read the A operand
+    if (p.Cout <= 32 && bn != 32) continue;
+    if (p.Cout > 32 && p.Cout <= 64 && bn > 64) continue;
+    if (p.Cout > 64 && p.Cout <= 96 && bn != 96 && bn != 32) continue;
+    if (p.Cout > 96 && bn < 64) continue;
+    if (p.Cout > 96 && bn == 96 && p.Cout % 96 != 0 && p.Cout <= 128) continue;
+    const long tiles = cfg_tiles(p, bm, bn);
+    for (int ks = 1; ks <= kcap; ks *= 2) {
+      if (ks > 1 && (tiles >= 512 || tiles * ks > 4096)) break;
+      if (tiles * ks < 96 && ks * 2 <= kcap) continue;  // hopelessly under-filled
+      cand.push_back({bm, bn, ks, 1});
+    }
+  }
+  cand.push_back(h);
+  ConvCfg best = h;
+  float best_ms = 1e30f;
+  for (auto& c : cand) {
+    const float ms = time_cfg(p, c, 3, stream);
+    if (ms < best_ms) { best_ms = ms; best = c; }
+  }
+  ConvCfg alt = best;
+  alt.ws = 0;
+  const float a = time_cfg(p, best, 5, stream), b = time_cfg(p, alt, 5, stream);
+  if (b < a * 0.97f) best = alt;
+  if (getenv("UDET_TUNE_LOG"))
+    fprintf(stderr, "[udet tune] N=%d %dx%d Kc=%d taps=%d cls=%d Cout=%d -> %dx%d ks=%d ws=%d  %.1f us (heuristic %dx%d ks=%d)\n", p.N,
+            p.OHq, p.OWq, p.Kc, p.ntaps, p.ncls, p.Cout, best.bm, best.bn, best.ks, best.ws, (a < b ? a : b) * 1e3f, h.bm, h.bn, h.ks);
+  return best;
 }
 
 int launch_conv(ConvParams& p, hipStream_t stream) {
@@ -410,24 +505,27 @@ int launch_conv(ConvParams& p, hipStream_t stream) {
     static const int dbg = getenv("UDET_DBG") ? atoi(getenv("UDET_DBG")) : 0;
     p.dbg = dbg;
   }
-  // N tile from the channel count; M tile shrunk while the launch would leave CUs without a workgroup
-  int bm, bn;
-  if (p.Cout <= 32) { bn = 32; bm = 256; if (cfg_tiles(p, 256, 32) < 384) bm = 128; }
-  else if (p.Cout <= 64) { bn = 64; bm = 128; if (cfg_tiles(p, 128, 64) < 384) bm = 64; }
-  else if (p.Cout <= 96) { bn = 96; bm = 128; }
-  else { bn = 128; bm = 128; if (cfg_tiles(p, 128, 128) < 320) { bn = 64; if (cfg_tiles(p, 128, 64) < 384) bm = 64; } }
-  if (g_force_bm) { bm = g_force_bm; bn = g_force_bn; }
-  p.ksplit = pick_ksplit(p, cfg_tiles(p, bm, bn), 32);
-  if (g_force_ks >= 0) p.ksplit = g_force_ks > 1 ? g_force_ks : 1;
-  if (p.ksplit > 1) p.ldp = (p.Cout + 3) & ~3;
-  if (bm == 256 && bn == 32) return launch_cfg<256, 32, 32, 4, 1>(p, stream);
-  if (bm == 128 && bn == 32) return launch_cfg<128, 32, 32, 4, 1>(p, stream);
-  if (bm == 128 && bn == 64) return launch_cfg<128, 64, 32, 2, 2>(p, stream);
-  if (bm == 64 && bn == 64) return launch_cfg<64, 64, 32, 2, 2>(p, stream);
-  if (bm == 128 && bn == 96) return launch_cfg<128, 96, 32, 4, 1>(p, stream);
-  if (bm == 128 && bn == 128) return launch_cfg<128, 128, 32, 2, 2>(p, stream);
-  set_error("conv: no kernel for tile %dx%d", bm, bn);
-  return UDET_ERR_UNSUPPORTED;
+  ConvCfg c;
+  bool have = false;
+  const uint64_t key = conv_key(p);
+  {
+    std::lock_guard<std::mutex> l(g_cache_mu);
+    auto it = g_cache.find(key);
+    if (it != g_cache.end()) { c = it->second; have = true; }
+  }
+  if (!have) {
+    if (g_tuning) {
+      c = tune_cfg(p, stream);
+      std::lock_guard<std::mutex> l(g_cache_mu);
+      g_cache[key] = c;
+    } else {
+      c = heuristic_cfg(p);
+    }
+  }
+  if (g_force_bm) { c.bm = g_force_bm; c.bn = g_force_bn; }
+  if (g_force_ks >= 0) c.ks = g_force_ks > max_ksplit(p) ? max_ksplit(p) : g_force_ks;
+  if (g_force_ws >= 0) c.ws = g_force_ws;
+  return run_cfg(p, c, stream);
 }
 
 }  // namespace udet

@@ -3,6 +3,11 @@
 //     dW[t][ci][co] = sum_q X(q@t)[ci] * dU[q][co],   dU = dY * act'(saved output),   db[co] = sum_q dU[q][co]
 // Replaces TF-1.13 Conv2DBackpropFilter / BiasAddGrad / FusedBatchNormGrad(inference) reached
 // through optimizer.compute_gradients (models/utils/loss_utils.py:18).
+#include <stdlib.h>
+
+#include <mutex>
+#include <unordered_map>
+
 #include "common.h"
 #include "conv_host.h"
 
@@ -231,6 +236,12 @@ size_t wgrad_partial_floats_needed(int T, int Cin, int Cout) {
   return (size_t)BND_SPLIT * Cout + ldn + mpad * ldn + 64;
 }
 
+static std::unordered_map<uint64_t, int> g_wcache;
+static std::mutex g_wcache_mu;
+static int g_wtuning = 0;
+void wgrad_set_tuning(int on) { g_wtuning = on; }
+int wgrad_tuned_shapes() { std::lock_guard<std::mutex> l(g_wcache_mu); return (int)g_wcache.size(); }
+
 template <int BM, int BN, int WM_, int WN_>
 static void wgrad_launch(const WgradParams& p, int m_tiles, int co_tiles, int nsplit, hipStream_t stream) {
   dim3 grid(m_tiles * co_tiles, nsplit);
@@ -264,27 +275,66 @@ int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream) {
     return UDET_ERR_ARG;
   }
   const long tiles = (long)m_tiles * co_tiles;
-  int nsplit = (int)((768 + tiles - 1) / tiles);
-  if (nsplit > nchunks / 2) nsplit = nchunks / 2;
   const size_t maxs = (p.partial_floats - fixed) / per_split;
-  if ((size_t)nsplit > maxs) nsplit = (int)maxs;
+  int cap = nchunks / 2 > 0 ? nchunks / 2 : 1;
+  if ((size_t)cap > maxs) cap = (int)maxs;
+  int nsplit = (int)((768 + tiles - 1) / tiles);
+  if (nsplit > cap) nsplit = cap;
   if (nsplit < 1) nsplit = 1;
   const size_t wsz = (size_t)T * p.Cin * p.Cout;
   if (p.ntaps < T) UDET_HIP(hipMemsetAsync(p.dw, 0, wsz * sizeof(float), stream));  // culled taps have zero gradient
-  WgradParams q = p;
-  q.pbias = base;                                  // [nsplit][ldn]
-  q.partial = base + (size_t)nsplit * ldn;        // [nsplit][Mpad][ldn]
-  if (bn == 128) wgrad_launch<128, 128, 2, 2>(q, m_tiles, co_tiles, nsplit, stream);
-  else if (bn == 64) wgrad_launch<128, 64, 2, 2>(q, m_tiles, co_tiles, nsplit, stream);
-  else wgrad_launch<128, 32, 4, 1>(q, m_tiles, co_tiles, nsplit, stream);
-  UDET_HIP(hipGetLastError());
   const long total = (long)(Mreal + 1) * p.Cout;
-  const int sl = (nsplit >= 64 && total * 64 <= 262144) ? 64 : ((nsplit >= 8 && total * 8 <= 262144) ? 8 : 1);
-  const long nbl = (total * sl + 255) / 256;
-  const int nb = (int)(nbl > 4096 ? 4096 : nbl);
-  if (sl == 64) hipLaunchKernelGGL(wgrad_reduce_kernel<64>, dim3(nb), dim3(256), 0, stream, q, ldn, nsplit);
-  else if (sl == 8) hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3(nb), dim3(256), 0, stream, q, ldn, nsplit);
-  else hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(nb), dim3(256), 0, stream, q, ldn, nsplit);
+  auto run = [&](int ns) {
+    WgradParams q = p;
+    q.pbias = base;                              // [ns][ldn]
+    q.partial = base + (size_t)ns * ldn;        // [ns][Mpad][ldn]
+    if (bn == 128) wgrad_launch<128, 128, 2, 2>(q, m_tiles, co_tiles, ns, stream);
+    else if (bn == 64) wgrad_launch<128, 64, 2, 2>(q, m_tiles, co_tiles, ns, stream);
+    else wgrad_launch<128, 32, 4, 1>(q, m_tiles, co_tiles, ns, stream);
+    const int sl = (ns >= 64 && total * 64 <= 262144) ? 64 : ((ns >= 8 && total * 8 <= 262144) ? 8 : 1);
+    const long nbl = (total * sl + 255) / 256;
+    const int nb = (int)(nbl > 4096 ? 4096 : nbl);
+    if (sl == 64) hipLaunchKernelGGL(wgrad_reduce_kernel<64>, dim3(nb), dim3(256), 0, stream, q, ldn, ns);
+    else if (sl == 8) hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3(nb), dim3(256), 0, stream, q, ldn, ns);
+    else hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(nb), dim3(256), 0, stream, q, ldn, ns);
+  };
+  // autotuned split count (see conv_igemm.hip): kernel + reduction timed together
+  {
+    const int f[] = {p.N, p.H, p.W, p.up_shift, p.Cin, p.Cout, p.ntaps, p.OH, p.OW, p.isy, p.ya ? 1 : 0, p.ldx, p.ldy, cap};
+    uint64_t key = 1469598103934665603ull;
+    for (int v : f) { key ^= (uint64_t)(uint32_t)v; key *= 1099511628211ull; }
+    bool have = false;
+    {
+      std::lock_guard<std::mutex> l(g_wcache_mu);
+      auto it = g_wcache.find(key);
+      if (it != g_wcache.end()) { nsplit = it->second; have = true; }
+    }
+    if (!have && g_wtuning) {
+      static hipEvent_t e0 = nullptr, e1 = nullptr;
+      if (!e0) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); }
+      const int h = nsplit;
+      float best_ms = 1e30f;
+      int best = h;
+      for (int ns : {h / 8, h / 4, h / 2, h, h * 2, h * 4}) {
+        if (ns < 1 || ns > cap) continue;
+        run(ns);
+        (void)hipEventRecord(e0, stream);
+        for (int r = 0; r < 3; ++r) run(ns);
+        (void)hipEventRecord(e1, stream);
+        if (hipEventSynchronize(e1) != hipSuccess) continue;
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best_ms) { best_ms = ms; best = ns; }
+      }
+      nsplit = best;
+      if (getenv("UDET_TUNE_LOG"))
+        fprintf(stderr, "[udet tune] wgrad N=%d %dx%d Cin=%d Cout=%d taps=%d -> nsplit=%d (heuristic %d) %.1f us\n", p.N, p.OH, p.OW,
+                p.Cin, p.Cout, p.ntaps, nsplit, h, best_ms / 3 * 1e3f);
+      std::lock_guard<std::mutex> l(g_wcache_mu);
+      g_wcache[key] = nsplit;
+    }
+  }
+  run(nsplit);
   UDET_HIP(hipGetLastError());
   int nbw = (int)((wsz + 255) / 256);
   if (nbw > 2048) nbw = 2048;

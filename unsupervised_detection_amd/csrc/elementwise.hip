@@ -492,6 +492,15 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, float*
     w[i] = w[i] - lr_t * mi / (sqrtf(vi) + eps);
   }
 }
+__global__ __launch_bounds__(256) void fill_uniform_kernel(float* __restrict__ x, long n, uint64_t seed, float lo, float hi) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+    x[i] = lo + (hi - lo) * udet_uniform01(seed, 0, (uint64_t)i);
+}
+int launch_fill_uniform(float* x, long n, uint64_t seed, float lo, float hi, hipStream_t s) {
+  hipLaunchKernelGGL(fill_uniform_kernel, dim3(grid_for(n, 8192)), dim3(256), 0, s, x, n, seed, lo, hi);
+  UDET_HIP(hipGetLastError());
+  return UDET_OK;
+}
 int launch_adam(float* w, float* g, float* m, float* v, long n, float lr_t, float b1, float b2, float eps, float clip,
                 const float* flag, uint64_t seed, uint64_t step, hipStream_t s) {
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, s, w, g, m, v, n, lr_t, b1, b2, eps, clip, flag, seed,

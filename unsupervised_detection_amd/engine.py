@@ -43,6 +43,10 @@ for _n, _a in (("udet_pack_pwc", [c_p, c_p, c_p, c_p]), ("udet_pack_trainable", 
     getattr(lib, _n).restype = c_i
     getattr(lib, _n).argtypes = _a
 
+lib.udet_autotune.restype = c_i
+lib.udet_autotune.argtypes = [c_p] * 7
+lib.udet_tuned_shapes.restype = c_i
+lib.udet_tuned_shapes.argtypes = []
 lib.udet_profile_begin.restype = c_i
 lib.udet_profile_begin.argtypes = [c_p]
 lib.udet_profile_end.restype = c_i
@@ -156,6 +160,12 @@ class Engine:
     def train_step(self, which, img1, img2, w_gen, w_rec, g_gen, g_rec, m_gen, v_gen, m_rec, v_rec):
         check(lib.udet_train_step(self._h, which, _ptr(img1), _ptr(img2), _ptr(w_gen), _ptr(w_rec), _ptr(g_gen), _ptr(g_rec),
                                   _ptr(m_gen), _ptr(v_gen), _ptr(m_rec), _ptr(v_rec), self.ws.data_ptr(), self._stream()))
+
+    def autotune(self, w_gen, w_rec, g_gen, g_rec):
+        """Time the candidate kernel configurations of every convolution of the plan once (process-wide cache).
+        Weights must be packed; g_gen / g_rec are scratch; activation buffers are re-zeroed."""
+        check(lib.udet_autotune(self._h, _ptr(w_gen), _ptr(w_rec), _ptr(g_gen), _ptr(g_rec), self.ws.data_ptr(), self._stream()))
+        return int(lib.udet_tuned_shapes())
 
     def profile(self, fn):
         """Run fn() with per-category HIP-event timing (udet_profile_begin/end). Returns {category: {...}}."""

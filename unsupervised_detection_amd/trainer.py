@@ -16,7 +16,7 @@ from .engine import BOTH, GEN, REC, Engine, EngineConfig
 class TrainState:
     """Flat fp32 parameter / gradient / Adam-slot buffers of the two trainable networks + frozen PWC-Net."""
 
-    def __init__(self, engine: Engine, seed: int = 8964, w_pwc=None, w_gen=None, w_rec=None):
+    def __init__(self, engine: Engine, seed: int = 8964, w_pwc=None, w_gen=None, w_rec=None, autotune: bool = False):
         dev = engine.device
         self.engine = engine
         self.w_pwc = (w_pwc if w_pwc is not None else W.init_flat(W.NET_PWC, seed)).to(dev)
@@ -27,6 +27,8 @@ class TrainState:
         self.m_rec, self.v_rec = torch.zeros_like(self.w_rec), torch.zeros_like(self.w_rec)
         engine.pack_pwc(self.w_pwc)
         engine.pack_trainable(self.w_gen, self.w_rec)
+        if autotune:
+            self.tuned_shapes = engine.autotune(self.w_gen, self.w_rec, self.g_gen, self.g_rec)
 
 
 def allreduce_mean_(t: torch.Tensor, group=None, async_op=False):
