@@ -61,14 +61,9 @@ int udet_pack_trainable(udet_plan* h, const float* w_gen, const float* w_rec, vo
 int udet_pwc_forward(udet_plan* h, const float* img1, const float* img2, void* ws, void* stream) {
   return plan_pwc_forward(h->p, img1, img2, (float*)ws, (hipStream_t)stream);
 }
-int udet_forward_from_flow(udet_plan* h, int ncalls, void* ws_, void* stream) {
-  float* ws = (float*)ws_;
-  hipStream_t s = (hipStream_t)stream;
+int udet_forward_from_flow(udet_plan* h, int ncalls, void* ws, void* stream) {
   if (ncalls < 0 || ncalls > 3) { set_error("forward: ncalls must be 0..3"); return UDET_ERR_ARG; }
-  UDET_TRY(plan_generator_forward(h->p, ws, s));
-  UDET_TRY(plan_recover_forward(h->p, ncalls, ws, s));
-  if (ncalls == 3) UDET_TRY(plan_losses(h->p, ws, s));
-  return UDET_OK;
+  return plan_forward(h->p, nullptr, nullptr, ncalls, (float*)ws, (hipStream_t)stream);
 }
 int udet_generator_forward(udet_plan* h, void* ws, void* stream) {
   UDET_TRY(plan_generator_forward(h->p, (float*)ws, (hipStream_t)stream));
@@ -79,16 +74,14 @@ int udet_recover_forward(udet_plan* h, int n, void* ws, void* stream) {
   return plan_recover_forward(h->p, n, (float*)ws, (hipStream_t)stream, true);
 }
 int udet_forward(udet_plan* h, const float* img1, const float* img2, int ncalls, void* ws, void* stream) {
-  UDET_TRY(plan_pwc_forward(h->p, img1, img2, (float*)ws, (hipStream_t)stream));
-  UDET_TRY(plan_prepare(h->p, img1, (float*)ws, (hipStream_t)stream));
-  return udet_forward_from_flow(h, ncalls, ws, stream);
+  if (ncalls < 0 || ncalls > 3) { set_error("forward: ncalls must be 0..3"); return UDET_ERR_ARG; }
+  if (!img1 || !img2) { set_error("forward: null image pointer"); return UDET_ERR_ARG; }
+  return plan_forward(h->p, img1, img2, ncalls, (float*)ws, (hipStream_t)stream);
 }
 int udet_backward(udet_plan* h, int which, const float* w_gen, const float* w_rec, float* g_gen, float* g_rec, void* ws,
                   void* stream) {
   if (which < 1 || which > 3) { set_error("backward: which must be 1 (generator), 2 (recover) or 3 (both)"); return UDET_ERR_ARG; }
-  if (which & 2) UDET_TRY(plan_backward_recover(h->p, w_rec, g_rec, (float*)ws, (hipStream_t)stream));
-  if (which & 1) UDET_TRY(plan_backward_generator(h->p, w_gen, g_gen, (float*)ws, (hipStream_t)stream));
-  return UDET_OK;
+  return plan_backward(h->p, which, w_gen, w_rec, g_gen, g_rec, (float*)ws, (hipStream_t)stream);
 }
 int udet_apply(udet_plan* h, int net, float* w, float* g, float* m, float* v, void* ws, void* stream) {
   return plan_apply(h->p, net, w, g, m, v, (float*)ws, (hipStream_t)stream);
@@ -115,14 +108,17 @@ int udet_autotune(udet_plan* h, const float* w_gen, const float* w_rec, float* g
   UDET_TRY(launch_fill_uniform(ws + lo, (long)(hi - lo), 0x5eedull, -0.5f, 0.5f, s));
   const size_t img_floats = (size_t)P->cfg.batch * P->cfg.in_h * P->cfg.in_w * 3;
   if (P->wgrad_floats < 2 * img_floats) { set_error("autotune: workspace too small for the probe images"); return UDET_ERR_ARG; }
-  const float* img1 = ws + P->wgrad_off;
+  const float* img1 = ws + P->wgrad_off[0];
   const float* img2 = img1 + img_floats;
+  const bool was_concurrent = P->concurrent;
+  P->concurrent = false;  // candidates are timed on the caller's stream with nothing else in flight
   conv_set_tuning(1);
   wgrad_set_tuning(1);
   int rc = udet_forward(h, img1, img2, 3, ws_, stream);
   if (rc == UDET_OK) rc = udet_backward(h, 3, w_gen, w_rec, g_gen, g_rec, ws_, stream);
   conv_set_tuning(0);
   wgrad_set_tuning(0);
+  P->concurrent = was_concurrent;
   UDET_HIP(hipMemsetAsync(ws + lo, 0, (hi - lo) * sizeof(float), s));
   UDET_HIP(hipStreamSynchronize(s));
   return rc;

@@ -9,8 +9,8 @@ int launch_pool2x2_sum(const float* du, float* dx, int N, int H, int W, int C, h
 int launch_pack_pwc_input(const float* i1, const float* i2, float* x8, long P, hipStream_t s);
 int launch_gen_input(const float* img, const float* f, double* part, float* gin, int B, long HW, hipStream_t s);
 size_t flow_stats_doubles(int B);
-int launch_mask_rec_inputs(const float* logits, const float* img, const float* f, float* mask, float* fin, float* imgin,
-                           long P, int ncalls, hipStream_t s);
+int launch_mask_rec_inputs(const float* logits, const float* f, float* mask, float* fin, long P, int ncalls, hipStream_t s);
+int launch_pack_imgin(const float* img, float* imgin, long P, int ncalls, hipStream_t s);
 int launch_losses(const float* f, const float* mask, const float* pred, long HW, int B, float cbn, float eps,
                   float num_pixels, float* part, float* losses, float* coef, float* sums, hipStream_t s);
 size_t loss_part_floats(int B);

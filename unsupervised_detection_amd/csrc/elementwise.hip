@@ -228,9 +228,8 @@ size_t flow_stats_doubles(int B) { return (size_t)B * FS_BLOCKS * 4; }
 //   imgin = image replicated for the 3 calls (8-channel padded)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mask_rec_inputs_kernel(const float* __restrict__ logits /*ld 8*/,
-                                                              const float* __restrict__ img, const float* __restrict__ f,
-                                                              float* __restrict__ mask, float* __restrict__ fin,
-                                                              float* __restrict__ imgin, long P, int ncalls) {
+                                                              const float* __restrict__ f, float* __restrict__ mask,
+                                                              float* __restrict__ fin, long P, int ncalls) {
   for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < P; q += (long)gridDim.x * 256) {
     const float l0 = logits[q * 8] / 10.f, l1 = logits[q * 8 + 1] / 10.f;
     const float mx = fmaxf(l0, l1);
@@ -240,29 +239,40 @@ __global__ __launch_bounds__(256) void mask_rec_inputs_kernel(const float* __res
     const float cm = 1.f - m;
     const float2 v = *reinterpret_cast<const float2*>(f + q * 2);
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 im = make_float4(img[q * 3], img[q * 3 + 1], img[q * 3 + 2], 0.f);
     const float a0 = 1.f - m, a1 = 1.f - cm;
-    *reinterpret_cast<float4*>(fin + q * 8) = make_float4(v.x * a0, v.y * a0, 1.f, a0);
-    *reinterpret_cast<float4*>(fin + q * 8 + 4) = z;
-    *reinterpret_cast<float4*>(imgin + q * 8) = im;
-    *reinterpret_cast<float4*>(imgin + q * 8 + 4) = z;
+    if (ncalls > 0) {
+      *reinterpret_cast<float4*>(fin + q * 8) = make_float4(v.x * a0, v.y * a0, 1.f, a0);
+      *reinterpret_cast<float4*>(fin + q * 8 + 4) = z;
+    }
     if (ncalls > 1) {
       *reinterpret_cast<float4*>(fin + (P + q) * 8) = make_float4(v.x * a1, v.y * a1, 1.f, a1);
       *reinterpret_cast<float4*>(fin + (P + q) * 8 + 4) = z;
-      *reinterpret_cast<float4*>(imgin + (P + q) * 8) = im;
-      *reinterpret_cast<float4*>(imgin + (P + q) * 8 + 4) = z;
     }
     if (ncalls > 2) {
       *reinterpret_cast<float4*>(fin + (2 * P + q) * 8) = make_float4(0.f, 0.f, 1.f, 0.f);
       *reinterpret_cast<float4*>(fin + (2 * P + q) * 8 + 4) = z;
-      *reinterpret_cast<float4*>(imgin + (2 * P + q) * 8) = im;
-      *reinterpret_cast<float4*>(imgin + (2 * P + q) * 8 + 4) = z;
     }
   }
 }
-int launch_mask_rec_inputs(const float* logits, const float* img, const float* f, float* mask, float* fin, float* imgin,
-                           long P, int ncalls, hipStream_t s) {
-  hipLaunchKernelGGL(mask_rec_inputs_kernel, dim3(grid_for(P)), dim3(256), 0, s, logits, img, f, mask, fin, imgin, P, ncalls);
+int launch_mask_rec_inputs(const float* logits, const float* f, float* mask, float* fin, long P, int ncalls, hipStream_t s) {
+  hipLaunchKernelGGL(mask_rec_inputs_kernel, dim3(grid_for(P)), dim3(256), 0, s, logits, f, mask, fin, P, ncalls);
+  UDET_HIP(hipGetLastError());
+  return UDET_OK;
+}
+// imgin[call][q] = [image(3) | 0 x5] for the `ncalls` recover invocations (nets.py:57: the image encoder's input)
+__global__ __launch_bounds__(256) void pack_imgin_kernel(const float* __restrict__ img, float* __restrict__ imgin, long P,
+                                                         int ncalls) {
+  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < P; q += (long)gridDim.x * 256) {
+    const float4 im = make_float4(img[q * 3], img[q * 3 + 1], img[q * 3 + 2], 0.f);
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < ncalls; ++k) {
+      *reinterpret_cast<float4*>(imgin + (k * P + q) * 8) = im;
+      *reinterpret_cast<float4*>(imgin + (k * P + q) * 8 + 4) = z;
+    }
+  }
+}
+int launch_pack_imgin(const float* img, float* imgin, long P, int ncalls, hipStream_t s) {
+  hipLaunchKernelGGL(pack_imgin_kernel, dim3(grid_for(P)), dim3(256), 0, s, img, imgin, P, ncalls);
   UDET_HIP(hipGetLastError());
   return UDET_OK;
 }

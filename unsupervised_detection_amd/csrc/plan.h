@@ -68,8 +68,16 @@ struct Plan {
   std::vector<Layer> pwc, gen, rec;
   size_t packed_floats = 0;      // packed-weight region (start of the workspace)
   size_t arena_floats = 0;       // everything
-  size_t scratch_off = 0, scratch_floats = 0;   // split-K slabs
-  size_t wgrad_off = 0, wgrad_floats = 0;       // wgrad partials
+  // Concurrency: independent chains of the step run on side streams forked from / joined to the caller's stream
+  // with events (lane 0 = the caller's stream).  Every lane owns its split-K and wgrad scratch.
+  enum { NLANE = 4 };
+  hipStream_t side[NLANE - 1] = {nullptr, nullptr, nullptr};
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_next = 0;
+  bool concurrent = true;
+  size_t scratch_off[NLANE] = {0, 0, 0, 0}, scratch_floats = 0;   // split-K slabs
+  size_t wgrad_off[NLANE] = {0, 0, 0, 0}, wgrad_floats = 0;       // wgrad partials
+  ~Plan();
   size_t small_off = 0;          // losses, coefficients, flags, reduction partials
   size_t seg_off[3] = {0, 0, 0}; // per-variable (offset,len) tables on device (as long)
   // optional per-category timing with HIP events on the launch stream (bench.py roofline)
@@ -90,12 +98,13 @@ int plan_init_workspace(Plan* P, float* ws, hipStream_t s);
 int plan_pack_pwc(Plan* P, const float* w_pwc, float* ws, hipStream_t s);
 int plan_pack_trainable(Plan* P, const float* w_gen, const float* w_rec, float* ws, hipStream_t s);
 int plan_pwc_forward(Plan* P, const float* img1, const float* img2, float* ws, hipStream_t s);
-int plan_prepare(Plan* P, const float* img1, float* ws, hipStream_t s);
+// img1 != null: PWC flow + resizes first; then generator, `ncalls` recover invocations, losses (ncalls == 3)
+int plan_forward(Plan* P, const float* img1, const float* img2, int ncalls, float* ws, hipStream_t s);
 int plan_generator_forward(Plan* P, float* ws, hipStream_t s);
-int plan_recover_forward(Plan* P, int ncalls, float* ws, hipStream_t s, bool inputs_prepacked = false);
+int plan_recover_forward(Plan* P, int ncalls, float* ws, hipStream_t s, bool inputs_prepacked = false, bool skip_enc_a = false);
 int plan_losses(Plan* P, float* ws, hipStream_t s);
-int plan_backward_recover(Plan* P, const float* w_rec, float* g_rec, float* ws, hipStream_t s);
-int plan_backward_generator(Plan* P, const float* w_gen, float* g_gen, float* ws, hipStream_t s);
+// which: 1 generator loss -> MaskNet, 2 recover loss -> FlownetS, 3 both (the two passes run concurrently)
+int plan_backward(Plan* P, int which, const float* w_gen, const float* w_rec, float* g_gen, float* g_rec, float* ws, hipStream_t s);
 int plan_apply(Plan* P, int net, float* w, float* g, float* m, float* v, float* ws, hipStream_t s);
 enum { PROF_CONV_FWD = 0, PROF_CONV_DGRAD = 1, PROF_CONV_WGRAD = 2, PROF_WARP = 3, PROF_CORR = 4, PROF_NCAT = 5 };
 void prof_begin(Plan* P, int cat, double flops, double bytes, hipStream_t s, const char* name = "");

@@ -4,6 +4,7 @@
 // Reference being restated structurally (no code shared): models/PWCNet/model_pwcnet.py:149-168,
 // 476-506,559-576,599-649 (PWC-Net lg-6-2), models/nets.py:4-42 (generator), :45-110 (recover).
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "conv_host.h"
@@ -166,6 +167,12 @@ static Layer mk_layer(int net, const std::string& name, const std::string& wname
 }
 
 static size_t align64(size_t v) { return (v + 63) & ~(size_t)63; }
+
+Plan::~Plan() {
+  for (auto& st : side)
+    if (st) (void)hipStreamDestroy(st);
+  for (auto& e : ev_pool) (void)hipEventDestroy(e);
+}
 
 Plan* plan_build(const Config& cfg) {
   if (cfg.batch > 16) {
@@ -406,6 +413,17 @@ Plan* plan_build(const Config& cfg) {
     (void)src_lvl;
   }
 
+  // The generator-loss backward pass runs concurrently with the recover-loss pass: it gets its own copy of the
+  // recover-side gradient buffers ("rec.e.*", "e.pred" mirror "rec.d.*", "d.pred").
+  {
+    const size_t nb = P->bufs.size();
+    for (size_t i = 0; i < nb; ++i) {
+      const Buf b = P->bufs[i];
+      if (b.name.rfind("rec.d.", 0) == 0) P->add_buf("rec.e." + b.name.substr(6), b.n, b.h, b.w, b.ld);
+      if (b.name == "d.pred") P->add_buf("e.pred", b.n, b.h, b.w, b.ld);
+    }
+  }
+
   // ======================= packed weights =======================
   size_t off = 0;
   auto place = [&](Layer& L, bool trainable) {
@@ -426,12 +444,14 @@ Plan* plan_build(const Config& cfg) {
 
   // ======================= arena =======================
   for (auto& b : P->bufs) { b.off = off; off = align64(off + b.floats()); }
-  P->scratch_off = off;
-  P->scratch_floats = (size_t)24 << 20;  // 96 MiB: split-K slabs
-  off = align64(off + P->scratch_floats);
-  P->wgrad_off = off;
-  P->wgrad_floats = (size_t)48 << 20;  // 192 MiB: wgrad split partials
-  off = align64(off + P->wgrad_floats);
+  P->scratch_floats = (size_t)24 << 20;  // 96 MiB per lane: split-K slabs
+  P->wgrad_floats = (size_t)48 << 20;    // 192 MiB per lane: wgrad split partials
+  for (int l = 0; l < Plan::NLANE; ++l) {
+    P->scratch_off[l] = off;
+    off = align64(off + P->scratch_floats);
+    P->wgrad_off[l] = off;
+    off = align64(off + P->wgrad_floats);
+  }
   P->small_off = off;
   off = align64(off + 65536);
   for (int net = 1; net <= 2; ++net) {
@@ -439,6 +459,9 @@ Plan* plan_build(const Config& cfg) {
     off = align64(off + 4 * net_params(net).p.size() + 64);  // two long tables (offset, len) = 4 floats per entry
   }
   P->arena_floats = off;
+  if (const char* e = getenv("UDET_SERIAL")) P->concurrent = atoi(e) == 0;
+  for (auto& st : P->side)
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { st = nullptr; P->concurrent = false; }
   // views into the small region (read by the host wrapper)
   struct { const char* n; int a, d; size_t o; } views[4] = {{"losses", 1, 8, 0}, {"loss_coef", B, 4, 16}, {"noise_flag", 1, 2, 256},
                                                             {"loss_sums", B, 5, 1024}};

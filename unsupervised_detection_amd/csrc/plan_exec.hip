@@ -49,13 +49,41 @@ static double layer_flops(const Layer& L, int N) {
   return 2.0 * N * oh * ow * L.cout * L.cin * taps;
 }
 
+// ---------------------------------------------------------------- lanes ----
+// Lane 0 is the caller's stream; lanes 1..3 are the plan's side streams.  While profiling (per-kernel timing) or
+// with UDET_SERIAL=1 every lane collapses onto the caller's stream, which reproduces the plain program order.
+struct Lane {
+  hipStream_t s;
+  int slot;
+};
+static Lane lane_of(Plan* P, hipStream_t main, int i) {
+  if (i == 0 || !P->concurrent || P->profiling) return Lane{main, 0};
+  return Lane{P->side[i - 1], i};
+}
+static hipEvent_t next_event(Plan* P) {
+  if (P->ev_next == P->ev_pool.size()) {
+    hipEvent_t e;
+    (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    P->ev_pool.push_back(e);
+  }
+  return P->ev_pool[P->ev_next++];
+}
+// work enqueued on `to` after this call also waits for everything enqueued on `from` so far
+static void order_after(Plan* P, const Lane& from, const Lane& to) {
+  if (from.s == to.s) return;
+  hipEvent_t e = next_event(P);
+  (void)hipEventRecord(e, from.s);
+  (void)hipStreamWaitEvent(to.s, e, 0);
+}
+
 // ------------------------------------------------------------- runners ----
-static void fill_common(Plan* P, ConvParams& p, float* ws) {
-  p.partial = ws + P->scratch_off;
+static void fill_common(Plan* P, ConvParams& p, float* ws, int slot) {
+  p.partial = ws + P->scratch_off[slot];
   p.partial_cap = P->scratch_floats;
 }
 
-static int run_fwd(Plan* P, const Layer& L, int N, float* ws, hipStream_t s, size_t x_extra = 0, size_t y_extra = 0) {
+static int run_fwd(Plan* P, const Layer& L, int N, float* ws, const Lane& ln, size_t x_extra = 0, size_t y_extra = 0) {
+  hipStream_t s = ln.s;
   const Buf &bx = P->buf(L.x), &by = P->buf(L.y);
   const int ncls = L.transposed ? conv_dgrad_classes(2, 2 * L.H, 2 * L.W) : 1;
   prof_begin(P, PROF_CONV_FWD, layer_flops(L, N), 0, s, L.name.c_str());
@@ -74,7 +102,7 @@ static int run_fwd(Plan* P, const Layer& L, int N, float* ws, hipStream_t s, siz
     p.act = L.act; p.alpha = L.alpha;
     if (L.res >= 0) { p.res = ws + P->buf(L.res).off; p.ldres = P->buf(L.res).ld; p.res_coff = L.res_coff; }
     if (L.y2 >= 0) { p.y2 = ws + P->buf(L.y2).off; p.ldy2 = P->buf(L.y2).ld; p.y2_coff = 0; }
-    fill_common(P, p, ws);
+    fill_common(P, p, ws, ln.slot);
     UDET_TRY(launch_conv(p, s));
   }
   prof_end(P, s);
@@ -83,7 +111,8 @@ static int run_fwd(Plan* P, const Layer& L, int N, float* ws, hipStream_t s, siz
 
 // gradient w.r.t. the layer input: dX(dx buffer) (=|+=) conv_T(dY * act'(saved output)) [+ res]
 static int run_dgrad(Plan* P, const Layer& L, int N, int dy, int dx, int dx_coff, int accumulate, int res, float* ws,
-                     hipStream_t s) {
+                     const Lane& ln) {
+  hipStream_t s = ln.s;
   const int act_buf = L.y2 >= 0 ? L.y2 : L.y;
   const Buf &bdy = P->buf(dy), &bdx = P->buf(dx), &ba = P->buf(act_buf);
   if (ba.ld != bdy.ld) {
@@ -102,14 +131,15 @@ static int run_dgrad(Plan* P, const Layer& L, int N, int dy, int dx, int dx_coff
     p.y = ws + bdx.off; p.ldy = bdx.ld; p.y_coff = dx_coff; p.Cout = L.cin;
     p.accumulate = accumulate;
     if (res >= 0) { p.res = ws + P->buf(res).off; p.ldres = P->buf(res).ld; p.res_coff = 0; }
-    fill_common(P, p, ws);
+    fill_common(P, p, ws, ln.slot);
     UDET_TRY(launch_conv(p, s));
   }
   prof_end(P, s);
   return UDET_OK;
 }
 
-static int run_wgrad(Plan* P, const Layer& L, int N, int dy, const float* w_flat, float* g_flat, float* ws, hipStream_t s) {
+static int run_wgrad(Plan* P, const Layer& L, int N, int dy, const float* w_flat, float* g_flat, float* ws, const Lane& ln) {
+  hipStream_t s = ln.s;
   const NetParams& np = net_params(L.net);
   const int act_buf = L.y2 >= 0 ? L.y2 : L.y;
   const Buf &bx = P->buf(L.x), &bdy = P->buf(dy), &ba = P->buf(act_buf);
@@ -128,7 +158,7 @@ static int run_wgrad(Plan* P, const Layer& L, int N, int dy, const float* w_flat
   memcpy(q.taps, g.taps, sizeof(g.taps));
   q.dw = g_flat + np.p[L.w_idx].offset;
   q.db = g_flat + np.p[L.b_idx].offset;
-  q.partial = ws + P->wgrad_off;
+  q.partial = ws + P->wgrad_off[ln.slot];
   q.partial_floats = P->wgrad_floats;
   if (L.g_idx >= 0) {
     q.w = w_flat + np.p[L.w_idx].offset;
@@ -213,13 +243,14 @@ int plan_pwc_forward(Plan* P, const float* img1, const float* img2, float* ws, h
   }
   const Config& c = P->cfg;
   const int B = c.batch;
+  const Lane L0 = lane_of(P, s, 0), LH = lane_of(P, s, 2);  // LH: the 2-channel heads, beside the context network
   UDET_TRY(launch_pack_pwc_input(img1, img2, ws + P->buf(P->bid("pwc.x8")).off, (long)B * c.in_h * c.in_w, s));
   // siamese feature pyramid on the 2B stacked images (model_pwcnet.py:149-168)
   for (int l = 1; l <= 6; ++l)
     for (const char* suf : {"a", "aa", "b"}) {
       char nm[64];
       snprintf(nm, sizeof(nm), "pwcnet/featpyr/conv%d%s", l, suf);
-      UDET_TRY(run_fwd(P, *find_layer(P->pwc, nm), 2 * B, ws, s));
+      UDET_TRY(run_fwd(P, *find_layer(P->pwc, nm), 2 * B, ws, L0));
     }
   for (int l = 6; l >= 2; --l) {
     const int h = c.in_h >> l, w = c.in_w >> l, C = PWC_CH[l];
@@ -240,13 +271,16 @@ int plan_pwc_forward(Plan* P, const float* img1, const float* img2, float* ws, h
     prof_begin(P, PROF_CORR, 2.0 * B * h * w * 81.0 * C, (double)B * h * w * (2.0 * C + 81.0) * 4.0, s);  // read c1 + warped, write 81 ch
     UDET_TRY(launch_cost_volume(c1, second, ws + slab.off, slab.ld, 448, B, h, w, C, s));
     prof_end(P, s);
-    for (int i = 0; i < 5; ++i) UDET_TRY(run_fwd(P, *find_layer(P->pwc, S("pwcnet/predict_flow/conv%d_%d", l, i)), B, ws, s));
-    UDET_TRY(run_fwd(P, *find_layer(P->pwc, S("pwcnet/predict_flow/flow%d", l)), B, ws, s));
-    for (int i = 1; i <= 7; ++i) UDET_TRY(run_fwd(P, *find_layer(P->pwc, S("pwcnet/ctxt/dc_conv%d%d", l, i)), B, ws, s));
-    if (l != 2) {
-      UDET_TRY(run_fwd(P, *find_layer(P->pwc, S("pwcnet/upsample/up_flow%d", l)), B, ws, s));
-      UDET_TRY(run_fwd(P, *find_layer(P->pwc, S("pwcnet/upsample/up_feat%d", l)), B, ws, s));
-    }
+    for (int i = 0; i < 5; ++i) UDET_TRY(run_fwd(P, *find_layer(P->pwc, S("pwcnet/predict_flow/conv%d_%d", l, i)), B, ws, L0));
+    // upfeat (the slab) is complete: the flow head and the learned upsampling of upfeat only read it, so they run on
+    // their own lane while the context network's six wide convolutions occupy the caller's stream
+    order_after(P, L0, LH);
+    UDET_TRY(run_fwd(P, *find_layer(P->pwc, S("pwcnet/predict_flow/flow%d", l)), B, ws, LH));
+    if (l != 2) UDET_TRY(run_fwd(P, *find_layer(P->pwc, S("pwcnet/upsample/up_feat%d", l)), B, ws, LH));
+    for (int i = 1; i <= 6; ++i) UDET_TRY(run_fwd(P, *find_layer(P->pwc, S("pwcnet/ctxt/dc_conv%d%d", l, i)), B, ws, L0));
+    order_after(P, LH, L0);
+    UDET_TRY(run_fwd(P, *find_layer(P->pwc, S("pwcnet/ctxt/dc_conv%d%d", l, 7)), B, ws, L0));  // + flow (residual operand)
+    if (l != 2) UDET_TRY(run_fwd(P, *find_layer(P->pwc, S("pwcnet/upsample/up_flow%d", l)), B, ws, L0));
   }
   // flow_pred = resize_bilinear(flow2, x4) * 4   (model_pwcnet.py:641-646)
   const Buf& fr = P->buf(P->bid("pwc.rflow2"));
@@ -254,12 +288,16 @@ int plan_pwc_forward(Plan* P, const float* img1, const float* img2, float* ws, h
   return launch_resize_bilinear_fwd(ws + fr.off, fr.ld, 0, B, fr.h, fr.w, ws + ff.off, 2, 0, c.in_h, c.in_w, 2, 4.0f, 1.f, s);
 }
 
-// image/flow -> img_h x img_w, flow / flow_normalizer  (adversarial_learner.py:87-97)
-int plan_prepare(Plan* P, const float* img1, float* ws, hipStream_t s) {
+// image -> img_h x img_w  (adversarial_learner.py:87-90)
+static int plan_prepare_image(Plan* P, const float* img1, float* ws, hipStream_t s) {
+  const Config& c = P->cfg;
+  return launch_resize_bilinear_fwd(img1, 3, 0, c.batch, c.in_h, c.in_w, ws + P->buf(P->bid("image")).off, 3, 0, c.img_h, c.img_w,
+                                    3, 1.f, 1.f, s);
+}
+// flow -> img_h x img_w, flow / flow_normalizer  (adversarial_learner.py:91-97)
+static int plan_prepare_flow(Plan* P, float* ws, hipStream_t s) {
   const Config& c = P->cfg;
   const Buf& ff = P->buf(P->bid("flow_full"));
-  UDET_TRY(launch_resize_bilinear_fwd(img1, 3, 0, c.batch, c.in_h, c.in_w, ws + P->buf(P->bid("image")).off, 3, 0, c.img_h,
-                                      c.img_w, 3, 1.f, 1.f, s));
   return launch_resize_bilinear_fwd(ws + ff.off, 2, 0, c.batch, c.in_h, c.in_w, ws + P->buf(P->bid("flow")).off, 2, 0, c.img_h,
                                     c.img_w, 2, 1.f, c.flow_normalizer, s);
 }
@@ -268,10 +306,11 @@ int plan_prepare(Plan* P, const float* img1, float* ws, hipStream_t s) {
 int plan_generator_forward(Plan* P, float* ws, hipStream_t s) {
   const Config& c = P->cfg;
   const long HW = (long)c.img_h * c.img_w;
+  const Lane L0 = lane_of(P, s, 0);
   double* part = reinterpret_cast<double*>(ws + P->small_off + 4096);
   UDET_TRY(launch_gen_input(ws + P->buf(P->bid("image")).off, ws + P->buf(P->bid("flow")).off, part,
                             ws + P->buf(P->bid("gen.in")).off, c.batch, HW, s));
-  for (const auto& L : P->gen) UDET_TRY(run_fwd(P, L, c.batch, ws, s));
+  for (const auto& L : P->gen) UDET_TRY(run_fwd(P, L, c.batch, ws, L0));
   return UDET_OK;
 }
 
@@ -280,27 +319,45 @@ static int rec_resize(Plan* P, const char* src, const char* dst, int N, float* w
   return launch_resize_bilinear_fwd(ws + a.off, a.ld, 0, N, a.h, a.w, ws + b.off, b.ld, 0, b.h, b.w, a.ld, 1.f, 1.f, s);
 }
 
+static const char* ENC_NAMES[9] = {"conv1", "conv2", "conv3", "conv31", "conv4", "conv41", "conv5", "conv51", "conv6"};
+
+// The image branch of recover_net (nets.py:57-65): image replicated for the `ncalls` invocations + encoder A.  It
+// depends on nothing but the image, so the step runs it beside PWC-Net / the generator.
+static int plan_rec_image_branch(Plan* P, int ncalls, float* ws, const Lane& ln) {
+  const Config& c = P->cfg;
+  if (ncalls < 1) return UDET_OK;
+  const long Ppix = (long)c.batch * c.img_h * c.img_w;
+  UDET_TRY(launch_pack_imgin(ws + P->buf(P->bid("image")).off, ws + P->buf(P->bid("rec.imgin")).off, Ppix, ncalls, ln.s));
+  for (int i = 0; i < 9; ++i) UDET_TRY(run_fwd(P, *find_layer(P->rec, std::string("a") + ENC_NAMES[i]), ncalls * c.batch, ws, ln));
+  return UDET_OK;
+}
+
 // mask, recover inputs, `ncalls` batched recover invocations (nets.py:45-110; adversarial_learner.py:107-131)
-int plan_recover_forward(Plan* P, int ncalls, float* ws, hipStream_t s, bool inputs_prepacked) {
+int plan_recover_forward(Plan* P, int ncalls, float* ws, hipStream_t s, bool inputs_prepacked, bool skip_enc_a) {
   const Config& c = P->cfg;
   const int B = c.batch, N = ncalls * B;
   const long Ppix = (long)B * c.img_h * c.img_w;
+  const Lane L0 = lane_of(P, s, 0);
   if (!inputs_prepacked)
-  UDET_TRY(launch_mask_rec_inputs(ws + P->buf(P->bid("gen.a17")).off, ws + P->buf(P->bid("image")).off,
-                                  ws + P->buf(P->bid("flow")).off, ws + P->buf(P->bid("mask")).off,
-                                  ws + P->buf(P->bid("rec.fin")).off, ws + P->buf(P->bid("rec.imgin")).off, Ppix, ncalls, s));
+    UDET_TRY(launch_mask_rec_inputs(ws + P->buf(P->bid("gen.a17")).off, ws + P->buf(P->bid("flow")).off,
+                                    ws + P->buf(P->bid("mask")).off, ws + P->buf(P->bid("rec.fin")).off, Ppix, ncalls, s));
   if (ncalls < 1) return UDET_OK;
-  const char* enc[9] = {"conv1", "conv2", "conv3", "conv31", "conv4", "conv41", "conv5", "conv51", "conv6"};
-  for (const char* e : {"a", "b"})
-    for (int i = 0; i < 9; ++i) UDET_TRY(run_fwd(P, *find_layer(P->rec, std::string(e) + enc[i]), N, ws, s));
+  if (!skip_enc_a) {
+    if (inputs_prepacked) {
+      for (int i = 0; i < 9; ++i) UDET_TRY(run_fwd(P, *find_layer(P->rec, std::string("a") + ENC_NAMES[i]), N, ws, L0));
+    } else {
+      UDET_TRY(plan_rec_image_branch(P, ncalls, ws, L0));
+    }
+  }
+  for (int i = 0; i < 9; ++i) UDET_TRY(run_fwd(P, *find_layer(P->rec, std::string("b") + ENC_NAMES[i]), N, ws, L0));
   for (int k = 5; k >= 1; --k) {
     UDET_TRY(rec_resize(P, k == 5 ? "rec.conv6" : S("rec.concat%d", k + 1).c_str(), S("rec.r%d", k + 1).c_str(), N, ws, s));
-    UDET_TRY(run_fwd(P, *find_layer(P->rec, S("deconv%d", k)), N, ws, s));
+    UDET_TRY(run_fwd(P, *find_layer(P->rec, S("deconv%d", k)), N, ws, L0));
     if (k < 5) {
       UDET_TRY(rec_resize(P, S("rec.flow%d", k + 1).c_str(), S("rec.rf%d", k + 1).c_str(), N, ws, s));
-      UDET_TRY(run_fwd(P, *find_layer(P->rec, S("upflow%d", k)), N, ws, s));
+      UDET_TRY(run_fwd(P, *find_layer(P->rec, S("upflow%d", k)), N, ws, L0));
     }
-    UDET_TRY(run_fwd(P, *find_layer(P->rec, S("flow%d", k)), N, ws, s));
+    UDET_TRY(run_fwd(P, *find_layer(P->rec, S("flow%d", k)), N, ws, L0));
   }
   const Buf& f1 = P->buf(P->bid("rec.flow1"));
   return launch_resize_bilinear_fwd(ws + f1.off, f1.ld, 0, N, f1.h, f1.w, ws + P->buf(P->bid("pred")).off, 2, 0, c.img_h,
@@ -308,7 +365,7 @@ int plan_recover_forward(Plan* P, int ncalls, float* ws, hipStream_t s, bool inp
 }
 
 // small region layout (floats from small_off): [0,8) losses, [16,16+4B) coef, [256,258) noise flag,
-// [2048,..) per-variable |g| partial sums, [1024,1024+5B) sums, [4096,..) flow-stat partials (doubles), [8192,..) loss partials
+// [1024,1024+5B) sums, [2048,..) per-variable |g| partial sums, [4096,..) flow-stat partials (doubles), [8192,..) loss partials
 int plan_losses(Plan* P, float* ws, hipStream_t s) {
   const Config& c = P->cfg;
   float* sm = ws + P->small_off;
@@ -317,85 +374,125 @@ int plan_losses(Plan* P, float* ws, hipStream_t s) {
                        c.batch, c.cbn, c.epsilon, (float)(c.img_w * c.img_h * c.batch), sm + 8192, sm, sm + 16, sm + 1024, s);
 }
 
+// adversarial_learner.py:83-204.  Lane 1 carries the image branch (image resize, recover encoder A) beside
+// PWC-Net and the generator on the caller's stream.
+int plan_forward(Plan* P, const float* img1, const float* img2, int ncalls, float* ws, hipStream_t s) {
+  P->ev_next = 0;
+  const Lane L0 = lane_of(P, s, 0), LI = lane_of(P, s, 1);
+  order_after(P, L0, LI);
+  if (img1) UDET_TRY(plan_prepare_image(P, img1, ws, LI.s));
+  hipEvent_t e_img = nullptr;
+  if (LI.s != L0.s) {
+    e_img = next_event(P);
+    (void)hipEventRecord(e_img, LI.s);
+  }
+  UDET_TRY(plan_rec_image_branch(P, ncalls, ws, LI));
+  if (img1) {
+    UDET_TRY(plan_pwc_forward(P, img1, img2, ws, s));
+    UDET_TRY(plan_prepare_flow(P, ws, s));
+  }
+  if (e_img) (void)hipStreamWaitEvent(s, e_img, 0);
+  UDET_TRY(plan_generator_forward(P, ws, s));
+  order_after(P, LI, L0);
+  UDET_TRY(plan_recover_forward(P, ncalls, ws, s, false, true));
+  if (ncalls == 3) UDET_TRY(plan_losses(P, ws, s));
+  return UDET_OK;
+}
+
 // ------------------------------------------------------------ backward ----
-// Recover decoder/encoder backward for the first N samples of the batched calls, seeded by d.pred.
-// with_wgrad: also produce parameter gradients into g_rec.  need_dfin: propagate to the b-encoder input.
-static int rec_backward(Plan* P, int N, bool with_wgrad, bool need_dfin, const float* w_rec, float* g_rec, float* ws,
-                        hipStream_t s) {
+// Recover decoder/encoder backward for the first N samples of the batched calls, seeded by <dp>pred.
+// `dp` is the gradient-buffer family ("d" recover-loss pass, "e" generator-loss pass).
+// with_wgrad: parameter gradients into g_rec, each on lane LW right where its output gradient is final.
+// need_dfin: propagate to the b-encoder input.
+static int rec_backward(Plan* P, int N, const char* dp, bool with_wgrad, bool need_dfin, const float* w_rec, float* g_rec, float* ws,
+                        const Lane& LD, const Lane& LW) {
   const Config& c = P->cfg;
+  hipStream_t s = LD.s;
+  const std::string pre = std::string("rec.") + dp + ".";
   auto B_ = [&](const std::string& n) { return P->bid(n); };
+  auto D_ = [&](const std::string& n) { return P->bid(pre + n); };
   auto Lr = [&](const std::string& n) { return find_layer(P->rec, n); };
+  auto wgrad = [&](const Layer& L, int dy) -> int {
+    order_after(P, LD, LW);
+    return run_wgrad(P, L, N, dy, w_rec, g_rec, ws, LW);
+  };
   // pred = resize(flow1)
   {
-    const Buf& df1 = P->buf(B_("rec.d.flow1"));
-    UDET_TRY(launch_resize_bilinear_bwd(ws + P->buf(B_("d.pred")).off, 2, 0, N, c.img_h, c.img_w, ws + df1.off, df1.ld, 0, df1.h,
-                                        df1.w, 2, 0, s));
+    const Buf& df1 = P->buf(D_("flow1"));
+    UDET_TRY(launch_resize_bilinear_bwd(ws + P->buf(B_(std::string(dp) + ".pred")).off, 2, 0, N, c.img_h, c.img_w, ws + df1.off,
+                                        df1.ld, 0, df1.h, df1.w, 2, 0, s));
   }
   for (int k = 1; k <= 5; ++k) {
-    const int dconcat = B_(S("rec.d.concat%d", k));
+    const int dconcat = D_(S("concat%d", k));
     const Layer* fl = Lr(S("flow%d", k));
     // concat_k feeds flow_k (and, for k<5 .. handled below, the resize of the next finer level wrote it first)
-    UDET_TRY(run_dgrad(P, *fl, N, B_(S("rec.d.flow%d", k)), dconcat, 0, k == 1 ? 0 : 1, -1, ws, s));
-    if (with_wgrad) UDET_TRY(run_wgrad(P, *fl, N, B_(S("rec.d.flow%d", k)), w_rec, g_rec, ws, s));
+    UDET_TRY(run_dgrad(P, *fl, N, D_(S("flow%d", k)), dconcat, 0, k == 1 ? 0 : 1, -1, ws, LD));
+    if (with_wgrad) UDET_TRY(wgrad(*fl, D_(S("flow%d", k))));
     if (k < 5) {
       const Layer* uf = Lr(S("upflow%d", k));
-      if (with_wgrad) UDET_TRY(run_wgrad(P, *uf, N, dconcat, w_rec, g_rec, ws, s));
-      UDET_TRY(run_dgrad(P, *uf, N, dconcat, B_(S("rec.d.rf%d", k + 1)), 0, 0, -1, ws, s));
-      const Buf &drf = P->buf(B_(S("rec.d.rf%d", k + 1))), &dfn = P->buf(B_(S("rec.d.flow%d", k + 1)));
+      if (with_wgrad) UDET_TRY(wgrad(*uf, dconcat));
+      UDET_TRY(run_dgrad(P, *uf, N, dconcat, D_(S("rf%d", k + 1)), 0, 0, -1, ws, LD));
+      const Buf &drf = P->buf(D_(S("rf%d", k + 1))), &dfn = P->buf(D_(S("flow%d", k + 1)));
       UDET_TRY(launch_resize_bilinear_bwd(ws + drf.off, drf.ld, 0, N, drf.h, drf.w, ws + dfn.off, dfn.ld, 0, dfn.h, dfn.w, 2, 0, s));
     }
     const Layer* dc = Lr(S("deconv%d", k));
-    if (with_wgrad) UDET_TRY(run_wgrad(P, *dc, N, dconcat, w_rec, g_rec, ws, s));
-    const int dr = B_(S("rec.d.r%d", k + 1));
-    UDET_TRY(run_dgrad(P, *dc, N, dconcat, dr, 0, 0, -1, ws, s));
+    if (with_wgrad) UDET_TRY(wgrad(*dc, dconcat));
+    const int dr = D_(S("r%d", k + 1));
+    UDET_TRY(run_dgrad(P, *dc, N, dconcat, dr, 0, 0, -1, ws, LD));
     const Buf& bdr = P->buf(dr);
-    const Buf& dsrc = P->buf(k == 5 ? B_("rec.d.conv6") : B_(S("rec.d.concat%d", k + 1)));
+    const Buf& dsrc = P->buf(k == 5 ? D_("conv6") : D_(S("concat%d", k + 1)));
     UDET_TRY(launch_resize_bilinear_bwd(ws + bdr.off, bdr.ld, 0, N, bdr.h, bdr.w, ws + dsrc.off, dsrc.ld, 0, dsrc.h, dsrc.w,
                                         bdr.ld, 0, s));
   }
   // encoders, deepest first.  gradient buffers mirror the forward buffers of each conv's output / input.
-  const char* enc[9] = {"conv1", "conv2", "conv3", "conv31", "conv4", "conv41", "conv5", "conv51", "conv6"};
   for (int i = 8; i >= 0; --i)
     for (const char* e : {"a", "b"}) {
-      const Layer* L = Lr(std::string(e) + enc[i]);
-      const int dy = B_("rec.d." + P->buf(L->y).name.substr(4));
-      if (with_wgrad) UDET_TRY(run_wgrad(P, *L, N, dy, w_rec, g_rec, ws, s));
+      // encoder A sees only the image: without parameter gradients (generator-loss pass) nothing upstream needs it
+      if (e[0] == 'a' && !with_wgrad) continue;
+      const Layer* L = Lr(std::string(e) + ENC_NAMES[i]);
+      const int dy = D_(P->buf(L->y).name.substr(4));
+      if (with_wgrad) UDET_TRY(wgrad(*L, dy));
       if (i == 0) {
-        if (e[0] == 'b' && need_dfin) UDET_TRY(run_dgrad(P, *L, N, dy, B_("rec.d.fin"), 0, 0, -1, ws, s));
+        if (e[0] == 'b' && need_dfin) UDET_TRY(run_dgrad(P, *L, N, dy, D_("fin"), 0, 0, -1, ws, LD));
         continue;
       }
       const std::string xname = P->buf(L->x).name;
-      const int dx = B_("rec.d." + xname.substr(4));
+      const int dx = D_(xname.substr(4));
       const bool slab_in = xname.find("concat") != std::string::npos;  // slab inputs already hold the decoder's gradient
-      UDET_TRY(run_dgrad(P, *L, N, dy, dx, L->x_coff, slab_in ? 1 : 0, -1, ws, s));
+      UDET_TRY(run_dgrad(P, *L, N, dy, dx, L->x_coff, slab_in ? 1 : 0, -1, ws, LD));
     }
   return UDET_OK;
 }
 
-int plan_backward_recover(Plan* P, const float* w_rec, float* g_rec, float* ws, hipStream_t s) {
+// d recover_loss / d FlownetS  (loss_utils.py:18; adversarial_learner.py:230-234)
+static int backward_recover(Plan* P, const float* w_rec, float* g_rec, float* ws, const Lane& LD, const Lane& LW) {
   const Config& c = P->cfg;
   const long BHW = (long)c.batch * c.img_h * c.img_w;
   UDET_TRY(launch_rec_loss_bwd(ws + P->buf(P->bid("flow")).off, ws + P->buf(P->bid("mask")).off, ws + P->buf(P->bid("pred")).off,
-                               ws + P->buf(P->bid("d.pred")).off, BHW, c.cbn, 1.0f / (float)(c.img_w * c.img_h * c.batch), s));
-  return rec_backward(P, 3 * c.batch, true, false, w_rec, g_rec, ws, s);
+                               ws + P->buf(P->bid("d.pred")).off, BHW, c.cbn, 1.0f / (float)(c.img_w * c.img_h * c.batch), LD.s));
+  return rec_backward(P, 3 * c.batch, "d", true, false, w_rec, g_rec, ws, LD, LW);
 }
 
-int plan_backward_generator(Plan* P, const float* w_gen, float* g_gen, float* ws, hipStream_t s) {
+// d generator_loss / d MaskNet  (adversarial_learner.py:224-228): through recover calls 1 and 2 (data gradient only,
+// "e" buffers), the mask, then the generator.
+static int backward_generator(Plan* P, const float* w_gen, float* g_gen, float* ws, const Lane& LD, const Lane& LW) {
   const Config& c = P->cfg;
   const int B = c.batch;
   const long HW = (long)c.img_h * c.img_w;
+  hipStream_t s = LD.s;
   float* sm = ws + P->small_off;
   auto B_ = [&](const std::string& n) { return P->bid(n); };
   UDET_TRY(launch_gen_loss_bwd(ws + P->buf(B_("flow")).off, ws + P->buf(B_("mask")).off, ws + P->buf(B_("pred")).off, sm + 16,
-                               ws + P->buf(B_("d.pred")).off, ws + P->buf(B_("d.mask")).off, HW, B, c.cbn, s));
-  UDET_TRY(rec_backward(P, 2 * B, false, true, nullptr, nullptr, ws, s));
-  UDET_TRY(launch_mask_bwd(ws + P->buf(B_("d.mask")).off, ws + P->buf(B_("rec.d.fin")).off, ws + P->buf(B_("flow")).off,
+                               ws + P->buf(B_("e.pred")).off, ws + P->buf(B_("d.mask")).off, HW, B, c.cbn, s));
+  UDET_TRY(rec_backward(P, 2 * B, "e", false, true, nullptr, nullptr, ws, LD, LD));
+  UDET_TRY(launch_mask_bwd(ws + P->buf(B_("d.mask")).off, ws + P->buf(B_("rec.e.fin")).off, ws + P->buf(B_("flow")).off,
                            ws + P->buf(B_("mask")).off, ws + P->buf(B_("gen.d17")).off, B * HW, s));
   // generator, last layer first.  gen.d{k} = gradient w.r.t. layer k's (post-skip) output.
   for (int i = 16; i >= 0; --i) {
     const Layer& L = P->gen[i];
     const int dy = B_(S("gen.d%d", i + 1));
-    UDET_TRY(run_wgrad(P, L, B, dy, w_gen, g_gen, ws, s));
+    order_after(P, LD, LW);
+    UDET_TRY(run_wgrad(P, L, B, dy, w_gen, g_gen, ws, LW));
     if (i == 0) break;
     // skip gradients: x2 = a6 (+ d11), x1 = a3 (+ d14), x0 = a1 (+ d15)   (nets.py:29,32,33)
     int res = -1;
@@ -405,12 +502,34 @@ int plan_backward_generator(Plan* P, const float* w_gen, float* g_gen, float* ws
     const int dx = B_(S("gen.d%d", i));
     if (L.up) {
       const int dup = B_(S("gen.dup%d", i + 1));
-      UDET_TRY(run_dgrad(P, L, B, dy, dup, 0, 0, -1, ws, s));
+      UDET_TRY(run_dgrad(P, L, B, dy, dup, 0, 0, -1, ws, LD));
       const Buf& bd = P->buf(dx);
       UDET_TRY(launch_pool2x2_sum(ws + P->buf(dup).off, ws + bd.off, B, bd.h, bd.w, bd.ld, s));
     } else {
-      UDET_TRY(run_dgrad(P, L, B, dy, dx, 0, 0, res, ws, s));
+      UDET_TRY(run_dgrad(P, L, B, dy, dx, 0, 0, res, ws, LD));
     }
+  }
+  return UDET_OK;
+}
+
+// Both passes only read the forward state, so with which == 3 they run concurrently: the recover-loss pass on the
+// caller's stream (its filter gradients on lane 2), the generator-loss pass on lane 1 (filter gradients on lane 3).
+int plan_backward(Plan* P, int which, const float* w_gen, const float* w_rec, float* g_gen, float* g_rec, float* ws, hipStream_t s) {
+  P->ev_next = 0;
+  const Lane L0 = lane_of(P, s, 0), L1 = lane_of(P, s, 1), L2 = lane_of(P, s, 2), L3 = lane_of(P, s, 3);
+  if (which == 3) {
+    order_after(P, L0, L1);
+    UDET_TRY(backward_recover(P, w_rec, g_rec, ws, L0, L2));
+    UDET_TRY(backward_generator(P, w_gen, g_gen, ws, L1, L3));
+    order_after(P, L1, L0);
+    order_after(P, L2, L0);
+    order_after(P, L3, L0);
+  } else if (which == 2) {
+    UDET_TRY(backward_recover(P, w_rec, g_rec, ws, L0, L2));
+    order_after(P, L2, L0);
+  } else {
+    UDET_TRY(backward_generator(P, w_gen, g_gen, ws, L0, L3));
+    order_after(P, L3, L0);
   }
   return UDET_OK;
 }

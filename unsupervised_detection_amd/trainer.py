@@ -51,12 +51,12 @@ def train_step(st: TrainState, img1, img2, which: int = BOTH, group=None):
     e = st.engine
     e.pack_trainable(st.w_gen if which & GEN else None, st.w_rec if which & REC else None)
     e.forward(img1, img2, 3)
+    # one call: with BOTH the two backward passes run concurrently on the plan's side streams (udet_backward)
+    e.backward(which, st.w_gen, st.w_rec, st.g_gen, st.g_rec)
     works = []
     if which & REC:
-        e.backward(REC, st.w_gen, st.w_rec, st.g_gen, st.g_rec)
-        works.append(allreduce_mean_(st.g_rec, group, async_op=True))  # overlaps the generator backward
+        works.append(allreduce_mean_(st.g_rec, group, async_op=True))
     if which & GEN:
-        e.backward(GEN, st.w_gen, st.w_rec, st.g_gen, st.g_rec)
         works.append(allreduce_mean_(st.g_gen, group, async_op=True))
     for wk in works:
         if wk is not None:
