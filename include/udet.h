@@ -124,6 +124,14 @@ int udet_pwc_forward(udet_plan* plan, const float* img1, const float* img2, void
  * and (ncalls==3) the 8 entries of losses{} (:196-204) into buffer "losses".
  * Results: buffers "image","flow","mask","pred" ([ncalls*B,...]). */
 int udet_forward(udet_plan* plan, const float* img1, const float* img2, int ncalls, void* workspace, void* stream);
+/* Cross-step pipelining.  PWC-Net is frozen (adversarial_learner.py:211-214), so the flow of the NEXT pair does not
+ * depend on this step's optimizer update: udet_prefetch_flow enqueues PWC flow + the two resizes of (img1,img2) on the
+ * plan's side streams, forked from `stream` at call time, into staging buffers ("image.next","flow.next"); it runs
+ * concurrently with whatever is enqueued on `stream` afterwards (typically udet_backward of the current step).
+ * udet_forward_prefetched joins it, moves the staging buffers into "image"/"flow" and continues like udet_forward.
+ * img1/img2 must stay valid until that join.  One prefetch may be pending at a time. */
+int udet_prefetch_flow(udet_plan* plan, const float* img1, const float* img2, void* workspace, void* stream);
+int udet_forward_prefetched(udet_plan* plan, int ncalls, void* workspace, void* stream);
 /* same but starting from caller-filled "image" and "flow" buffers (generator_net/recover_net surface, nets.py:4,45) */
 int udet_forward_from_flow(udet_plan* plan, int ncalls, void* workspace, void* stream);
 /* generator_net(images, flows) alone (models/nets.py:4-42): reads "image","flow", writes "mask" (flow standardisation

@@ -50,3 +50,31 @@ def test_autotuned_step_matches_oracle():
     ref = W.from_dict({k: v.float() for k, v in gr.items()}, W.NET_REC)
     err = float((g[W.NET_REC].cpu() - ref).abs().max())
     assert err < 1e-3 * max(1.0, float(ref.abs().max())), err
+
+
+def test_pipelined_and_concurrent_steps_are_bit_identical_to_serial(monkeypatch):
+    """Cross-step prefetch of the PWC flow + the multi-stream step only re-order independent work: three training steps
+    must leave exactly the same weights as the same steps run strictly serially (UDET_SERIAL=1, no prefetch)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from unsupervised_detection_amd.engine import BOTH, Engine, EngineConfig
+    from unsupervised_detection_amd.trainer import TrainState, train_step
+    cfg = EngineConfig(batch_size=2, in_height=128, in_width=192, img_height=64, img_width=128)
+    gen = torch.Generator().manual_seed(11)
+    pairs = [((torch.rand(2, 128, 192, 3, generator=gen) - 0.5).cuda(), (torch.rand(2, 128, 192, 3, generator=gen) - 0.5).cuda())
+             for _ in range(3)]
+
+    def run(pipelined):
+        st = TrainState(Engine(cfg), seed=5)
+        for i, (a, b) in enumerate(pairs):
+            nxt = pairs[i + 1] if (pipelined and i + 1 < len(pairs)) else None
+            train_step(st, a, b, BOTH, next_pair=nxt)
+        torch.cuda.synchronize()
+        return st.w_gen.clone(), st.w_rec.clone(), st.engine.losses()
+
+    monkeypatch.setenv("UDET_SERIAL", "1")
+    g0, r0, l0 = run(False)
+    monkeypatch.setenv("UDET_SERIAL", "0")
+    g1, r1, l1 = run(True)
+    assert torch.equal(g0, g1) and torch.equal(r0, r1)
+    assert l0 == l1

@@ -78,6 +78,14 @@ int udet_forward(udet_plan* h, const float* img1, const float* img2, int ncalls,
   if (!img1 || !img2) { set_error("forward: null image pointer"); return UDET_ERR_ARG; }
   return plan_forward(h->p, img1, img2, ncalls, (float*)ws, (hipStream_t)stream);
 }
+int udet_prefetch_flow(udet_plan* h, const float* img1, const float* img2, void* ws, void* stream) {
+  if (!img1 || !img2) { set_error("prefetch_flow: null image pointer"); return UDET_ERR_ARG; }
+  return plan_prefetch(h->p, img1, img2, (float*)ws, (hipStream_t)stream);
+}
+int udet_forward_prefetched(udet_plan* h, int ncalls, void* ws, void* stream) {
+  if (ncalls < 0 || ncalls > 3) { set_error("forward: ncalls must be 0..3"); return UDET_ERR_ARG; }
+  return plan_forward(h->p, nullptr, nullptr, ncalls, (float*)ws, (hipStream_t)stream, true);
+}
 int udet_backward(udet_plan* h, int which, const float* w_gen, const float* w_rec, float* g_gen, float* g_rec, void* ws,
                   void* stream) {
   if (which < 1 || which > 3) { set_error("backward: which must be 1 (generator), 2 (recover) or 3 (both)"); return UDET_ERR_ARG; }

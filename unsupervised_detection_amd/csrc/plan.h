@@ -70,13 +70,16 @@ struct Plan {
   size_t arena_floats = 0;       // everything
   // Concurrency: independent chains of the step run on side streams forked from / joined to the caller's stream
   // with events (lane 0 = the caller's stream).  Every lane owns its split-K and wgrad scratch.
-  enum { NLANE = 4 };
-  hipStream_t side[NLANE - 1] = {nullptr, nullptr, nullptr};
-  std::vector<hipEvent_t> ev_pool;
-  size_t ev_next = 0;
+  enum { NLANE = 6 };
+  hipStream_t side[NLANE - 1] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t prefetch_ev = nullptr;  // completion of the last udet_prefetch_flow (lane 4)
+  bool prefetch_pending = false;
+  std::vector<hipEvent_t> ev_pool, ev_pool_prefetch;  // recycled per call (step) / per prefetch
+  size_t ev_next = 0, ev_next_prefetch = 0;
+  bool in_prefetch = false;
   bool concurrent = true;
-  size_t scratch_off[NLANE] = {0, 0, 0, 0}, scratch_floats = 0;   // split-K slabs
-  size_t wgrad_off[NLANE] = {0, 0, 0, 0}, wgrad_floats = 0;       // wgrad partials
+  size_t scratch_off[NLANE] = {}, scratch_floats = 0;   // split-K slabs
+  size_t wgrad_off[NLANE] = {}, wgrad_floats = 0;       // wgrad partials (lanes that run filter gradients)
   ~Plan();
   size_t small_off = 0;          // losses, coefficients, flags, reduction partials
   size_t seg_off[3] = {0, 0, 0}; // per-variable (offset,len) tables on device (as long)
@@ -99,7 +102,10 @@ int plan_pack_pwc(Plan* P, const float* w_pwc, float* ws, hipStream_t s);
 int plan_pack_trainable(Plan* P, const float* w_gen, const float* w_rec, float* ws, hipStream_t s);
 int plan_pwc_forward(Plan* P, const float* img1, const float* img2, float* ws, hipStream_t s);
 // img1 != null: PWC flow + resizes first; then generator, `ncalls` recover invocations, losses (ncalls == 3)
-int plan_forward(Plan* P, const float* img1, const float* img2, int ncalls, float* ws, hipStream_t s);
+int plan_forward(Plan* P, const float* img1, const float* img2, int ncalls, float* ws, hipStream_t s, bool prefetched = false);
+// PWC flow + resizes of the NEXT step's pair into staging buffers, on lanes 4/5, concurrent with whatever the caller
+// enqueues next (PWC-Net is frozen: adversarial_learner.py:211-214); consumed by plan_forward(.., prefetched=true)
+int plan_prefetch(Plan* P, const float* img1, const float* img2, float* ws, hipStream_t s);
 int plan_generator_forward(Plan* P, float* ws, hipStream_t s);
 int plan_recover_forward(Plan* P, int ncalls, float* ws, hipStream_t s, bool inputs_prepacked = false, bool skip_enc_a = false);
 int plan_losses(Plan* P, float* ws, hipStream_t s);

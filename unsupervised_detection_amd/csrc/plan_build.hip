@@ -172,6 +172,8 @@ Plan::~Plan() {
   for (auto& st : side)
     if (st) (void)hipStreamDestroy(st);
   for (auto& e : ev_pool) (void)hipEventDestroy(e);
+  for (auto& e : ev_pool_prefetch) (void)hipEventDestroy(e);
+  if (prefetch_ev) (void)hipEventDestroy(prefetch_ev);
 }
 
 Plan* plan_build(const Config& cfg) {
@@ -289,6 +291,8 @@ Plan* plan_build(const Config& cfg) {
   const int H = cfg.img_h, W = cfg.img_w;
   P->add_buf("image", B, H, W, 3);
   P->add_buf("flow", B, H, W, 2);
+  P->add_buf("image.next", B, H, W, 3);  // staging of the prefetched next step (udet_prefetch_flow)
+  P->add_buf("flow.next", B, H, W, 2);
   P->add_buf("mask", B, H, W, 1);
   P->add_buf("pred", 3 * B, H, W, 2);
   P->add_buf("d.pred", 3 * B, H, W, 2);
@@ -450,7 +454,7 @@ Plan* plan_build(const Config& cfg) {
     P->scratch_off[l] = off;
     off = align64(off + P->scratch_floats);
     P->wgrad_off[l] = off;
-    off = align64(off + P->wgrad_floats);
+    if (l < 4) off = align64(off + P->wgrad_floats);  // lanes 4/5 (prefetch) never run filter gradients
   }
   P->small_off = off;
   off = align64(off + 65536);

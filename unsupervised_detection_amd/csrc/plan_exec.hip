@@ -61,12 +61,14 @@ static Lane lane_of(Plan* P, hipStream_t main, int i) {
   return Lane{P->side[i - 1], i};
 }
 static hipEvent_t next_event(Plan* P) {
-  if (P->ev_next == P->ev_pool.size()) {
+  std::vector<hipEvent_t>& pool = P->in_prefetch ? P->ev_pool_prefetch : P->ev_pool;
+  size_t& nx = P->in_prefetch ? P->ev_next_prefetch : P->ev_next;
+  if (nx == pool.size()) {
     hipEvent_t e;
     (void)hipEventCreateWithFlags(&e, hipEventDisableTiming);
-    P->ev_pool.push_back(e);
+    pool.push_back(e);
   }
-  return P->ev_pool[P->ev_next++];
+  return pool[nx++];
 }
 // work enqueued on `to` after this call also waits for everything enqueued on `from` so far
 static void order_after(Plan* P, const Lane& from, const Lane& to) {
@@ -236,14 +238,15 @@ int plan_pack_trainable(Plan* P, const float* w_gen, const float* w_rec, float* 
 // ------------------------------------------------------------ PWC-Net ----
 static const int PWC_CH[7] = {0, 16, 32, 64, 96, 128, 196};
 
-int plan_pwc_forward(Plan* P, const float* img1, const float* img2, float* ws, hipStream_t s) {
+// L0: the lane of the pyramid / estimator / context chain; LH: the 2-channel heads, beside the context network
+static int pwc_forward_on(Plan* P, const float* img1, const float* img2, float* ws, const Lane& L0, const Lane& LH) {
   if (!P->pwc_packed) {
     set_error("pwc_forward: call udet_pack_pwc first");
     return UDET_ERR_ARG;
   }
   const Config& c = P->cfg;
   const int B = c.batch;
-  const Lane L0 = lane_of(P, s, 0), LH = lane_of(P, s, 2);  // LH: the 2-channel heads, beside the context network
+  hipStream_t s = L0.s;
   UDET_TRY(launch_pack_pwc_input(img1, img2, ws + P->buf(P->bid("pwc.x8")).off, (long)B * c.in_h * c.in_w, s));
   // siamese feature pyramid on the 2B stacked images (model_pwcnet.py:149-168)
   for (int l = 1; l <= 6; ++l)
@@ -288,18 +291,39 @@ int plan_pwc_forward(Plan* P, const float* img1, const float* img2, float* ws, h
   return launch_resize_bilinear_fwd(ws + fr.off, fr.ld, 0, B, fr.h, fr.w, ws + ff.off, 2, 0, c.in_h, c.in_w, 2, 4.0f, 1.f, s);
 }
 
+int plan_pwc_forward(Plan* P, const float* img1, const float* img2, float* ws, hipStream_t s) {
+  P->ev_next = 0;
+  return pwc_forward_on(P, img1, img2, ws, lane_of(P, s, 0), lane_of(P, s, 2));
+}
+
 // image -> img_h x img_w  (adversarial_learner.py:87-90)
-static int plan_prepare_image(Plan* P, const float* img1, float* ws, hipStream_t s) {
+static int plan_prepare_image(Plan* P, const float* img1, const char* dst, float* ws, hipStream_t s) {
   const Config& c = P->cfg;
-  return launch_resize_bilinear_fwd(img1, 3, 0, c.batch, c.in_h, c.in_w, ws + P->buf(P->bid("image")).off, 3, 0, c.img_h, c.img_w,
+  return launch_resize_bilinear_fwd(img1, 3, 0, c.batch, c.in_h, c.in_w, ws + P->buf(P->bid(dst)).off, 3, 0, c.img_h, c.img_w,
                                     3, 1.f, 1.f, s);
 }
 // flow -> img_h x img_w, flow / flow_normalizer  (adversarial_learner.py:91-97)
-static int plan_prepare_flow(Plan* P, float* ws, hipStream_t s) {
+static int plan_prepare_flow(Plan* P, const char* dst, float* ws, hipStream_t s) {
   const Config& c = P->cfg;
   const Buf& ff = P->buf(P->bid("flow_full"));
-  return launch_resize_bilinear_fwd(ws + ff.off, 2, 0, c.batch, c.in_h, c.in_w, ws + P->buf(P->bid("flow")).off, 2, 0, c.img_h,
+  return launch_resize_bilinear_fwd(ws + ff.off, 2, 0, c.batch, c.in_h, c.in_w, ws + P->buf(P->bid(dst)).off, 2, 0, c.img_h,
                                     c.img_w, 2, 1.f, c.flow_normalizer, s);
+}
+
+int plan_prefetch(Plan* P, const float* img1, const float* img2, float* ws, hipStream_t s) {
+  const Lane L0 = lane_of(P, s, 0), LC = lane_of(P, s, 4), LH = lane_of(P, s, 5);
+  P->in_prefetch = true;  // own event pool: the step's pool is recycled while this work is still in flight
+  P->ev_next_prefetch = 0;
+  order_after(P, L0, LC);
+  int rc = pwc_forward_on(P, img1, img2, ws, LC, LH);
+  P->in_prefetch = false;
+  UDET_TRY(rc);
+  UDET_TRY(plan_prepare_flow(P, "flow.next", ws, LC.s));
+  UDET_TRY(plan_prepare_image(P, img1, "image.next", ws, LC.s));
+  if (!P->prefetch_ev) (void)hipEventCreateWithFlags(&P->prefetch_ev, hipEventDisableTiming);
+  (void)hipEventRecord(P->prefetch_ev, LC.s);
+  P->prefetch_pending = true;
+  return UDET_OK;
 }
 
 // --------------------------------------------------- generator / recover ----
@@ -376,11 +400,23 @@ int plan_losses(Plan* P, float* ws, hipStream_t s) {
 
 // adversarial_learner.py:83-204.  Lane 1 carries the image branch (image resize, recover encoder A) beside
 // PWC-Net and the generator on the caller's stream.
-int plan_forward(Plan* P, const float* img1, const float* img2, int ncalls, float* ws, hipStream_t s) {
+int plan_forward(Plan* P, const float* img1, const float* img2, int ncalls, float* ws, hipStream_t s, bool prefetched) {
   P->ev_next = 0;
   const Lane L0 = lane_of(P, s, 0), LI = lane_of(P, s, 1);
+  if (prefetched) {
+    if (!P->prefetch_pending) {
+      set_error("forward_prefetched: no udet_prefetch_flow is pending");
+      return UDET_ERR_ARG;
+    }
+    (void)hipStreamWaitEvent(s, P->prefetch_ev, 0);
+    P->prefetch_pending = false;
+    const Buf &fn = P->buf(P->bid("flow.next")), &in = P->buf(P->bid("image.next"));
+    UDET_HIP(hipMemcpyAsync(ws + P->buf(P->bid("flow")).off, ws + fn.off, fn.floats() * sizeof(float), hipMemcpyDeviceToDevice, s));
+    UDET_HIP(hipMemcpyAsync(ws + P->buf(P->bid("image")).off, ws + in.off, in.floats() * sizeof(float), hipMemcpyDeviceToDevice, s));
+    img1 = img2 = nullptr;
+  }
   order_after(P, L0, LI);
-  if (img1) UDET_TRY(plan_prepare_image(P, img1, ws, LI.s));
+  if (img1) UDET_TRY(plan_prepare_image(P, img1, "image", ws, LI.s));
   hipEvent_t e_img = nullptr;
   if (LI.s != L0.s) {
     e_img = next_event(P);
@@ -388,8 +424,8 @@ int plan_forward(Plan* P, const float* img1, const float* img2, int ncalls, floa
   }
   UDET_TRY(plan_rec_image_branch(P, ncalls, ws, LI));
   if (img1) {
-    UDET_TRY(plan_pwc_forward(P, img1, img2, ws, s));
-    UDET_TRY(plan_prepare_flow(P, ws, s));
+    UDET_TRY(pwc_forward_on(P, img1, img2, ws, L0, lane_of(P, s, 2)));
+    UDET_TRY(plan_prepare_flow(P, "flow", ws, s));
   }
   if (e_img) (void)hipStreamWaitEvent(s, e_img, 0);
   UDET_TRY(plan_generator_forward(P, ws, s));

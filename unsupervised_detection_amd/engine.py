@@ -37,6 +37,7 @@ for _n, _a in (("udet_pack_pwc", [c_p, c_p, c_p, c_p]), ("udet_pack_trainable", 
                ("udet_pwc_forward", [c_p, c_p, c_p, c_p, c_p]), ("udet_forward", [c_p, c_p, c_p, c_i, c_p, c_p]),
                ("udet_forward_from_flow", [c_p, c_i, c_p, c_p]), ("udet_generator_forward", [c_p, c_p, c_p]),
                ("udet_recover_forward", [c_p, c_i, c_p, c_p]),
+               ("udet_prefetch_flow", [c_p, c_p, c_p, c_p, c_p]), ("udet_forward_prefetched", [c_p, c_i, c_p, c_p]),
                ("udet_backward", [c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
                ("udet_apply", [c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
                ("udet_train_step", [c_p, c_i] + [c_p] * 12)):
@@ -139,6 +140,16 @@ class Engine:
 
     def forward(self, img1, img2, ncalls=3):
         check(lib.udet_forward(self._h, _ptr(img1), _ptr(img2), ncalls, self.ws.data_ptr(), self._stream()))
+
+    def prefetch_flow(self, img1, img2):
+        """PWC flow + resizes of the NEXT step's pair on the plan's side streams (PWC-Net is frozen); overlaps whatever
+        is enqueued next.  Keep img1/img2 alive until forward_prefetched()."""
+        self._prefetch_keep = (img1, img2)
+        check(lib.udet_prefetch_flow(self._h, _ptr(img1), _ptr(img2), self.ws.data_ptr(), self._stream()))
+
+    def forward_prefetched(self, ncalls=3):
+        check(lib.udet_forward_prefetched(self._h, ncalls, self.ws.data_ptr(), self._stream()))
+        self._prefetch_keep = None
 
     def forward_from_flow(self, image, flow, ncalls=3):
         self.buffer("image").copy_(image)

@@ -43,14 +43,27 @@ def allreduce_mean_(t: torch.Tensor, group=None, async_op=False):
     return work if async_op else None
 
 
-def train_step(st: TrainState, img1, img2, which: int = BOTH, group=None):
+def train_step(st: TrainState, img1, img2, which: int = BOTH, group=None, next_pair=None):
     """One adversarial step on this rank's frame pairs: PWC flow + generator fwd + 3x recover fwd + the
     backward pass(es) of `which` + gradient all-reduce + clipped Adam.
     which=REC / GEN reproduce train_recover_op / train_generator_op (adversarial_learner.py:224-234);
-    which=BOTH computes both gradients from one forward (the benchmark's "both backward" step)."""
+    which=BOTH computes both gradients from one forward (the benchmark's "both backward" step).
+    next_pair=(img1', img2'): cross-step pipelining -- the frozen PWC-Net's flow of the NEXT pair is enqueued on side
+    streams right after this step's forward and overlaps its backward; the next call (which must be given that same
+    pair) then starts from the prefetched flow.  Every step still does all of its work, one step earlier for PWC."""
     e = st.engine
     e.pack_trainable(st.w_gen if which & GEN else None, st.w_rec if which & REC else None)
-    e.forward(img1, img2, 3)
+    if getattr(st, "_prefetched", None) is not None:
+        p1, p2 = st._prefetched
+        if p1.data_ptr() != img1.data_ptr() or p2.data_ptr() != img2.data_ptr():
+            raise ValueError("train_step: this step's pair is not the one prefetched by the previous call")
+        e.forward_prefetched(3)
+        st._prefetched = None
+    else:
+        e.forward(img1, img2, 3)
+    if next_pair is not None:
+        e.prefetch_flow(next_pair[0], next_pair[1])
+        st._prefetched = (next_pair[0], next_pair[1])
     # one call: with BOTH the two backward passes run concurrently on the plan's side streams (udet_backward)
     e.backward(which, st.w_gen, st.w_rec, st.g_gen, st.g_rec)
     works = []
