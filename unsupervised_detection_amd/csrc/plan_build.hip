@@ -464,8 +464,21 @@ Plan* plan_build(const Config& cfg) {
   }
   P->arena_floats = off;
   if (const char* e = getenv("UDET_SERIAL")) P->concurrent = atoi(e) == 0;
-  for (auto& st : P->side)
-    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { st = nullptr; P->concurrent = false; }
+  // Side streams.  Lanes that carry background work (filter gradients: 2,3; next-step PWC prefetch: 4,5) get the
+  // lowest priority so that the dependent chains on lanes 0/1 keep first call on freed CUs (UDET_PRIO=0: all equal).
+  {
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    const int mode = getenv("UDET_PRIO") ? atoi(getenv("UDET_PRIO")) : 1;
+    for (int i = 0; i < Plan::NLANE - 1; ++i) {
+      const int lane = i + 1;
+      int prio = 0;
+      if (mode == 1 && lane >= 4) prio = least;
+      if (mode == 2 && lane >= 2) prio = least;
+      if (mode == 3) prio = lane >= 4 ? least : (lane == 1 ? greatest : 0);
+      if (hipStreamCreateWithPriority(&P->side[i], hipStreamNonBlocking, prio) != hipSuccess) { P->side[i] = nullptr; P->concurrent = false; }
+    }
+  }
   // views into the small region (read by the host wrapper)
   struct { const char* n; int a, d; size_t o; } views[4] = {{"losses", 1, 8, 0}, {"loss_coef", B, 4, 16}, {"noise_flag", 1, 2, 256},
                                                             {"loss_sums", B, 5, 1024}};

@@ -58,6 +58,12 @@ struct Lane {
 };
 static Lane lane_of(Plan* P, hipStream_t main, int i) {
   if (i == 0 || !P->concurrent || P->profiling) return Lane{main, 0};
+  // UDET_LANES bit mask of enabled side lanes (default all): a disabled lane falls back onto its parent chain
+  static const int mask = getenv("UDET_LANES") ? atoi(getenv("UDET_LANES")) : 0x3e;
+  if (!(mask & (1 << i))) {
+    const int parent = i == 5 ? 4 : (i == 3 ? 1 : 0);  // heads -> prefetch chain, gen wgrad -> gen chain, else caller
+    return lane_of(P, main, parent);
+  }
   return Lane{P->side[i - 1], i};
 }
 static hipEvent_t next_event(Plan* P) {
