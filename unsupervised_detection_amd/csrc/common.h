@@ -116,6 +116,14 @@ struct ConvParams {
 
 int launch_conv(ConvParams& p, hipStream_t stream);
 
+// One job of the table-driven weight re-layout (see pack_jobs_kernel in conv_host.hip): offsets are in floats,
+// src/gamma/beta/bias relative to the network's flat TF-order weight buffer, dst relative to the workspace.
+struct PackJob {
+  long src_off, dst_off, gamma_off, beta_off;  // gamma_off < 0: no BN fold
+  long total;
+  int T, R, C, Kc, ldw, k_split, k_gap, mode;  // mode 0 forward, 1 transposed, 2 bias (dst[c] = b*gamma*c + beta | b)
+};
+
 // --------------------------------------------------------------- wgrad ----
 // dW[t][ci][co] = sum_q X(q@t)[ci] * (dY[q][co] * act'(ya[q][co]))
 struct WgradParams {

@@ -131,6 +131,42 @@ int launch_pack_weights(const float* src, float* dst, int T, int R, int C, int K
   return UDET_OK;
 }
 
+// All re-layout jobs of one network in ONE launch (blockIdx.y = job): the per-step repack of the trainable weights
+// was ~140 launches of ~3 us.  BN (inference, moving stats 0/1) is folded on the fly: scale = gamma*c,
+// bias' = b*gamma*c + beta.
+__global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restrict__ jobs, const float* __restrict__ wsrc,
+                                                        float* __restrict__ ws, float bn_c) {
+  const PackJob j = jobs[blockIdx.y];
+  const float* src = wsrc + j.src_off;
+  float* dst = ws + j.dst_off;
+  const float* gamma = j.gamma_off >= 0 ? wsrc + j.gamma_off : nullptr;
+  if (j.mode == 2) {
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < j.total; e += (long)gridDim.x * 256)
+      dst[e] = gamma ? src[e] * (gamma[e] * bn_c) + wsrc[j.beta_off + e] : src[e];
+    return;
+  }
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < j.total; e += (long)gridDim.x * 256) {
+    const int n = (int)(e % j.ldw);
+    const int k = (int)((e / j.ldw) % j.Kc);
+    const int t = (int)(e / ((long)j.ldw * j.Kc));
+    float v = 0.f;
+    int ks = k;  // source index of packed row k (-1 inside the zero gap)
+    if (k >= j.k_split) ks = (k < j.k_split + j.k_gap) ? -1 : k - j.k_gap;
+    const int r = j.mode == 0 ? ks : n, c = j.mode == 0 ? n : ks;
+    if (r >= 0 && r < j.R && c >= 0 && c < j.C) {
+      v = src[((long)t * j.R + r) * j.C + c];
+      if (gamma) v *= gamma[c] * bn_c;
+    }
+    dst[e] = v;
+  }
+}
+int launch_pack_jobs(const PackJob* jobs_dev, int njobs, const float* wsrc, float* ws, float bn_c, hipStream_t stream) {
+  if (njobs < 1) return UDET_OK;
+  hipLaunchKernelGGL(pack_jobs_kernel, dim3(48, njobs), dim3(256), 0, stream, jobs_dev, wsrc, ws, bn_c);
+  UDET_HIP(hipGetLastError());
+  return UDET_OK;
+}
+
 // BN (inference, moving stats 0/1) folded into the conv:  scale = gamma*c, bias' = b*gamma*c + beta
 __global__ void fold_bn_kernel(const float* __restrict__ b, const float* __restrict__ gamma, const float* __restrict__ beta,
                                float c, float* __restrict__ scale, float* __restrict__ bias_f, int n) {

@@ -83,6 +83,8 @@ struct Plan {
   ~Plan();
   size_t small_off = 0;          // losses, coefficients, flags, reduction partials
   size_t seg_off[3] = {0, 0, 0}; // per-variable (offset,len) tables on device (as long)
+  size_t jobs_off[3] = {0, 0, 0}; // PackJob tables on device
+  int njobs[3] = {0, 0, 0};
   // optional per-category timing with HIP events on the launch stream (bench.py roofline)
   struct ProfRec { int cat; double flops, bytes; hipEvent_t a, b; std::string name; };
   bool profiling = false;

@@ -462,6 +462,11 @@ Plan* plan_build(const Config& cfg) {
     P->seg_off[net] = off;
     off = align64(off + 4 * net_params(net).p.size() + 64);  // two long tables (offset, len) = 4 floats per entry
   }
+  for (int net = 1; net <= 2; ++net) {  // PackJob tables: <= 3 jobs per layer
+    const size_t nl = net == NET_GEN ? P->gen.size() : P->rec.size();
+    P->jobs_off[net] = off;
+    off = align64(off + 3 * nl * (sizeof(PackJob) / sizeof(float)) + 64);
+  }
   P->arena_floats = off;
   if (const char* e = getenv("UDET_SERIAL")) P->concurrent = atoi(e) == 0;
   // Side streams.  Lanes that carry background work (filter gradients: 2,3; next-step PWC prefetch: 4,5) get the
@@ -469,7 +474,7 @@ Plan* plan_build(const Config& cfg) {
   {
     int least = 0, greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-    const int mode = getenv("UDET_PRIO") ? atoi(getenv("UDET_PRIO")) : 1;
+    const int mode = getenv("UDET_PRIO") ? atoi(getenv("UDET_PRIO")) : 0;  // measured: any priority split costs 4-5 ms/step
     for (int i = 0; i < Plan::NLANE - 1; ++i) {
       const int lane = i + 1;
       int prio = 0;

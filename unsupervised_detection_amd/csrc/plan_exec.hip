@@ -195,6 +195,34 @@ int plan_init_workspace(Plan* P, float* ws, hipStream_t s) {
     UDET_HIP(hipMemcpyAsync(ws + P->seg_off[net], tab.data(), tab.size() * sizeof(long), hipMemcpyHostToDevice, s));
     UDET_HIP(hipStreamSynchronize(s));  // `tab` is a host temporary
   }
+  // weight re-layout job tables of the trainable networks (one launch per network and step)
+  for (int net = 1; net <= 2; ++net) {
+    const NetParams& np = net_params(net);
+    const std::vector<Layer>& layers = net == NET_GEN ? P->gen : P->rec;
+    std::vector<PackJob> jobs;
+    for (const auto& L : layers) {
+      const int T = L.kh * L.kw;
+      const long goff = L.g_idx >= 0 ? (long)np.p[L.g_idx].offset : -1, beoff = L.be_idx >= 0 ? (long)np.p[L.be_idx].offset : -1;
+      PackJob j;
+      memset(&j, 0, sizeof(j));
+      j.src_off = (long)np.p[L.w_idx].offset; j.gamma_off = goff; j.beta_off = beoff;
+      j.T = T;
+      // forward operand (conv2d_transpose layers store [t][cout][cin] and never occur in the trainable nets)
+      j.dst_off = (long)L.wp_off; j.R = L.cin; j.C = L.cout; j.Kc = L.Kc; j.ldw = L.ldw; j.k_split = L.k_split; j.k_gap = L.k_gap;
+      j.mode = 0; j.total = (long)T * L.Kc * L.ldw;
+      jobs.push_back(j);
+      // transposed operand of the backward-data pass
+      j.dst_off = (long)L.wpT_off; j.Kc = L.KcT; j.ldw = L.ldwT; j.k_split = L.KcT; j.k_gap = 0;
+      j.mode = 1; j.total = (long)T * L.KcT * L.ldwT;
+      jobs.push_back(j);
+      // bias (BN-folded for the generator)
+      j.src_off = (long)np.p[L.b_idx].offset; j.dst_off = (long)L.bias_f_off; j.mode = 2; j.total = L.cout;
+      jobs.push_back(j);
+    }
+    P->njobs[net] = (int)jobs.size();
+    UDET_HIP(hipMemcpyAsync(ws + P->jobs_off[net], jobs.data(), jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice, s));
+    UDET_HIP(hipStreamSynchronize(s));  // `jobs` is a host temporary
+  }
   P->pwc_packed = false;
   return UDET_OK;
 }
@@ -223,21 +251,10 @@ int plan_pack_pwc(Plan* P, const float* w, float* ws, hipStream_t s) {
 }
 
 int plan_pack_trainable(Plan* P, const float* w_gen, const float* w_rec, float* ws, hipStream_t s) {
-  if (w_gen) {
-    const NetParams& np = net_params(NET_GEN);
-    for (const auto& L : P->gen) {
-      UDET_TRY(launch_fold_bn(w_gen + np.p[L.b_idx].offset, w_gen + np.p[L.g_idx].offset, w_gen + np.p[L.be_idx].offset, BN_C,
-                              ws + L.scale_off, ws + L.bias_f_off, L.cout, s));
-      UDET_TRY(pack_layer(L, w_gen, ws, ws + L.scale_off, true, s));
-    }
-  }
-  if (w_rec) {
-    const NetParams& np = net_params(NET_REC);
-    for (const auto& L : P->rec) {
-      UDET_TRY(pack_layer(L, w_rec, ws, nullptr, true, s));
-      UDET_TRY(launch_copy_channels(w_rec + np.p[L.b_idx].offset, L.cout, 0, ws + L.bias_f_off, L.cout, 0, 1, L.cout, 1.f, 0.f, s));
-    }
-  }
+  if (w_gen)
+    UDET_TRY(launch_pack_jobs(reinterpret_cast<const PackJob*>(ws + P->jobs_off[NET_GEN]), P->njobs[NET_GEN], w_gen, ws, BN_C, s));
+  if (w_rec)
+    UDET_TRY(launch_pack_jobs(reinterpret_cast<const PackJob*>(ws + P->jobs_off[NET_REC]), P->njobs[NET_REC], w_rec, ws, BN_C, s));
   return UDET_OK;
 }
 
