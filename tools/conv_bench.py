@@ -39,7 +39,7 @@ SHAPES = [
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--cfg", action="append", default=[], help="bm,bn,ks forced configuration (repeatable; bm+65536 selects the non-specialised 256-thread kernel); "
+    ap.add_argument("--cfg", action="append", default=[], help="bm,bn,ks forced configuration (repeatable; bm+65536 selects the non-specialised 256-thread kernel, bm+131072 the LDS-DMA kernel); "
                     "the default heuristics always run")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default="")
@@ -55,6 +55,7 @@ def main():
         us = 2 if up else 1
         gflop = 2.0 * n * (h * us // s) * (w * us // s) * cout * cin * k * k * 1e-9
         line = f"{name:16s} {gflop:7.2f} GF |"
+        y_ref = None
         for cfg in cfgs:
             if cfg is None:
                 lib.udet_debug_force_conv(0, 0, -1)
@@ -71,8 +72,12 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 us_ = e0.elapsed_time(e1) * 1e3 / args.reps
-                tag = "auto" if cfg is None else "x".join(map(str, (cfg[0] & 0xffff,) + cfg[1:])) + ("n" if cfg[0] >> 16 else "")
-                line += f" {tag:>11s}: {us_:7.1f}us {gflop / us_ * 1e3:6.1f}TF |"
+                y = ops.conv2d(x, wt, b, s, d, "leaky", 0.1, up)
+                if y_ref is None:
+                    y_ref = y
+                err = float((y - y_ref).abs().max())
+                tag = "auto" if cfg is None else "x".join(map(str, (cfg[0] & 0xffff,) + cfg[1:])) + ("n" if (cfg[0] >> 16) & 1 else "") + ("d" if (cfg[0] >> 17) & 1 else "")
+                line += f" {tag:>11s}: {us_:7.1f}us {gflop / us_ * 1e3:6.1f}TF" + (f" ERR={err:.1e}" if err > 1e-4 else "") + " |"
             except Exception as ex:  # unsupported forced tile
                 line += f" {'x'.join(map(str, cfg))}: n/a |"
         print(line, flush=True)

@@ -75,7 +75,7 @@ size_t udet_conv2d_workspace_bytes(int n, int h, int w, int cin, int cout, int k
   b += 2 * gran(pix_out * round_up(cout, 8));                    // channel-padded dy / y_saved
   b += gran(SPLITK_FLOATS);                                      // split-K partials
   b += gran(64 * wgrad_partial_floats_needed(kh * kw, cin, cout));
-  return b + 4096;
+  return b + 8192;
 }
 
 int udet_conv2d(const float* x, const float* w_hwio, const float* bias, float* y, int n, int h, int w, int cin, int cout,
@@ -100,7 +100,9 @@ int udet_conv2d(const float* x, const float* w_hwio, const float* bias, float* y
     ldx = kc;
   }
   float* part = ar.take(SPLITK_FLOATS);
-  if (!wp || !part) { set_error("conv2d: workspace too small"); return UDET_ERR_ARG; }
+  float* zero = ar.take(64);
+  if (!wp || !part || !zero) { set_error("conv2d: workspace too small"); return UDET_ERR_ARG; }
+  UDET_HIP(hipMemsetAsync(zero, 0, 64 * sizeof(float), stream));
   UDET_TRY(launch_pack_weights(w_hwio, wp, kh * kw, cin, cout, kc, ldw, kc, 0, 0, nullptr, stream));
   ConvParams p;
   memset(&p, 0, sizeof(p));
@@ -111,6 +113,7 @@ int udet_conv2d(const float* x, const float* w_hwio, const float* bias, float* y
   p.y = y; p.ldy = cout; p.y_coff = 0; p.Cout = cout;
   p.act = act; p.alpha = alpha;
   p.partial = part; p.partial_cap = SPLITK_FLOATS;
+  p.zero16 = zero;
   return launch_conv(p, stream);
 }
 

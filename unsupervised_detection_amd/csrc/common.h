@@ -98,6 +98,7 @@ struct ConvParams {
   int ncls;
   int cls_tap[5];
   FastDiv fd_ohw, fd_ow;  // filled by launch_conv
+  const float* zero16;    // >= 16 bytes of zeros in device memory (source of halo / tail lanes of the LDS-DMA kernel); may be null
   int dbg;                // ablation switches for tuning runs (env UDET_DBG; results are wrong when set)
   // epilogue
   int act;

@@ -309,6 +309,242 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 2) void conv_igemm_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// LDS-DMA variant (forward convolutions and backward-data of linear layers: no act' on the A operand).
+// The staging waves issue `global_load_lds_dwordx4` (16 B per lane straight into LDS, no VGPR round trip, no
+// ds_write pass); halo / K-tail lanes read a 16-byte zero block instead of branching.  DMA writes LDS lane-linearly,
+// so the A stage is row-major [BM][32] (one 128-byte line per pixel) with the 16-byte slot index XOR-swizzled by
+// (row>>1)&7 on the SOURCE side; the MFMA waves read their fragment as ONE ds_read_b128 per 32 rows per 4 k-pairs
+// (conflict-free under the swizzle) and walk K in the permuted order {4g+e : g = 2*kk+half}, which the B fragment
+// reads ([k][n] rows, ds_read_b32) follow.  Same flat-K / parity-class / split-K semantics as conv_igemm_kernel.
+// ---------------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(512, 4) void conv_igemm_dma_kernel(const ConvParams p) {
+  static_assert(WAVES_M * WAVES_N == 4, "4 MFMA waves");
+  constexpr int BK = 32;
+  constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  static_assert(TM * 32 == WTM && TN * 32 == WTN && BM % 32 == 0, "tile");
+  constexpr int A_LD = BM / 32;               // 256 staging threads cover 32 rows x 8 slots per pass
+  constexpr int B_F4_ROW = BN / 4;
+  constexpr int B_LD = BK * B_F4_ROW / 256;
+  static_assert(B_LD * 256 == BK * B_F4_ROW, "BK*BN/4 must be a multiple of 256");
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+
+  __shared__ __attribute__((aligned(16))) float As[2][BM][BK];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
+  __shared__ int rowoff[BM];
+  __shared__ int2 tap_yx[UDET_MAX_TAPS];
+  __shared__ int tap_w[UDET_MAX_TAPS];
+
+  const int tid = threadIdx.x;
+  const int role = __builtin_amdgcn_readfirstlane(tid >> 8);  // 0 = MFMA waves, 1 = staging waves
+  const int t = tid & 255;
+  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int li = lane & 31, lh = lane >> 5;
+
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int OHWq = p.OHq * p.OWq;
+  const int Mtot = p.N * OHWq;
+  const int mtiles = (Mtot + BM - 1) / BM;
+  const int cls = bid / mtiles;
+  const int m0 = (bid - cls * mtiles) * BM;
+  const int n0 = blockIdx.y * BN;
+  const int tap0 = p.cls_tap[cls];
+  const int ntc = p.cls_tap[cls + 1] - tap0;
+  const int ooy = p.ncls > 1 ? (cls >> 1) : p.ooy, oox = p.ncls > 1 ? (cls & 1) : p.oox;
+  const int Hs = p.H >> p.up_shift, Ws = p.W >> p.up_shift;
+
+  for (int i = tid; i < ntc; i += 512) {
+    tap_yx[i] = make_int2(p.taps[tap0 + i].dy, p.taps[tap0 + i].dx);
+    tap_w[i] = p.taps[tap0 + i].widx;
+  }
+  for (int r = tid; r < BM; r += 512) {
+    const int m = m0 + r;
+    int off = -1;
+    if (m < Mtot) {
+      const int n = (int)fdiv(m, p.fd_ohw), rem = m - n * OHWq;
+      const int qy = (int)fdiv(rem, p.fd_ow), qx = rem - qy * p.OWq;
+      off = p.ksplit > 1 ? cls * Mtot + m : (n * p.OH + qy * p.osy + ooy) * p.OW + qx * p.osx + oox;
+    }
+    rowoff[r] = off;
+  }
+  const int Kc = p.Kc;
+  const int nchunks = (ntc * Kc + BK - 1) / BK;
+  int c_begin = 0, c_end = nchunks;
+  if (p.ksplit > 1) {
+    c_begin = (int)((long)nchunks * blockIdx.z / p.ksplit);
+    c_end = (int)((long)nchunks * (blockIdx.z + 1) / p.ksplit);
+  }
+  __syncthreads();
+
+  if (role == 1) {
+    // ------------------------------------------------ staging waves ------------------------------------------------
+    const int kq = lane & 7;                                  // LDS slot written by this lane (lane-linear)
+    const int kqs = kq ^ ((wave * 4 + (lane >> 4)) & 7);      // channel group it holds: slot ^ ((row>>1)&7)
+    int a_base[A_LD], a_iy0[A_LD], a_ix0[A_LD];
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) {
+      const int m = m0 + j * 32 + wave * 8 + (lane >> 3);
+      if (m < Mtot) {
+        const int n = (int)fdiv(m, p.fd_ohw), rem = m - n * OHWq;
+        const int qy = (int)fdiv(rem, p.fd_ow), qx = rem - qy * p.OWq;
+        a_base[j] = n * Hs * Ws;
+        a_iy0[j] = qy * p.isy;
+        a_ix0[j] = qx * p.isx;
+      } else {
+        a_base[j] = 0;
+        a_iy0[j] = -(1 << 28);
+        a_ix0[j] = 0;
+      }
+    }
+    int a_tap, a_c, b_tap[B_LD], b_c[B_LD];
+    {
+      const int kf = c_begin * BK + kqs * 4;
+      a_tap = kf / Kc;
+      a_c = kf - a_tap * Kc;
+#pragma unroll
+      for (int j = 0; j < B_LD; ++j) {
+        const int kb = c_begin * BK + (t + j * 256) / B_F4_ROW;
+        b_tap[j] = kb / Kc;
+        b_c[j] = kb - b_tap[j] * Kc;
+      }
+    }
+    const float* zero = p.zero16;
+    auto issue = [&](int buf) {
+      int dy = 0, dx = 0;
+      const bool a_ok = a_tap < ntc;
+      if (a_ok) {
+        const int2 yx = tap_yx[a_tap];
+        dy = yx.x;
+        dx = yx.y;
+      }
+#pragma unroll
+      for (int j = 0; j < A_LD; ++j) {
+        int iy = a_iy0[j] + dy, ix = a_ix0[j] + dx;
+        const bool ok = a_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        iy >>= p.up_shift;
+        ix >>= p.up_shift;
+        const float* src = ok ? p.x + ((size_t)(a_base[j] + iy * Ws + ix) * p.ldx + p.x_coff + a_c) : zero;
+        __builtin_amdgcn_global_load_lds(src, (lds_ptr)&As[buf][j * 32 + wave * 8][0], 16, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < B_LD; ++j) {
+        const int c4 = (t + j * 256) % B_F4_ROW;
+        const int n = n0 + c4 * 4;
+        const bool ok = b_tap[j] < ntc && n < p.ldw;
+        const int wi = ok ? tap_w[b_tap[j]] : 0;
+        const float* src = ok ? p.wp + (((size_t)wi * Kc + b_c[j]) * p.ldw + n) : zero;
+        __builtin_amdgcn_global_load_lds(src, (lds_ptr)(&Bs[buf][0][0] + (j * 256 + wave * 64) * 4), 16, 0, 0);
+      }
+      a_c += BK;
+      while (a_c >= Kc) { a_c -= Kc; ++a_tap; }
+#pragma unroll
+      for (int j = 0; j < B_LD; ++j) {
+        b_c[j] += BK;
+        while (b_c[j] >= Kc) { b_c[j] -= Kc; ++b_tap[j]; }
+      }
+    };
+    auto landed = [&]() {  // all DMA of this wave has been written to LDS, then meet the MFMA waves
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    };
+    if (c_begin < c_end) issue(0);
+    landed();
+    int buf = 0;
+    for (int c = c_begin; c < c_end; ++c) {
+      if (c + 1 < c_end) issue(buf ^ 1);  // stage c+1 lands while the MFMA waves work on stage c
+      landed();
+      buf ^= 1;
+    }
+    return;
+  }
+
+  // -------------------------------------------------- MFMA waves --------------------------------------------------
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int swz = (li >> 1) & 7;  // (row>>1)&7 of every row this lane reads (wave / sub-tile offsets are multiples of 16)
+  auto handover = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  auto compute_chunk = [&](int buf) {
+    float4 a[2][TM];
+    float b[2][4][TN];
+    auto frag = [&](int s, int kk) {
+      const int g = 2 * kk + lh;  // channel group of this lane half
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[s][i] = *reinterpret_cast<const float4*>(&As[buf][wm * WTM + i * 32 + li][(g ^ swz) * 4]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[s][e][j] = Bs[buf][g * 4 + e][wn * WTN + j * 32 + li];
+    };
+    frag(0, 0);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      if (kk + 1 < 4) frag((kk + 1) & 1, kk + 1);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const float av = e == 0 ? a[kk & 1][i].x : (e == 1 ? a[kk & 1][i].y : (e == 2 ? a[kk & 1][i].z : a[kk & 1][i].w));
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[kk & 1][e][j], acc[i][j], 0, 0, 0);
+        }
+      }
+      if (kk + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, TM + 4 * TN, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);
+    }
+  };
+  handover();
+  {
+    int buf = 0;
+    for (int c = c_begin; c < c_end; ++c) {
+      compute_chunk(buf);
+      handover();
+      buf ^= 1;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int off = rowoff[row];
+      if (off < 0) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WTN + j * 32 + li;
+        float v = acc[i][j][r];
+        if (p.ksplit > 1) {
+          if (n < p.ldp) p.partial[((size_t)blockIdx.z * p.ncls * Mtot + off) * p.ldp + n] = v;
+          continue;
+        }
+        if (n >= p.Cout) continue;
+        if (p.bias) v += p.bias[n];
+        v = act_fwd(v, p.act, p.alpha);
+        if (p.y2) p.y2[(size_t)off * p.ldy2 + p.y2_coff + n] = v;
+        if (p.res) v += p.res[(size_t)off * p.ldres + p.res_coff + n];
+        float* dst = p.y + (size_t)off * p.ldy + p.y_coff + n;
+        if (p.accumulate) v += *dst;
+        *dst = v;
+      }
+    }
+  }
+}
+
 // second pass of a split-K launch: sum the partial slabs and run the epilogue.  SL lanes share one output element
 // (each sums every SL-th slab, then a fixed-order shuffle tree): small outputs with many splits stay parallel.
 template <int SL>
@@ -343,14 +579,15 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const ConvPar
 static int g_force_bm = 0, g_force_bn = 0, g_force_ks = -1, g_force_ws = -1;
 void conv_force_config(int bm, int bn, int ks) {
   g_force_bm = bm & 0xffff; g_force_bn = bn; g_force_ks = ks;
-  g_force_ws = (bm >> 16) & 1 ? 0 : -1;  // bit 16 of bm: use the 256-thread non-specialised kernel
+  g_force_ws = (bm >> 16) & 1 ? 0 : ((bm >> 17) & 1 ? 2 : -1);  // bit 16 of bm: non-specialised kernel; bit 17: LDS-DMA kernel
 }
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
 static int launch_cfg(const ConvParams& p, int ws, hipStream_t stream) {
   const int Mtot = p.N * p.OHq * p.OWq;
   dim3 grid(p.ncls * ((Mtot + BM - 1) / BM), (p.Cout + BN - 1) / BN, p.ksplit > 1 ? p.ksplit : 1);
-  if (ws) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, true>), grid, dim3(512), 0, stream, p);
+  if (ws == 2) hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WAVES_M, WAVES_N>), grid, dim3(512), 0, stream, p);
+  else if (ws) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, true>), grid, dim3(512), 0, stream, p);
   else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, false>), grid, dim3(256), 0, stream, p);
   UDET_HIP(hipGetLastError());
   if (p.ksplit > 1) {
@@ -386,6 +623,7 @@ static int max_ksplit(const ConvParams& p) {  // capacity / minimum-work bound o
   while (ks > 1 && per_split * ks > p.partial_cap) --ks;
   return ks < 1 ? 1 : ks;
 }
+static bool dma_ok(const ConvParams& p) { return p.xa == nullptr && p.zero16 != nullptr && !(reinterpret_cast<uintptr_t>(p.zero16) & 15); }
 static ConvCfg heuristic_cfg(const ConvParams& p) {
   // N tile from the channel count; M tile shrunk while the launch would leave CUs without a workgroup
   ConvCfg c;
@@ -473,8 +711,20 @@ static ConvCfg tune_cfg(ConvParams& p, hipStream_t stream) {
   }
   ConvCfg alt = best;
   alt.ws = 0;
-  const float a = time_cfg(p, best, 5, stream), b = time_cfg(p, alt, 5, stream);
-  if (b < a * 0.97f) best = alt;
+  float a = time_cfg(p, best, 5, stream), b = time_cfg(p, alt, 5, stream);
+  if (b < a * 0.97f) { best = alt; a = b; }
+  if (dma_ok(p)) {  // LDS-DMA staging: re-scan the tiles, the balance between staging and MFMA waves differs
+    for (auto& c : cand) {
+      ConvCfg d = c;
+      d.ws = 2;
+      const float ms = time_cfg(p, d, 3, stream);
+      if (ms < a * 0.98f) {
+        const float ms5 = time_cfg(p, d, 5, stream);
+        if (ms5 < a * 0.98f) { a = ms5; best = d; }
+      }
+    }
+    b = a;
+  }
   if (getenv("UDET_TUNE_LOG"))
     fprintf(stderr, "[udet tune] N=%d %dx%d Kc=%d taps=%d cls=%d Cout=%d -> %dx%d ks=%d ws=%d  %.1f us (heuristic %dx%d ks=%d)\n", p.N,
             p.OHq, p.OWq, p.Kc, p.ntaps, p.ncls, p.Cout, best.bm, best.bn, best.ks, best.ws, (a < b ? a : b) * 1e3f, h.bm, h.bn, h.ks);
@@ -525,6 +775,7 @@ int launch_conv(ConvParams& p, hipStream_t stream) {
   if (g_force_bm) { c.bm = g_force_bm; c.bn = g_force_bn; }
   if (g_force_ks >= 0) c.ks = g_force_ks > max_ksplit(p) ? max_ksplit(p) : g_force_ks;
   if (g_force_ws >= 0) c.ws = g_force_ws;
+  if (c.ws == 2 && !dma_ok(p)) c.ws = 1;
   return run_cfg(p, c, stream);
 }
 

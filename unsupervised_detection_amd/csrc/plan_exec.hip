@@ -88,6 +88,7 @@ static void order_after(Plan* P, const Lane& from, const Lane& to) {
 static void fill_common(Plan* P, ConvParams& p, float* ws, int slot) {
   p.partial = ws + P->scratch_off[slot];
   p.partial_cap = P->scratch_floats;
+  p.zero16 = ws + P->small_off + 60000;  // never written after udet_plan_init's memset
 }
 
 static int run_fwd(Plan* P, const Layer& L, int N, float* ws, const Lane& ln, size_t x_extra = 0, size_t y_extra = 0) {
