@@ -108,6 +108,12 @@ def main():
     img1 = data.preprocess_image(torch.from_numpy(f1).cuda())
     img2 = data.preprocess_image(torch.from_numpy(f2).cuda())
 
+    # every launch of the step goes to one explicitly created stream (not the legacy null stream, whose implicit
+    # synchronisation with blocking streams would serialise the plan's side streams on some runtimes)
+    torch.cuda.synchronize()
+    work_stream = torch.cuda.Stream()
+    torch.cuda.set_stream(work_stream)
+
     def barrier():
         if world > 1:
             dist.barrier()

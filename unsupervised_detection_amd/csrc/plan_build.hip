@@ -481,7 +481,8 @@ Plan* plan_build(const Config& cfg) {
       if (mode == 1 && lane >= 4) prio = least;
       if (mode == 2 && lane >= 2) prio = least;
       if (mode == 3) prio = lane >= 4 ? least : (lane == 1 ? greatest : 0);
-      if (hipStreamCreateWithPriority(&P->side[i], hipStreamNonBlocking, prio) != hipSuccess) { P->side[i] = nullptr; P->concurrent = false; }
+      const hipError_t rc = hipStreamCreateWithPriority(&P->side[i], hipStreamNonBlocking, prio);
+      if (rc != hipSuccess) { P->side[i] = nullptr; P->concurrent = false; }
     }
   }
   // views into the small region (read by the host wrapper)
