@@ -146,18 +146,54 @@ def main():
     if getattr(st, "_prefetched", None) is not None:  # drain the pipeline: the profiled step below is self-contained
         eng.forward_prefetched(3)
         st._prefetched = None
-    prof = eng.profile(lambda: train_step(st, img1, img2, BOTH)) if rank == 0 else None
+    # per-kernel timing with HIP events on the launch stream: ONE extra, untimed step executed serially (the plan collapses
+    # its side streams while profiling, so every launch group's duration is its stand-alone duration)
+    prof, layers = None, []
+    if rank == 0:
+        import csv
+        import tempfile
+        dump = os.path.join(tempfile.gettempdir(), "udet_layers_%d.csv" % os.getpid())
+        if os.path.exists(dump):
+            os.remove(dump)
+        os.environ["UDET_PROF_DUMP"] = dump
+        prof = eng.profile(lambda: train_step(st, img1, img2, BOTH))
+        os.environ.pop("UDET_PROF_DUMP", None)
+        if os.path.exists(dump):
+            with open(dump) as f:
+                layers = [(int(r[0]), r[1], float(r[2]), float(r[3])) for r in csv.reader(f)]
+            os.remove(dump)
 
     if rank == 0:
         conv_ms = sum(prof[c]["ms"] for c in ("conv_fwd", "conv_dgrad", "conv_wgrad"))
         conv_groups = sum(prof[c]["groups"] for c in ("conv_fwd", "conv_dgrad", "conv_wgrad"))
         alg_flops = ALG_GFLOP_PER_PAIR * 1e9 * args.batch
         achieved = alg_flops / (conv_ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": "conv_igemm_kernel / conv_wgrad_kernel (v_mfma_f32_32x32x2_f32), all launches of one step",
+        # the largest single launch of the step (dense estimator / context convolutions of PWC level 2)
+        top = max((l for l in layers if l[0] < 3), key=lambda l: l[3], default=None)
+        pmc = {}
+        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_dc_conv21.json")
+        if os.path.exists(pmc_path):
+            with open(pmc_path) as f:
+                pmc = json.load(f)
+        top_launch = None
+        if top is not None:
+            top_tf = top[3] / top[2] if top[2] > 0 else 0.0  # GFLOP / ms = TFLOP/s
+            top_launch = {"layer": top[1], "alg_gflop": round(top[3], 3), "ms": round(top[2], 4), "achieved": round(top_tf, 2),
+                          "frac": round(top_tf / PEAK_FP32_MFMA_TFLOPS, 4),
+                          "alg_bytes": pmc.get("algorithmic_bytes_total"), "traffic_bytes": pmc.get("traffic_bytes_per_launch"),
+                          "traffic_source": "profiles/r01_pmc_dc_conv21.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+                          if pmc else None}
+        roofline = {"bound": "mfma",
+                    "kernel": "conv_igemm_dma_kernel / conv_igemm_kernel / conv_wgrad_kernel (v_mfma_f32_32x32x2_f32): every "
+                              "convolution launch of one step, timed stand-alone (serial pass)",
                     "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                    "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
+                    "traffic": pmc.get("traffic_bytes_per_launch"),
+                    "traffic_scope": "HBM bytes of the largest launch (top_launch), PMC-derived; algorithmic bytes of that launch: "
+                                     "%s" % pmc.get("algorithmic_bytes_total") if pmc else None,
                     "launch_groups_per_step": int(conv_groups), "avg_group_ms": round(conv_ms / conv_groups, 4),
-                    "alg_gflop_per_step": round(alg_flops / 1e9, 2), "conv_ms_per_step": round(conv_ms, 3)}
+                    "alg_gflop_per_step": round(alg_flops / 1e9, 2), "conv_ms_per_step_serial": round(conv_ms, 3),
+                    "top_launch": top_launch}
         hbm = {}
         for c in ("warp", "cost_volume"):
             p = prof[c]
@@ -175,7 +211,10 @@ def main():
                        "alg_gflop_per_pair": ALG_GFLOP_PER_PAIR},
             "step_tflops_algorithmic": round(alg_flops * world / (ms * 1e-3) / 1e12, 2),
             "roofline": roofline, "hbm_kernels": hbm,
-            "profile_ms_per_step": {k: round(v["ms"], 3) for k, v in prof.items()},
+            "profile_ms_per_step_serial": {k: round(v["ms"], 3) for k, v in prof.items()},
+            "execution": {"autotuned_shapes": getattr(st, "tuned_shapes", 0), "pipelined": nxt is not None,
+                          "note": "step = forward(prefetched PWC flow) + PWC flow of the next pair beside both backward passes "
+                                  "+ 2 applies; every timed step contains all of that work exactly once"},
             "losses": {k: round(v, 5) for k, v in losses.items()},
         }
         if world == 1 and not args.no_cpu_baseline:
