@@ -108,6 +108,14 @@ struct ConvParams {
   float* y2;  // optional second output: activation before the residual add
   int ldy2, y2_coff;
   int accumulate;  // y += result
+  // backward-data launches may also emit dU = (final y) * act'(saved activation) for output channels [u_c0,u_c1): the
+  // operand the NEXT backward-data / backward-filter launches consume, so that they need no act' on load
+  float* uo;
+  int ldu, u_coff;
+  const float* ua;
+  int ldua, ua_coff, uact;
+  float ualpha;
+  int u_c0, u_c1;
   // split-K
   int ksplit;
   float* partial;  // [ksplit][Mtot][ldp]

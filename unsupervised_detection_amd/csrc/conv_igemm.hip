@@ -63,16 +63,16 @@ __device__ __forceinline__ KCursor kc_init(const KOrder& o, int kf) {
   return k;
 }
 __device__ __forceinline__ void kc_advance(const KOrder& o, KCursor& k, int step) {
-  if (k.w == step) {  // common case (32-channel block, 32-wide stage): same channels, next tap
+  if (k.w == step) {  // common case (32-channel block, 32-wide stage): same channel offset, next tap
     if (++k.tap == o.ntc) {
       k.tap = 0;
       ++k.blk;
       k.w = k.blk == o.nblk - 1 ? o.wl : o.CB;
     }
-    return;
+  } else {
+    k.c += step;
   }
-  k.c += step;
-  while (k.c >= k.w) {
+  while (k.c >= k.w) {  // (also re-normalises the offset after stepping into the narrower last block)
     k.c -= k.w;
     if (++k.tap == o.ntc) {
       k.tap = 0;
@@ -83,6 +83,19 @@ __device__ __forceinline__ void kc_advance(const KOrder& o, KCursor& k, int step
 }
 __device__ __forceinline__ bool kc_valid(const KOrder& o, const KCursor& k) { return k.blk < o.nblk; }
 __device__ __forceinline__ int kc_chan(const KOrder& o, const KCursor& k) { return k.blk * o.CB + k.c; }
+
+// bias, activation, second output, residual, accumulate, store (+ optional dU emission) of one output element
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, int off, int n, float v) {
+  if (p.bias) v += p.bias[n];
+  v = act_fwd(v, p.act, p.alpha);
+  if (p.y2) p.y2[(size_t)off * p.ldy2 + p.y2_coff + n] = v;
+  if (p.res) v += p.res[(size_t)off * p.ldres + p.res_coff + n];
+  float* dst = p.y + (size_t)off * p.ldy + p.y_coff + n;
+  if (p.accumulate) v += *dst;
+  *dst = v;
+  if (p.uo && n >= p.u_c0 && n < p.u_c1)
+    p.uo[(size_t)off * p.ldu + p.u_coff + n] = v * act_dfo(p.ua[(size_t)off * p.ldua + p.ua_coff + n], p.uact, p.ualpha);
+}
 
 // WS (wave specialisation): 512-thread workgroups; waves 0-3 only read fragments from LDS and issue MFMAs, waves
 // 4-7 only stage (global -> registers -> LDS) one stage ahead.  The matrix pipe of a SIMD is then fed by waves that
@@ -342,13 +355,7 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 2) void conv_igemm_kernel(
           continue;
         }
         if (n >= p.Cout) continue;
-        if (p.bias) v += p.bias[n];
-        v = act_fwd(v, p.act, p.alpha);
-        if (p.y2) p.y2[(size_t)off * p.ldy2 + p.y2_coff + n] = v;
-        if (p.res) v += p.res[(size_t)off * p.ldres + p.res_coff + n];
-        float* dst = p.y + (size_t)off * p.ldy + p.y_coff + n;
-        if (p.accumulate) v += *dst;
-        *dst = v;
+        conv_epilogue(p, off, n, v);
       }
     }
   }
@@ -567,13 +574,7 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_dma_kernel(const ConvParams
           continue;
         }
         if (n >= p.Cout) continue;
-        if (p.bias) v += p.bias[n];
-        v = act_fwd(v, p.act, p.alpha);
-        if (p.y2) p.y2[(size_t)off * p.ldy2 + p.y2_coff + n] = v;
-        if (p.res) v += p.res[(size_t)off * p.ldres + p.res_coff + n];
-        float* dst = p.y + (size_t)off * p.ldy + p.y_coff + n;
-        if (p.accumulate) v += *dst;
-        *dst = v;
+        conv_epilogue(p, off, n, v);
       }
     }
   }
@@ -600,13 +601,7 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const ConvPar
     const int nb = (int)fdiv(m, p.fd_ohw), rem = m - nb * OHWq;
     const int qy = (int)fdiv(rem, p.fd_ow), qx = rem - qy * p.OWq;
     const int off = (nb * p.OH + qy * p.osy + ooy) * p.OW + qx * p.osx + oox;
-    if (p.bias) v += p.bias[n];
-    v = act_fwd(v, p.act, p.alpha);
-    if (p.y2) p.y2[(size_t)off * p.ldy2 + p.y2_coff + n] = v;
-    if (p.res) v += p.res[(size_t)off * p.ldres + p.res_coff + n];
-    float* dst = p.y + (size_t)off * p.ldy + p.y_coff + n;
-    if (p.accumulate) v += *dst;
-    *dst = v;
+    conv_epilogue(p, off, n, v);
   }
 }
 
@@ -699,7 +694,7 @@ void conv_clear_tuning() { std::lock_guard<std::mutex> l(g_cache_mu); g_cache.cl
 
 static uint64_t conv_key(const ConvParams& p) {
   const int f[] = {p.N, p.H, p.W, p.up_shift, p.Kc, p.Cout, p.ntaps, p.ncls, p.OHq, p.OWq, p.isy, p.osy, p.xa ? 1 : 0,
-                   p.ldx, p.ldy, p.accumulate, p.res ? 1 : 0, p.y2 ? 1 : 0, p.partial ? 1 : 0, p.cls_tap[1]};
+                   p.ldx, p.ldy, p.accumulate, p.res ? 1 : 0, p.y2 ? 1 : 0, p.partial ? 1 : 0, p.cls_tap[1], p.uo ? 1 : 0};
   uint64_t h = 1469598103934665603ull;
   for (int v : f) { h ^= (uint64_t)(uint32_t)v; h *= 1099511628211ull; }
   return h;

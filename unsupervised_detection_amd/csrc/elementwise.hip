@@ -149,6 +149,24 @@ int launch_pool2x2_sum(const float* du, float* dx, int N, int H, int W, int C, h
   return UDET_OK;
 }
 
+// u[p][coff+c] = d[p][coff+c] * act'(a[p][coff+c]), c < C: dU of a region whose gradient was finalised by a
+// non-convolution kernel (resize adjoint, 2x2 pooling)
+__global__ __launch_bounds__(256) void emit_du_kernel(const float* __restrict__ d, const float* __restrict__ a,
+                                                      float* __restrict__ u, long P, int ld, int coff, int C, int act,
+                                                      float alpha) {
+  const long total = P * C;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long pix = e / C;
+    const long o = pix * ld + coff + (e - pix * C);
+    u[o] = d[o] * act_dfo(a[o], act, alpha);
+  }
+}
+int launch_emit_du(const float* d, const float* a, float* u, long P, int ld, int coff, int C, int act, float alpha, hipStream_t s) {
+  hipLaunchKernelGGL(emit_du_kernel, dim3(grid_for(P * C)), dim3(256), 0, s, d, a, u, P, ld, coff, C, act, alpha);
+  UDET_HIP(hipGetLastError());
+  return UDET_OK;
+}
+
 // ---------------------------------------------------------------------------
 // PWC input: x8[2B,H,W,8] = [img1+0.5 | img2+0.5 | 0..]   (model_pwcnet.py:39-56 adapt_x)
 // ---------------------------------------------------------------------------

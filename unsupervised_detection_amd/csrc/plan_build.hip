@@ -315,6 +315,7 @@ Plan* plan_build(const Config& cfg) {
       const int ldo = round_up(g.cout, 8);
       L.y = P->add_buf(S("gen.a%d", i + 1), B, h, w, ldo);
       P->add_buf(S("gen.d%d", i + 1), B, h, w, ldo);  // gradient w.r.t. this layer's (summed) output
+      P->add_buf(S("gen.u%d", i + 1), B, h, w, ldo);  // ... times act'(output): what the layer's own backward launches read
       if (i == 10 || i == 13 || i == 14) {          // conv11 + x2, conv14 + x1, conv15_upsample + x0 (nets.py:29,32,33)
         L.y2 = L.y;                                  // a_k keeps the pre-skip activation
         L.y = P->add_buf(S("gen.s%d", i + 1), B, h, w, ldo);
@@ -423,7 +424,11 @@ Plan* plan_build(const Config& cfg) {
     const size_t nb = P->bufs.size();
     for (size_t i = 0; i < nb; ++i) {
       const Buf b = P->bufs[i];
-      if (b.name.rfind("rec.d.", 0) == 0) P->add_buf("rec.e." + b.name.substr(6), b.n, b.h, b.w, b.ld);
+      if (b.name.rfind("rec.d.", 0) == 0) {
+        P->add_buf("rec.e." + b.name.substr(6), b.n, b.h, b.w, b.ld);
+        P->add_buf("rec.ud." + b.name.substr(6), b.n, b.h, b.w, b.ld);  // dU = gradient * act'(activation) mirrors
+        P->add_buf("rec.ue." + b.name.substr(6), b.n, b.h, b.w, b.ld);
+      }
       if (b.name == "d.pred") P->add_buf("e.pred", b.n, b.h, b.w, b.ld);
     }
   }

@@ -3,6 +3,7 @@
 // Reference being replaced: the single sess.run of models/adversarial_learner.py:396 over the graph
 // built by build_train_graph (:72-258) / build_test_graph (:450-523).
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "conv_host.h"
@@ -118,9 +119,17 @@ static int run_fwd(Plan* P, const Layer& L, int N, float* ws, const Lane& ln, si
   return UDET_OK;
 }
 
-// gradient w.r.t. the layer input: dX(dx buffer) (=|+=) conv_T(dY * act'(saved output)) [+ res]
-static int run_dgrad(Plan* P, const Layer& L, int N, int dy, int dx, int dx_coff, int accumulate, int res, float* ws,
-                     const Lane& ln) {
+// dU emission of a backward-data launch: output channels [c0,c1) of the result (relative to dx_coff) are also written,
+// multiplied by act'(activation `abuf`), into `ubuf` (same layout as the dx buffer)
+struct Emit {
+  int ubuf = -1, abuf = -1, c0 = 0, c1 = 0, act = ACT_NONE;
+  float alpha = 0.f;
+};
+
+// gradient w.r.t. the layer input: dX(dx buffer) (=|+=) conv_T(dU) [+ res].  dy_is_du: `dy` already holds
+// dU = dY * act'(saved output) (emitted by the launch that finalised dY); otherwise act' is applied on load.
+static int run_dgrad(Plan* P, const Layer& L, int N, int dy, bool dy_is_du, int dx, int dx_coff, int accumulate, int res,
+                     const Emit& em, float* ws, const Lane& ln) {
   hipStream_t s = ln.s;
   const int act_buf = L.y2 >= 0 ? L.y2 : L.y;
   const Buf &bdy = P->buf(dy), &bdx = P->buf(dx), &ba = P->buf(act_buf);
@@ -135,11 +144,17 @@ static int run_dgrad(Plan* P, const Layer& L, int N, int dy, int dx, int dx_coff
     memset(&p, 0, sizeof(p));
     if (!conv_setup_dgrad(p, cls, N, L.H << up, L.W << up, L.kh, L.kw, L.stride, L.dil)) continue;
     p.x = ws + bdy.off; p.ldx = bdy.ld; p.x_coff = L.y_coff;
-    if (L.act != ACT_NONE) { p.xa = ws + ba.off; p.xact = L.act; p.xalpha = L.alpha; }
+    if (L.act != ACT_NONE && !dy_is_du) { p.xa = ws + ba.off; p.xact = L.act; p.xalpha = L.alpha; }
     p.wp = ws + L.wpT_off; p.Kc = L.KcT; p.ldw = L.ldwT;
     p.y = ws + bdx.off; p.ldy = bdx.ld; p.y_coff = dx_coff; p.Cout = L.cin;
     p.accumulate = accumulate;
     if (res >= 0) { p.res = ws + P->buf(res).off; p.ldres = P->buf(res).ld; p.res_coff = 0; }
+    if (em.ubuf >= 0) {
+      const Buf &bu = P->buf(em.ubuf), &bua = P->buf(em.abuf);
+      p.uo = ws + bu.off; p.ldu = bu.ld; p.u_coff = dx_coff;
+      p.ua = ws + bua.off; p.ldua = bua.ld; p.ua_coff = dx_coff;
+      p.uact = em.act; p.ualpha = em.alpha; p.u_c0 = em.c0; p.u_c1 = em.c1;
+    }
     fill_common(P, p, ws, ln.slot);
     UDET_TRY(launch_conv(p, s));
   }
@@ -147,7 +162,7 @@ static int run_dgrad(Plan* P, const Layer& L, int N, int dy, int dx, int dx_coff
   return UDET_OK;
 }
 
-static int run_wgrad(Plan* P, const Layer& L, int N, int dy, const float* w_flat, float* g_flat, float* ws, const Lane& ln) {
+static int run_wgrad(Plan* P, const Layer& L, int N, int dy, bool dy_is_du, const float* w_flat, float* g_flat, float* ws, const Lane& ln) {
   hipStream_t s = ln.s;
   const NetParams& np = net_params(L.net);
   const int act_buf = L.y2 >= 0 ? L.y2 : L.y;
@@ -161,7 +176,7 @@ static int run_wgrad(Plan* P, const Layer& L, int N, int dy, const float* w_flat
   q.x = ws + bx.off; q.ldx = bx.ld; q.x_coff = L.x_coff;
   q.N = N; q.H = L.H << up; q.W = L.W << up; q.up_shift = up; q.Cin = L.cin;
   q.dy = ws + bdy.off; q.ldy = bdy.ld; q.y_coff = L.y_coff; q.Cout = L.cout;
-  if (L.act != ACT_NONE) { q.ya = ws + ba.off; q.yact = L.act; q.yalpha = L.alpha; }
+  if (L.act != ACT_NONE && !dy_is_du) { q.ya = ws + ba.off; q.yact = L.act; q.yalpha = L.alpha; }
   q.OH = g.OH; q.OW = g.OW; q.isy = q.isx = L.stride;
   q.ntaps = g.ntaps;
   memcpy(q.taps, g.taps, sizeof(g.taps));
@@ -461,21 +476,26 @@ int plan_forward(Plan* P, const float* img1, const float* img2, int ncalls, floa
 
 // ------------------------------------------------------------ backward ----
 // Recover decoder/encoder backward for the first N samples of the batched calls, seeded by <dp>pred.
-// `dp` is the gradient-buffer family ("d" recover-loss pass, "e" generator-loss pass).
+// `dp` is the gradient-buffer family ("d" recover-loss pass, "e" generator-loss pass); "rec.u<dp>.*" mirrors it with
+// dU = gradient * act'(activation), emitted by whichever launch writes a region last, so that the backward-data and
+// backward-filter launches of every activated layer read their operand without an act' on load.
 // with_wgrad: parameter gradients into g_rec, each on lane LW right where its output gradient is final.
 // need_dfin: propagate to the b-encoder input.
 static int rec_backward(Plan* P, int N, const char* dp, bool with_wgrad, bool need_dfin, const float* w_rec, float* g_rec, float* ws,
                         const Lane& LD, const Lane& LW) {
   const Config& c = P->cfg;
   hipStream_t s = LD.s;
-  const std::string pre = std::string("rec.") + dp + ".";
+  const std::string pre = std::string("rec.") + dp + ".", upre = std::string("rec.u") + dp + ".";
   auto B_ = [&](const std::string& n) { return P->bid(n); };
   auto D_ = [&](const std::string& n) { return P->bid(pre + n); };
+  auto U_ = [&](const std::string& n) { return P->bid(upre + n); };
   auto Lr = [&](const std::string& n) { return find_layer(P->rec, n); };
-  auto wgrad = [&](const Layer& L, int dy) -> int {
+  auto wgrad = [&](const Layer& L, int dy, bool is_du) -> int {
     order_after(P, LD, LW);
-    return run_wgrad(P, L, N, dy, w_rec, g_rec, ws, LW);
+    return run_wgrad(P, L, N, dy, is_du, w_rec, g_rec, ws, LW);
   };
+  const Emit none;
+  const float LEAK = 0.2f;
   // pred = resize(flow1)
   {
     const Buf& df1 = P->buf(D_("flow1"));
@@ -483,26 +503,35 @@ static int rec_backward(Plan* P, int N, const char* dp, bool with_wgrad, bool ne
                                         df1.ld, 0, df1.h, df1.w, 2, 0, s));
   }
   for (int k = 1; k <= 5; ++k) {
-    const int dconcat = D_(S("concat%d", k));
+    const std::string cname = S("concat%d", k);
+    const int dconcat = D_(cname), uconcat = U_(cname);
     const Layer* fl = Lr(S("flow%d", k));
-    // concat_k feeds flow_k (and, for k<5 .. handled below, the resize of the next finer level wrote it first)
-    UDET_TRY(run_dgrad(P, *fl, N, D_(S("flow%d", k)), dconcat, 0, k == 1 ? 0 : 1, -1, ws, LD));
-    if (with_wgrad) UDET_TRY(wgrad(*fl, D_(S("flow%d", k))));
+    const Layer* dc = Lr(S("deconv%d", k));
+    // concat_k feeds flow_k (and, for k>1, the resize of the next finer level wrote it first).  flow_k's backward-data
+    // launch is the last writer of the deconv_k segment [0, Cout(deconv_k)): it emits that segment's dU.
+    Emit em;
+    em.ubuf = uconcat; em.abuf = fl->x; em.c0 = 0; em.c1 = dc->cout; em.act = ACT_LEAKY; em.alpha = LEAK;
+    UDET_TRY(run_dgrad(P, *fl, N, D_(S("flow%d", k)), false, dconcat, 0, k == 1 ? 0 : 1, -1, em, ws, LD));
+    if (with_wgrad) UDET_TRY(wgrad(*fl, D_(S("flow%d", k)), false));
     if (k < 5) {
       const Layer* uf = Lr(S("upflow%d", k));
-      if (with_wgrad) UDET_TRY(wgrad(*uf, dconcat));
-      UDET_TRY(run_dgrad(P, *uf, N, dconcat, D_(S("rf%d", k + 1)), 0, 0, -1, ws, LD));
+      if (with_wgrad) UDET_TRY(wgrad(*uf, dconcat, false));  // linear layer: raw gradient
+      UDET_TRY(run_dgrad(P, *uf, N, dconcat, false, D_(S("rf%d", k + 1)), 0, 0, -1, none, ws, LD));
       const Buf &drf = P->buf(D_(S("rf%d", k + 1))), &dfn = P->buf(D_(S("flow%d", k + 1)));
       UDET_TRY(launch_resize_bilinear_bwd(ws + drf.off, drf.ld, 0, N, drf.h, drf.w, ws + dfn.off, dfn.ld, 0, dfn.h, dfn.w, 2, 0, s));
     }
-    const Layer* dc = Lr(S("deconv%d", k));
-    if (with_wgrad) UDET_TRY(wgrad(*dc, dconcat));
+    if (with_wgrad) UDET_TRY(wgrad(*dc, uconcat, true));
     const int dr = D_(S("r%d", k + 1));
-    UDET_TRY(run_dgrad(P, *dc, N, dconcat, dr, 0, 0, -1, ws, LD));
+    UDET_TRY(run_dgrad(P, *dc, N, uconcat, true, dr, 0, 0, -1, none, ws, LD));
     const Buf& bdr = P->buf(dr);
     const Buf& dsrc = P->buf(k == 5 ? D_("conv6") : D_(S("concat%d", k + 1)));
     UDET_TRY(launch_resize_bilinear_bwd(ws + bdr.off, bdr.ld, 0, N, bdr.h, bdr.w, ws + dsrc.off, dsrc.ld, 0, dsrc.h, dsrc.w,
                                         bdr.ld, 0, s));
+  }
+  // conv6's output gradient was finalised by the resize adjoint: emit its dU with an elementwise pass (3x6 grid)
+  {
+    const Buf &d6 = P->buf(D_("conv6")), &a6 = P->buf(B_("rec.conv6")), &u6 = P->buf(U_("conv6"));
+    UDET_TRY(launch_emit_du(ws + d6.off, ws + a6.off, ws + u6.off, (long)N * d6.h * d6.w, d6.ld, 0, d6.ld, ACT_LEAKY, LEAK, s));
   }
   // encoders, deepest first.  gradient buffers mirror the forward buffers of each conv's output / input.
   for (int i = 8; i >= 0; --i)
@@ -510,16 +539,19 @@ static int rec_backward(Plan* P, int N, const char* dp, bool with_wgrad, bool ne
       // encoder A sees only the image: without parameter gradients (generator-loss pass) nothing upstream needs it
       if (e[0] == 'a' && !with_wgrad) continue;
       const Layer* L = Lr(std::string(e) + ENC_NAMES[i]);
-      const int dy = D_(P->buf(L->y).name.substr(4));
-      if (with_wgrad) UDET_TRY(wgrad(*L, dy));
+      const int du = U_(P->buf(L->y).name.substr(4));  // dU of this layer's output (emitted by its consumer's dgrad)
+      if (with_wgrad) UDET_TRY(wgrad(*L, du, true));
       if (i == 0) {
-        if (e[0] == 'b' && need_dfin) UDET_TRY(run_dgrad(P, *L, N, dy, D_("fin"), 0, 0, -1, ws, LD));
+        if (e[0] == 'b' && need_dfin) UDET_TRY(run_dgrad(P, *L, N, du, true, D_("fin"), 0, 0, -1, none, ws, LD));
         continue;
       }
       const std::string xname = P->buf(L->x).name;
       const int dx = D_(xname.substr(4));
       const bool slab_in = xname.find("concat") != std::string::npos;  // slab inputs already hold the decoder's gradient
-      UDET_TRY(run_dgrad(P, *L, N, dy, dx, L->x_coff, slab_in ? 1 : 0, -1, ws, LD));
+      // this launch is the last writer of the previous encoder layer's output gradient: emit its dU
+      Emit em;
+      em.ubuf = U_(xname.substr(4)); em.abuf = L->x; em.c0 = 0; em.c1 = L->cin; em.act = ACT_LEAKY; em.alpha = LEAK;
+      UDET_TRY(run_dgrad(P, *L, N, du, true, dx, L->x_coff, slab_in ? 1 : 0, -1, em, ws, LD));
     }
   return UDET_OK;
 }
@@ -547,12 +579,14 @@ static int backward_generator(Plan* P, const float* w_gen, float* g_gen, float* 
   UDET_TRY(rec_backward(P, 2 * B, "e", false, true, nullptr, nullptr, ws, LD, LD));
   UDET_TRY(launch_mask_bwd(ws + P->buf(B_("d.mask")).off, ws + P->buf(B_("rec.e.fin")).off, ws + P->buf(B_("flow")).off,
                            ws + P->buf(B_("mask")).off, ws + P->buf(B_("gen.d17")).off, B * HW, s));
-  // generator, last layer first.  gen.d{k} = gradient w.r.t. layer k's (post-skip) output.
+  // generator, last layer first.  gen.d{k} = gradient w.r.t. layer k's (post-skip) output; gen.u{k} = that times
+  // act'(a_k), emitted by the launch that finalises gen.d{k} (the next layer's backward-data launch or the 2x2 pooling).
   for (int i = 16; i >= 0; --i) {
     const Layer& L = P->gen[i];
-    const int dy = B_(S("gen.d%d", i + 1));
+    const bool has_act = L.act != ACT_NONE;
+    const int dy = has_act ? B_(S("gen.u%d", i + 1)) : B_(S("gen.d%d", i + 1));
     order_after(P, LD, LW);
-    UDET_TRY(run_wgrad(P, L, B, dy, w_gen, g_gen, ws, LW));
+    UDET_TRY(run_wgrad(P, L, B, dy, has_act, w_gen, g_gen, ws, LW));
     if (i == 0) break;
     // skip gradients: x2 = a6 (+ d11), x1 = a3 (+ d14), x0 = a1 (+ d15)   (nets.py:29,32,33)
     int res = -1;
@@ -560,13 +594,20 @@ static int backward_generator(Plan* P, const float* w_gen, float* g_gen, float* 
     if (i == 3) res = B_("gen.d14");
     if (i == 1) res = B_("gen.d15");
     const int dx = B_(S("gen.d%d", i));
+    const Layer& Lp = P->gen[i - 1];  // the layer whose output gradient this launch produces
+    const int ap = Lp.y2 >= 0 ? Lp.y2 : Lp.y;
     if (L.up) {
       const int dup = B_(S("gen.dup%d", i + 1));
-      UDET_TRY(run_dgrad(P, L, B, dy, dup, 0, 0, -1, ws, LD));
+      UDET_TRY(run_dgrad(P, L, B, dy, has_act, dup, 0, 0, -1, Emit(), ws, LD));
       const Buf& bd = P->buf(dx);
       UDET_TRY(launch_pool2x2_sum(ws + P->buf(dup).off, ws + bd.off, B, bd.h, bd.w, bd.ld, s));
+      if (Lp.act != ACT_NONE)
+        UDET_TRY(launch_emit_du(ws + bd.off, ws + P->buf(ap).off, ws + P->buf(B_(S("gen.u%d", i))).off, (long)B * bd.h * bd.w, bd.ld, 0,
+                                bd.ld, Lp.act, Lp.alpha, s));
     } else {
-      UDET_TRY(run_dgrad(P, L, B, dy, dx, 0, 0, res, ws, LD));
+      Emit em;
+      if (Lp.act != ACT_NONE) { em.ubuf = B_(S("gen.u%d", i)); em.abuf = ap; em.c0 = 0; em.c1 = L.cin; em.act = Lp.act; em.alpha = Lp.alpha; }
+      UDET_TRY(run_dgrad(P, L, B, dy, has_act, dx, 0, 0, res, em, ws, LD));
     }
   }
   return UDET_OK;
