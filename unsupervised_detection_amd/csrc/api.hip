@@ -233,6 +233,9 @@ int udet_conv2d_backward_filter(const float* x, const float* dy, const float* y_
     }
     ldy = cout8;
   }
+  float* zero = ar.take(64);
+  if (!zero) { set_error("conv2d_backward_filter: workspace too small"); return UDET_ERR_ARG; }
+  UDET_HIP(hipMemsetAsync(zero, 0, 64 * sizeof(float), stream));
   const size_t pf = 64 * wgrad_partial_floats_needed(kh * kw, cin, cout);
   size_t avail = (ar.cap - ar.used) / sizeof(float);
   if (avail > 256) avail -= 256;
@@ -245,6 +248,7 @@ int udet_conv2d_backward_filter(const float* x, const float* dy, const float* y_
   p.ntaps = g.ntaps;
   memcpy(p.taps, g.taps, sizeof(g.taps));
   p.dw = dw_hwio; p.db = dbias; p.partial = part; p.partial_floats = takef;
+  p.zero16 = zero;
   return launch_wgrad_T(p, kh * kw, stream);
 }
 

@@ -152,6 +152,7 @@ struct WgradParams {
   float* db;        // [Cout] or null
   float* partial;   // workspace
   size_t partial_floats;
+  const float* zero16;  // >= 16 bytes of device zeros (LDS-DMA variant: source of halo / tail lanes); may be null
   // filled by launch_wgrad_T
   int Cin4, Mpad;
   float* pbias;

@@ -167,6 +167,149 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, in
   if (mt == 0 && t < BN) p.pbias[(size_t)blockIdx.y * ldn + co0 + t] = bsum;
 }
 
+// LDS-DMA variant (dU operand, i.e. no act' on load): 512-thread workgroups, waves 4-7 stage both pixel-major operands
+// with global_load_lds_dwordx4 (they ARE the K-major LDS image: no swizzle needed, fragments stay conflict-free
+// ds_read_b32), halo / tail lanes read a zero block; waves 0-3 run the MFMAs and the bias column sums.
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(512, 4) void conv_wgrad_dma_kernel(const WgradParams p, int co_tiles, int nsplit) {
+  constexpr int BKP = 32;
+  constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  static_assert(WAVES_M * WAVES_N == 4 && TM * 32 == WTM && TN * 32 == WTN, "tile");
+  constexpr int A_F4_ROW = BM / 4, B_F4_ROW = BN / 4;
+  constexpr int A_LD = BKP * A_F4_ROW / 256, B_F4 = BKP * B_F4_ROW;
+  constexpr int B_LD = (B_F4 + 255) / 256;
+  static_assert(A_LD * 256 == BKP * A_F4_ROW, "tile");
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  __shared__ __attribute__((aligned(16))) float As[2][BKP][BM];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BKP][BN];
+  __shared__ int2 tap_yx[UDET_MAX_TAPS];
+
+  const int tid = threadIdx.x;
+  const int role = __builtin_amdgcn_readfirstlane(tid >> 8);
+  const int t = tid & 255, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N, li = lane & 31, lh = lane >> 5;
+  const int mt = blockIdx.x / co_tiles;
+  const int m0 = mt * BM, co0 = (blockIdx.x - mt * co_tiles) * BN;
+  const int OHW = p.OH * p.OW;
+  const int Q = p.N * OHW;
+  const int nchunks = (Q + BKP - 1) / BKP;
+  const int c_begin = (int)((long)nchunks * blockIdx.y / nsplit), c_end = (int)((long)nchunks * (blockIdx.y + 1) / nsplit);
+  const int Hs = p.H >> p.up_shift, Ws = p.W >> p.up_shift;
+  const int cout4 = (p.Cout + 3) & ~3;
+
+  for (int i = tid; i < p.ntaps; i += 512) tap_yx[i] = make_int2(p.taps[i].dy, p.taps[i].dx);
+  __syncthreads();
+
+  if (role == 1) {
+    const int a_m4 = t % A_F4_ROW;
+    const int a_m = m0 + a_m4 * 4;
+    const int a_tap = a_m / p.Cin4, a_ci = a_m - a_tap * p.Cin4;
+    const bool a_on = a_tap < p.ntaps;
+    int a_dy = 0, a_dx = 0;
+    if (a_on) { a_dy = tap_yx[a_tap].x; a_dx = tap_yx[a_tap].y; }
+    const float* a_src = p.x + p.x_coff + a_ci;
+    const float* zero = p.zero16;
+    auto issue = [&](int buf, int c) {
+      const int q0 = c * BKP;
+#pragma unroll
+      for (int j = 0; j < A_LD; ++j) {
+        const int q = q0 + (t + j * 256) / A_F4_ROW;
+        const float* src = zero;
+        if (a_on && q < Q) {
+          const int n = (int)fdiv(q, p.fd_ohw), rem = q - n * OHW;
+          const int oy = (int)fdiv(rem, p.fd_ow), ox = rem - oy * p.OW;
+          int iy = oy * p.isy + a_dy, ix = ox * p.isx + a_dx;
+          if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
+            iy >>= p.up_shift;
+            ix >>= p.up_shift;
+            src = a_src + (size_t)((n * Hs + iy) * Ws + ix) * p.ldx;
+          }
+        }
+        __builtin_amdgcn_global_load_lds(src, (lds_ptr)(&As[buf][0][0] + (j * 256 + wave * 64) * 4), 16, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < B_LD; ++j) {
+        const int idx = t + j * 256;
+        if (B_F4 % 256 != 0 && idx - lane + 63 >= B_F4 && idx - lane >= B_F4) continue;  // whole wave beyond the tile
+        const int kp = idx / B_F4_ROW, c4 = idx - kp * B_F4_ROW;
+        const int q = q0 + kp, co = co0 + c4 * 4;
+        const float* src = (idx < B_F4 && q < Q && co < cout4) ? p.dy + ((size_t)q * p.ldy + p.y_coff + co) : zero;
+        __builtin_amdgcn_global_load_lds(src, (lds_ptr)(&Bs[buf][0][0] + (j * 256 + wave * 64) * 4), 16, 0, 0);
+      }
+    };
+    auto landed = [&]() {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    };
+    if (c_begin < c_end) issue(0, c_begin);
+    landed();
+    int buf = 0;
+    for (int c = c_begin; c < c_end; ++c) {
+      if (c + 1 < c_end) issue(buf ^ 1, c + 1);
+      landed();
+      buf ^= 1;
+    }
+    return;
+  }
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float bsum = 0.f;
+  auto handover = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  handover();
+  int buf = 0;
+  for (int c = c_begin; c < c_end; ++c) {
+    {
+      float a[2][TM], b[2][TN];
+      auto frag = [&](int s, int kk) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[s][i] = As[buf][kk * 2 + lh][wm * WTM + i * 32 + li];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[s][j] = Bs[buf][kk * 2 + lh][wn * WTN + j * 32 + li];
+      };
+      frag(0, 0);
+#pragma unroll
+      for (int kk = 0; kk < BKP / 2; ++kk) {
+        if (kk + 1 < BKP / 2) frag((kk + 1) & 1, kk + 1);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk & 1][i], b[kk & 1][j], acc[i][j], 0, 0, 0);
+        if (kk + 1 < BKP / 2) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+      }
+    }
+    if (mt == 0 && t < BN) {
+#pragma unroll
+      for (int k = 0; k < BKP; ++k) bsum += Bs[buf][k][t];
+    }
+    handover();
+    buf ^= 1;
+  }
+  const int ldn = co_tiles * BN;
+  float* dst = p.partial + (size_t)blockIdx.y * p.Mpad * ldn;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) dst[(size_t)m * ldn + co0 + wn * WTN + j * 32 + li] = acc[i][j][r];
+    }
+  if (mt == 0 && t < BN) p.pbias[(size_t)blockIdx.y * ldn + co0 + t] = bsum;
+}
+
 // dw[widx][ci][co] = sum_s partial[s][tap*Cin4+ci][co] ; db[co] = sum_s pbias[s][co].  SL lanes share one element
 // (each sums every SL-th split, then a fixed-order shuffle tree): deterministic, and parallel for tiny filters.
 template <int SL>
@@ -236,16 +379,17 @@ size_t wgrad_partial_floats_needed(int T, int Cin, int Cout) {
   return (size_t)BND_SPLIT * Cout + ldn + mpad * ldn + 64;
 }
 
-static std::unordered_map<uint64_t, int> g_wcache;
+static std::unordered_map<uint64_t, int> g_wcache;  // problem shape -> split count | (LDS-DMA variant ? 1<<20 : 0)
 static std::mutex g_wcache_mu;
 static int g_wtuning = 0;
 void wgrad_set_tuning(int on) { g_wtuning = on; }
 int wgrad_tuned_shapes() { std::lock_guard<std::mutex> l(g_wcache_mu); return (int)g_wcache.size(); }
 
 template <int BM, int BN, int WM_, int WN_>
-static void wgrad_launch(const WgradParams& p, int m_tiles, int co_tiles, int nsplit, hipStream_t stream) {
+static void wgrad_launch(const WgradParams& p, int m_tiles, int co_tiles, int nsplit, bool dma, hipStream_t stream) {
   dim3 grid(m_tiles * co_tiles, nsplit);
-  hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM_, WN_>), grid, dim3(256), 0, stream, p, co_tiles, nsplit);
+  if (dma) hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, WM_, WN_>), grid, dim3(512), 0, stream, p, co_tiles, nsplit);
+  else hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM_, WN_>), grid, dim3(256), 0, stream, p, co_tiles, nsplit);
 }
 
 // p.taps must list the (non-culled) taps with widx = ky*kw+kx; T = kh*kw.
@@ -284,13 +428,16 @@ int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream) {
   const size_t wsz = (size_t)T * p.Cin * p.Cout;
   if (p.ntaps < T) UDET_HIP(hipMemsetAsync(p.dw, 0, wsz * sizeof(float), stream));  // culled taps have zero gradient
   const long total = (long)(Mreal + 1) * p.Cout;
-  auto run = [&](int ns) {
+  const bool dma_ok = p.ya == nullptr && p.zero16 != nullptr && !(reinterpret_cast<uintptr_t>(p.zero16) & 15);
+  auto run = [&](int cfg) {
+    const int ns = cfg & 0xfffff;
+    const bool dma = dma_ok && (cfg >> 20) != 0;
     WgradParams q = p;
     q.pbias = base;                              // [ns][ldn]
     q.partial = base + (size_t)ns * ldn;        // [ns][Mpad][ldn]
-    if (bn == 128) wgrad_launch<128, 128, 2, 2>(q, m_tiles, co_tiles, ns, stream);
-    else if (bn == 64) wgrad_launch<128, 64, 2, 2>(q, m_tiles, co_tiles, ns, stream);
-    else wgrad_launch<128, 32, 4, 1>(q, m_tiles, co_tiles, ns, stream);
+    if (bn == 128) wgrad_launch<128, 128, 2, 2>(q, m_tiles, co_tiles, ns, dma, stream);
+    else if (bn == 64) wgrad_launch<128, 64, 2, 2>(q, m_tiles, co_tiles, ns, dma, stream);
+    else wgrad_launch<128, 32, 4, 1>(q, m_tiles, co_tiles, ns, dma, stream);
     const int sl = (ns >= 64 && total * 64 <= 262144) ? 64 : ((ns >= 8 && total * 8 <= 262144) ? 8 : 1);
     const long nbl = (total * sl + 255) / 256;
     const int nb = (int)(nbl > 4096 ? 4096 : nbl);
@@ -300,7 +447,7 @@ int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream) {
   };
   // autotuned split count (see conv_igemm.hip): kernel + reduction timed together
   {
-    const int f[] = {p.N, p.H, p.W, p.up_shift, p.Cin, p.Cout, p.ntaps, p.OH, p.OW, p.isy, p.ya ? 1 : 0, p.ldx, p.ldy, cap};
+    const int f[] = {p.N, p.H, p.W, p.up_shift, p.Cin, p.Cout, p.ntaps, p.OH, p.OW, p.isy, p.ya ? 1 : 0, p.ldx, p.ldy, cap, dma_ok ? 1 : 0};
     uint64_t key = 1469598103934665603ull;
     for (int v : f) { key ^= (uint64_t)(uint32_t)v; key *= 1099511628211ull; }
     bool have = false;
@@ -315,21 +462,23 @@ int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream) {
       const int h = nsplit;
       float best_ms = 1e30f;
       int best = h;
-      for (int ns : {h / 8, h / 4, h / 2, h, h * 2, h * 4}) {
-        if (ns < 1 || ns > cap) continue;
-        run(ns);
-        (void)hipEventRecord(e0, stream);
-        for (int r = 0; r < 3; ++r) run(ns);
-        (void)hipEventRecord(e1, stream);
-        if (hipEventSynchronize(e1) != hipSuccess) continue;
-        float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, e0, e1);
-        if (ms < best_ms) { best_ms = ms; best = ns; }
-      }
+      for (int dma = 0; dma <= (dma_ok ? 1 : 0); ++dma)
+        for (int ns : {h / 8, h / 4, h / 2, h, h * 2, h * 4}) {
+          if (ns < 1 || ns > cap) continue;
+          const int cfg = ns | (dma << 20);
+          run(cfg);
+          (void)hipEventRecord(e0, stream);
+          for (int r = 0; r < 3; ++r) run(cfg);
+          (void)hipEventRecord(e1, stream);
+          if (hipEventSynchronize(e1) != hipSuccess) continue;
+          float ms = 0.f;
+          (void)hipEventElapsedTime(&ms, e0, e1);
+          if (ms < best_ms) { best_ms = ms; best = cfg; }
+        }
       nsplit = best;
       if (getenv("UDET_TUNE_LOG"))
-        fprintf(stderr, "[udet tune] wgrad N=%d %dx%d Cin=%d Cout=%d taps=%d -> nsplit=%d (heuristic %d) %.1f us\n", p.N, p.OH, p.OW,
-                p.Cin, p.Cout, p.ntaps, nsplit, h, best_ms / 3 * 1e3f);
+        fprintf(stderr, "[udet tune] wgrad N=%d %dx%d Cin=%d Cout=%d taps=%d -> nsplit=%d dma=%d (heuristic %d) %.1f us\n", p.N, p.OH,
+                p.OW, p.Cin, p.Cout, p.ntaps, nsplit & 0xfffff, nsplit >> 20, h, best_ms / 3 * 1e3f);
       std::lock_guard<std::mutex> l(g_wcache_mu);
       g_wcache[key] = nsplit;
     }

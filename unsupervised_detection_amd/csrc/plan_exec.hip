@@ -183,6 +183,7 @@ static int run_wgrad(Plan* P, const Layer& L, int N, int dy, bool dy_is_du, cons
   q.dw = g_flat + np.p[L.w_idx].offset;
   q.db = g_flat + np.p[L.b_idx].offset;
   q.partial = ws + P->wgrad_off[ln.slot];
+  q.zero16 = ws + P->small_off + 60000;
   q.partial_floats = P->wgrad_floats;
   if (L.g_idx >= 0) {
     q.w = w_flat + np.p[L.w_idx].offset;
