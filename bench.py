@@ -152,7 +152,8 @@ def main():
     if rank == 0:
         import csv
         import tempfile
-        dump = os.path.join(tempfile.gettempdir(), "udet_layers_%d.csv" % os.getpid())
+        keep = os.environ.get("UDET_PROF_DUMP")  # a caller-provided path is kept (per-layer CSV for analysis)
+        dump = keep or os.path.join(tempfile.gettempdir(), "udet_layers_%d.csv" % os.getpid())
         if os.path.exists(dump):
             os.remove(dump)
         os.environ["UDET_PROF_DUMP"] = dump
@@ -161,7 +162,8 @@ def main():
         if os.path.exists(dump):
             with open(dump) as f:
                 layers = [(int(r[0]), r[1], float(r[2]), float(r[3])) for r in csv.reader(f)]
-            os.remove(dump)
+            if not keep:
+                os.remove(dump)
 
     if rank == 0:
         conv_ms = sum(prof[c]["ms"] for c in ("conv_fwd", "conv_dgrad", "conv_wgrad"))

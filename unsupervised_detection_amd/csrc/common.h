@@ -124,13 +124,17 @@ struct ConvParams {
 };
 
 int launch_conv(ConvParams& p, hipStream_t stream);
+// y[n, oy, ox, y_coff+co] = bias[co] + sum_{taps t of the pixel's parity class} Z[n, qy+dy_t, qx+dx_t, widx_t*Cout+co]
+// (zero outside Z's grid); g describes taps / classes / output lattice exactly like a convolution launch
+int launch_tap_gather(const ConvParams& g, const float* z, int ldz, hipStream_t stream);
 
 // One job of the table-driven weight re-layout (see pack_jobs_kernel in conv_host.hip): offsets are in floats,
 // src/gamma/beta/bias relative to the network's flat TF-order weight buffer, dst relative to the workspace.
 struct PackJob {
   long src_off, dst_off, gamma_off, beta_off;  // gamma_off < 0: no BN fold
   long total;
-  int T, R, C, Kc, ldw, k_split, k_gap, mode;  // mode 0 forward, 1 transposed, 2 bias (dst[c] = b*gamma*c + beta | b)
+  int T, R, C, Kc, ldw, k_split, k_gap, mode;  // mode 0 forward, 1 transposed, 2 bias (dst[c] = b*gamma*c + beta | b),
+                                               // 3/4 taps-into-N: dst[kmap(r)][t*C+c] = src[t][r][c] (3) | src[t][c][r] (4)
 };
 
 // --------------------------------------------------------------- wgrad ----

@@ -13,6 +13,8 @@ int wgrad_tuned_shapes();  // debugging / tuning hook: bm == 0 and ks < 0 restor
 bool conv_setup_dgrad(ConvParams& p, int cls, int N, int H, int W, int kh, int kw, int s, int d);
 int launch_pack_weights(const float* src, float* dst, int T, int R, int C, int Kc, int ldw, int k_split, int k_gap,
                         int mode, const float* scale, hipStream_t stream);
+int launch_pack_taps_into_n(const float* src, float* dst, int T, int R, int C, int Kc, int ldz, int k_split, int k_gap,
+                            int transposed, hipStream_t stream);
 int launch_pack_jobs(const PackJob* jobs_dev, int njobs, const float* wsrc, float* ws, float bn_c, hipStream_t stream);
 int launch_fold_bn(const float* b, const float* gamma, const float* beta, float c, float* scale, float* bias_f, int n,
                    hipStream_t stream);

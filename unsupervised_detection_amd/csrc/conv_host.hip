@@ -1,5 +1,7 @@
 // Host-side helpers that turn a TF-style convolution description into ConvParams
 // (tap lists, sub-grids, TF 'SAME' padding) + the weight packing kernels.
+#include <string.h>
+
 #include "common.h"
 #include "conv_host.h"
 
@@ -148,13 +150,19 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < j.total; e += (long)gridDim.x * 256) {
     const int n = (int)(e % j.ldw);
     const int k = (int)((e / j.ldw) % j.Kc);
-    const int t = (int)(e / ((long)j.ldw * j.Kc));
+    int t = (int)(e / ((long)j.ldw * j.Kc));
     float v = 0.f;
     int ks = k;  // source index of packed row k (-1 inside the zero gap)
     if (k >= j.k_split) ks = (k < j.k_split + j.k_gap) ? -1 : k - j.k_gap;
-    const int r = j.mode == 0 ? ks : n, c = j.mode == 0 ? n : ks;
+    int r = j.mode == 0 ? ks : n, c = j.mode == 0 ? n : ks;
+    if (j.mode >= 3) {  // taps folded into the N axis: column n = t*C + c
+      t = n / j.C;
+      c = n - t * j.C;
+      r = ks;
+      if (t >= j.T) r = -1;
+    }
     if (r >= 0 && r < j.R && c >= 0 && c < j.C) {
-      v = src[((long)t * j.R + r) * j.C + c];
+      v = j.mode == 4 ? src[((long)t * j.C + c) * j.R + r] : src[((long)t * j.R + r) * j.C + c];
       if (gamma) v *= gamma[c] * bn_c;
     }
     dst[e] = v;
@@ -163,6 +171,67 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
 int launch_pack_jobs(const PackJob* jobs_dev, int njobs, const float* wsrc, float* ws, float bn_c, hipStream_t stream) {
   if (njobs < 1) return UDET_OK;
   hipLaunchKernelGGL(pack_jobs_kernel, dim3(48, njobs), dim3(256), 0, stream, jobs_dev, wsrc, ws, bn_c);
+  UDET_HIP(hipGetLastError());
+  return UDET_OK;
+}
+
+// one-off variant of the same re-layout for a single job passed by value (PWC-Net packing, single-op entry points)
+__global__ __launch_bounds__(256) void pack_job_kernel(const PackJob j, const float* __restrict__ wsrc, float* __restrict__ ws) {
+  const float* src = wsrc + j.src_off;
+  float* dst = ws + j.dst_off;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < j.total; e += (long)gridDim.x * 256) {
+    const int n = (int)(e % j.ldw);
+    const int k = (int)((e / j.ldw) % j.Kc);
+    int ks = k;
+    if (k >= j.k_split) ks = (k < j.k_split + j.k_gap) ? -1 : k - j.k_gap;
+    const int t = n / j.C, c = n - t * j.C;
+    float v = 0.f;
+    if (ks >= 0 && ks < j.R && t < j.T) v = j.mode == 4 ? src[((long)t * j.C + c) * j.R + ks] : src[((long)t * j.R + ks) * j.C + c];
+    dst[e] = v;
+  }
+}
+int launch_pack_taps_into_n(const float* src, float* dst, int T, int R, int C, int Kc, int ldz, int k_split, int k_gap,
+                            int transposed, hipStream_t stream) {
+  PackJob j;
+  memset(&j, 0, sizeof(j));
+  j.T = T; j.R = R; j.C = C; j.Kc = Kc; j.ldw = ldz; j.k_split = k_split; j.k_gap = k_gap;
+  j.mode = transposed ? 4 : 3; j.total = (long)Kc * ldz; j.gamma_off = -1;
+  int nb = (int)((j.total + 255) / 256);
+  if (nb > 1024) nb = 1024;
+  hipLaunchKernelGGL(pack_job_kernel, dim3(nb), dim3(256), 0, stream, j, src, dst);
+  UDET_HIP(hipGetLastError());
+  return UDET_OK;
+}
+
+// gather-sum over the taps of a GEMM + gather head (see common.h)
+__global__ __launch_bounds__(256) void tap_gather_kernel(const ConvParams g, const float* __restrict__ z, int ldz) {
+  const long total = (long)g.N * g.OH * g.OW * g.Cout;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int co = (int)(e % g.Cout);
+    const long pix = e / g.Cout;
+    const int ox = (int)(pix % g.OW), oy = (int)((pix / g.OW) % g.OH), n = (int)(pix / ((long)g.OW * g.OH));
+    int cls = 0, qy = oy, qx = ox;
+    if (g.ncls > 1) {
+      cls = (oy & 1) * 2 + (ox & 1);
+      qy = oy >> 1;
+      qx = ox >> 1;
+    }
+    float v = g.bias ? g.bias[co] : 0.f;
+    for (int t = g.cls_tap[cls]; t < g.cls_tap[cls + 1]; ++t) {
+      const int iy = qy + g.taps[t].dy, ix = qx + g.taps[t].dx;
+      if ((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
+        v += z[((size_t)(n * g.H + iy) * g.W + ix) * ldz + g.taps[t].widx * g.Cout + co];
+    }
+    g.y[(size_t)pix * g.ldy + g.y_coff + co] = v;
+  }
+}
+int launch_tap_gather(const ConvParams& g, const float* z, int ldz, hipStream_t stream) {
+  ConvParams q = g;
+  if (q.ncls != 4) { q.ncls = 1; q.cls_tap[0] = 0; q.cls_tap[1] = q.ntaps; }
+  const long total = (long)q.N * q.OH * q.OW * q.Cout;
+  int nb = (int)((total + 255) / 256);
+  if (nb > 4096) nb = 4096;
+  hipLaunchKernelGGL(tap_gather_kernel, dim3(nb), dim3(256), 0, stream, q, z, ldz);
   UDET_HIP(hipGetLastError());
   return UDET_OK;
 }

@@ -38,10 +38,15 @@ struct KCursor {
 struct KOrder {
   int Kc, CB, nblk, wl, ntc;
 };
-__device__ __forceinline__ KOrder korder(int Kc, int ntc) {
+__device__ __forceinline__ KOrder korder(int Kc, int ntc, int dbg = 0) {
   KOrder o;
   o.Kc = Kc; o.ntc = ntc;
-  o.CB = Kc < 32 ? Kc : 32;
+  int cb = 32;
+  if (dbg & 16) cb = Kc;
+  if (dbg & 32) cb = 64;
+  if (dbg & 64) cb = 128;
+  if (dbg & 128) cb = 256;
+  o.CB = Kc < cb ? Kc : cb;
   o.nblk = (Kc + o.CB - 1) / o.CB;
   o.wl = Kc - (o.nblk - 1) * o.CB;
   return o;
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 2) void conv_igemm_kernel(
     c_end = (int)((long)nchunks * (blockIdx.z + 1) / p.ksplit);
   }
   // flat-K cursors of this thread's A float4 and of its B rows; advanced by BK per stage
-  const KOrder ko = korder(Kc, ntc);
+  const KOrder ko = korder(Kc, ntc, p.dbg);
   KCursor ka = kc_init(ko, c_begin * BK + a_kq * 4), kb[B_LD];
 #pragma unroll
   for (int j = 0; j < B_LD; ++j) kb[j] = kc_init(ko, c_begin * BK + (t + j * 256) / B_F4_ROW);
@@ -455,7 +460,7 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_dma_kernel(const ConvParams
         a_ix0[j] = 0;
       }
     }
-    const KOrder ko = korder(Kc, ntc);
+    const KOrder ko = korder(Kc, ntc, p.dbg);
     KCursor ka = kc_init(ko, c_begin * BK + kqs * 4), kb[B_LD];
 #pragma unroll
     for (int j = 0; j < B_LD; ++j) kb[j] = kc_init(ko, c_begin * BK + (t + j * 256) / B_F4_ROW);

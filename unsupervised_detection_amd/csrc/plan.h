@@ -52,6 +52,10 @@ struct Layer {
   int x = -1, x_coff = 0, y = -1, y_coff = 0;
   int res = -1, res_coff = 0, y2 = -1;
   int H = 0, W = 0;  // stored input grid
+  // 2-channel heads: forward as ONE 1x1 GEMM Z[p][(tap,co)] = sum_c X[p][c] W[tap][c][co] + a gather-sum over the taps
+  bool col2im = false;
+  int ldz = 0, zbuf = -1;
+  size_t wz_off = 0;
 };
 
 struct Config {

@@ -433,6 +433,20 @@ Plan* plan_build(const Config& cfg) {
     }
   }
 
+  // 2-channel heads whose K (input channels) is deep: GEMM + gather formulation (see run_fwd)
+  auto mark_heads = [&](std::vector<Layer>& v, int N) {
+    for (auto& L : v) {
+      const bool head = L.cout == 2 && L.cin >= 32 && L.kh * L.kw * L.cout <= 64 && L.dil == 1 && !L.up && L.res < 0 && L.y2 < 0 &&
+                        ((L.transposed && L.kh == 4) || (!L.transposed && L.stride == 1));
+      if (!head || getenv("UDET_NO_COL2IM")) continue;
+      L.col2im = true;
+      L.ldz = round_up(L.kh * L.kw * L.cout, 32);
+      L.zbuf = P->add_buf("z." + L.name, N, L.H, L.W, L.ldz);
+    }
+  };
+  mark_heads(P->pwc, B);
+  mark_heads(P->rec, 3 * B);
+
   // ======================= packed weights =======================
   size_t off = 0;
   auto place = [&](Layer& L, bool trainable) {
@@ -440,6 +454,7 @@ Plan* plan_build(const Config& cfg) {
     L.wp_off = off; off = align64(off + (size_t)T * L.Kc * L.ldw);
     L.bias_f_off = off; off = align64(off + L.cout);
     L.scale_off = off; off = align64(off + L.cout);
+    if (L.col2im) { L.wz_off = off; off = align64(off + (size_t)L.Kc * L.ldz); }
     if (trainable) {
       L.KcT = round_up(L.cout, 8);
       L.ldwT = round_up(L.cin, 4);
@@ -467,10 +482,10 @@ Plan* plan_build(const Config& cfg) {
     P->seg_off[net] = off;
     off = align64(off + 4 * net_params(net).p.size() + 64);  // two long tables (offset, len) = 4 floats per entry
   }
-  for (int net = 1; net <= 2; ++net) {  // PackJob tables: <= 3 jobs per layer
+  for (int net = 1; net <= 2; ++net) {  // PackJob tables: <= 4 jobs per layer
     const size_t nl = net == NET_GEN ? P->gen.size() : P->rec.size();
     P->jobs_off[net] = off;
-    off = align64(off + 3 * nl * (sizeof(PackJob) / sizeof(float)) + 64);
+    off = align64(off + 4 * nl * (sizeof(PackJob) / sizeof(float)) + 64);
   }
   P->arena_floats = off;
   if (const char* e = getenv("UDET_SERIAL")) P->concurrent = atoi(e) == 0;

@@ -97,6 +97,29 @@ static int run_fwd(Plan* P, const Layer& L, int N, float* ws, const Lane& ln, si
   const Buf &bx = P->buf(L.x), &by = P->buf(L.y);
   const int ncls = L.transposed ? conv_dgrad_classes(2, 2 * L.H, 2 * L.W) : 1;
   prof_begin(P, PROF_CONV_FWD, layer_flops(L, N), 0, s, L.name.c_str());
+  if (L.col2im && (!L.transposed || ncls == 1) && x_extra == 0 && y_extra == 0) {
+    // 2-channel head: the (tap, output channel) pairs become the N axis of ONE 1x1 GEMM over the deep channel axis
+    // (every input byte read once, no 16x padding of the MFMA columns per tap), then a gather-sum over the taps
+    const Buf& bz = P->buf(L.zbuf);
+    ConvParams p;
+    memset(&p, 0, sizeof(p));
+    conv_setup_fwd(p, N, L.H, L.W, 1, 1, 1, 1);
+    p.x = ws + bx.off; p.ldx = bx.ld; p.x_coff = L.x_coff;
+    p.wp = ws + L.wz_off; p.Kc = L.Kc; p.ldw = L.ldz;
+    p.y = ws + bz.off; p.ldy = bz.ld; p.y_coff = 0; p.Cout = L.kh * L.kw * L.cout;
+    fill_common(P, p, ws, ln.slot);
+    UDET_TRY(launch_conv(p, s));
+    ConvParams g;
+    memset(&g, 0, sizeof(g));
+    if (L.transposed) conv_setup_dgrad(g, 0, N, 2 * L.H, 2 * L.W, L.kh, L.kw, 2, 1);
+    else conv_setup_fwd(g, N, L.H, L.W, L.kh, L.kw, 1, 1);
+    g.H = L.H; g.W = L.W;  // Z lives on the input grid
+    g.bias = ws + L.bias_f_off;
+    g.y = ws + by.off; g.ldy = by.ld; g.y_coff = L.y_coff; g.Cout = L.cout;
+    UDET_TRY(launch_tap_gather(g, ws + bz.off, bz.ld, s));
+    prof_end(P, s);
+    return UDET_OK;
+  }
   for (int cls = 0; cls < ncls; ++cls) {
     ConvParams p;
     memset(&p, 0, sizeof(p));
@@ -232,6 +255,11 @@ int plan_init_workspace(Plan* P, float* ws, hipStream_t s) {
       j.dst_off = (long)L.wpT_off; j.Kc = L.KcT; j.ldw = L.ldwT; j.k_split = L.KcT; j.k_gap = 0;
       j.mode = 1; j.total = (long)T * L.KcT * L.ldwT;
       jobs.push_back(j);
+      if (L.col2im) {  // taps folded into the N axis (GEMM + gather heads)
+        j.dst_off = (long)L.wz_off; j.R = L.cin; j.C = L.cout; j.Kc = L.Kc; j.ldw = L.ldz; j.k_split = L.k_split; j.k_gap = L.k_gap;
+        j.mode = 3; j.total = (long)L.Kc * L.ldz;
+        jobs.push_back(j);
+      }
       // bias (BN-folded for the generator)
       j.src_off = (long)np.p[L.b_idx].offset; j.dst_off = (long)L.bias_f_off; j.mode = 2; j.total = L.cout;
       jobs.push_back(j);
@@ -254,6 +282,8 @@ static int pack_layer(const Layer& L, const float* w_flat, float* ws, const floa
     UDET_TRY(launch_pack_weights(w, ws + L.wp_off, T, L.cin, L.cout, L.Kc, L.ldw, L.k_split, L.k_gap, 0, scale, s));
   if (trainable)
     UDET_TRY(launch_pack_weights(w, ws + L.wpT_off, T, L.cin, L.cout, L.KcT, L.ldwT, L.KcT, 0, 1, scale, s));
+  if (L.col2im)
+    UDET_TRY(launch_pack_taps_into_n(w, ws + L.wz_off, T, L.cin, L.cout, L.Kc, L.ldz, L.k_split, L.k_gap, L.transposed ? 1 : 0, s));
   return UDET_OK;
 }
 
