@@ -158,6 +158,7 @@ struct WgradParams {
   size_t partial_floats;
   const float* zero16;  // >= 16 bytes of device zeros (LDS-DMA variant: source of halo / tail lanes); may be null
   // filled by launch_wgrad_T
+  int swapped, oCin, oCout, bias_m;  // operand-swapped GEMM view for <=4-channel outputs (see launch_wgrad_T)
   int Cin4, Mpad;
   float* pbias;
   FastDiv fd_ohw, fd_ow;

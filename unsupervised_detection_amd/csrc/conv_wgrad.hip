@@ -144,7 +144,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, in
         __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
       }
     }
-    if (mt == 0 && t < BN) {
+    if (p.swapped) {  // bias = column sums of the centre tap's rows of the (gathered) A stage
+      if (co0 == 0 && t < 4 && p.bias_m >= m0 && p.bias_m < m0 + BM) {
+#pragma unroll
+        for (int k = 0; k < BKP; ++k) bsum += As[buf][k][p.bias_m - m0 + t];
+      }
+    } else if (mt == 0 && t < BN) {
 #pragma unroll
       for (int k = 0; k < BKP; ++k) bsum += Bs[buf][k][t];
     }
@@ -164,7 +169,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, in
 #pragma unroll
       for (int j = 0; j < TN; ++j) dst[(size_t)m * ldn + co0 + wn * WTN + j * 32 + li] = acc[i][j][r];
     }
-  if (mt == 0 && t < BN) p.pbias[(size_t)blockIdx.y * ldn + co0 + t] = bsum;
+  if (p.swapped) {
+    if (co0 == 0 && t < 4 && p.bias_m >= m0 && p.bias_m < m0 + BM) p.pbias[(size_t)blockIdx.y * ldn + t] = bsum;
+  } else if (mt == 0 && t < BN) {
+    p.pbias[(size_t)blockIdx.y * ldn + co0 + t] = bsum;
+  }
 }
 
 // LDS-DMA variant (dU operand, i.e. no act' on load): 512-thread workgroups, waves 4-7 stage both pixel-major operands
@@ -290,7 +299,12 @@ __global__ __launch_bounds__(512, 4) void conv_wgrad_dma_kernel(const WgradParam
         __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
       }
     }
-    if (mt == 0 && t < BN) {
+    if (p.swapped) {  // bias = column sums of the centre tap's rows of the (gathered) A stage
+      if (co0 == 0 && t < 4 && p.bias_m >= m0 && p.bias_m < m0 + BM) {
+#pragma unroll
+        for (int k = 0; k < BKP; ++k) bsum += As[buf][k][p.bias_m - m0 + t];
+      }
+    } else if (mt == 0 && t < BN) {
 #pragma unroll
       for (int k = 0; k < BKP; ++k) bsum += Bs[buf][k][t];
     }
@@ -307,7 +321,11 @@ __global__ __launch_bounds__(512, 4) void conv_wgrad_dma_kernel(const WgradParam
 #pragma unroll
       for (int j = 0; j < TN; ++j) dst[(size_t)m * ldn + co0 + wn * WTN + j * 32 + li] = acc[i][j][r];
     }
-  if (mt == 0 && t < BN) p.pbias[(size_t)blockIdx.y * ldn + co0 + t] = bsum;
+  if (p.swapped) {
+    if (co0 == 0 && t < 4 && p.bias_m >= m0 && p.bias_m < m0 + BM) p.pbias[(size_t)blockIdx.y * ldn + t] = bsum;
+  } else if (mt == 0 && t < BN) {
+    p.pbias[(size_t)blockIdx.y * ldn + co0 + t] = bsum;
+  }
 }
 
 // dw[widx][ci][co] = sum_s partial[s][tap*Cin4+ci][co] ; db[co] = sum_s pbias[s][co].  SL lanes share one element
@@ -315,12 +333,14 @@ __global__ __launch_bounds__(512, 4) void conv_wgrad_dma_kernel(const WgradParam
 template <int SL>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradParams p, int ldn, int nsplit) {
   const int Mreal = p.ntaps * p.Cin4;
-  const long total = (long)(Mreal + 1) * p.Cout;
+  const int ncol = p.Cout;  // GEMM-view columns
+  const long total = (long)(Mreal + 1) * ncol;
   const size_t slab = (size_t)p.Mpad * ldn;
   const int sl = threadIdx.x % SL;
   for (long e = ((long)blockIdx.x * 256 + threadIdx.x) / SL; e < total; e += (long)gridDim.x * (256 / SL)) {
-    const int m = (int)(e / p.Cout), co = (int)(e - (long)m * p.Cout);
+    const int m = (int)(e / ncol), co = (int)(e - (long)m * ncol);
     const bool is_bias = m == Mreal;
+    if (is_bias && p.swapped && co >= p.oCout) continue;  // (uniform over the SL lanes of an element)
     const float* src = is_bias ? p.pbias + co : p.partial + (size_t)m * ldn + co;
     const size_t stride = is_bias ? (size_t)ldn : slab;
     float s = 0.f;
@@ -333,7 +353,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradParams p, 
       continue;
     }
     const int tap = m / p.Cin4, ci = m - tap * p.Cin4;
-    if (ci < p.Cin) p.dw[((size_t)p.taps[tap].widx * p.Cin + ci) * p.Cout + co] = s;
+    if (p.swapped) {  // rows are (tap, output channel), columns input channels
+      if (ci < p.oCout) p.dw[((size_t)p.taps[tap].widx * p.oCin + co) * p.oCout + ci] = s;
+    } else if (ci < p.Cin) {
+      p.dw[((size_t)p.taps[tap].widx * p.Cin + ci) * p.Cout + co] = s;
+    }
   }
 }
 
@@ -398,22 +422,42 @@ int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream) {
     set_error("wgrad: ldx=%d x_coff=%d ldy=%d y_coff=%d must be multiples of 4", p.ldx, p.x_coff, p.ldy, p.y_coff);
     return UDET_ERR_ALIGN;
   }
+  // <=4 output channels over a deep input: the plain view pads the 2 MFMA output columns to 32 for every (tap, ci) row.
+  // Swap the operands instead: rows = (tap, output channel) gathered from dU at the mirrored tap offsets, columns =
+  // input channels read straight from X, K = input pixels:  G[(t,co)][ci] = sum_q dU[q - d_t][co] * X[q][ci] = dW[t][ci][co].
+  // The bias gradient is the column sum of the centre tap's rows.
+  WgradParams g = p;
+  g.swapped = 0; g.bias_m = -1; g.oCin = p.Cin; g.oCout = p.Cout;
+  {
+    int centre = -1;
+    for (int t = 0; t < p.ntaps; ++t)
+      if (p.taps[t].dy == 0 && p.taps[t].dx == 0) centre = t;
+    const bool swap = p.Cout <= 4 && p.Cin >= 16 && p.isy == 1 && p.isx == 1 && p.up_shift == 0 && p.H == p.OH && p.W == p.OW &&
+                      p.ya == nullptr && centre >= 0 && !getenv("UDET_NO_WSWAP");
+    if (swap) {
+      g.x = p.dy; g.ldx = p.ldy; g.x_coff = p.y_coff; g.Cin = p.Cout;
+      g.dy = p.x; g.ldy = p.ldx; g.y_coff = p.x_coff; g.Cout = p.Cin;
+      for (int t = 0; t < p.ntaps; ++t) { g.taps[t].dy = -p.taps[t].dy; g.taps[t].dx = -p.taps[t].dx; }
+      g.swapped = 1;
+      g.bias_m = centre * 4;
+    }
+  }
   const int BM = 128;
-  const int bn = p.Cout > 64 ? 128 : (p.Cout > 32 ? 64 : 32);
-  p.Cin4 = (p.Cin + 3) & ~3;
-  const int Mreal = p.ntaps * p.Cin4;
-  const int m_tiles = Mreal > 0 ? (Mreal + BM - 1) / BM : 1, co_tiles = (p.Cout + bn - 1) / bn;
-  p.Mpad = m_tiles * BM;
+  const int bn = g.Cout > 64 ? 128 : (g.Cout > 32 ? 64 : 32);
+  g.Cin4 = (g.Cin + 3) & ~3;
+  const int Mreal = g.ntaps * g.Cin4;
+  const int m_tiles = Mreal > 0 ? (Mreal + BM - 1) / BM : 1, co_tiles = (g.Cout + bn - 1) / bn;
+  g.Mpad = m_tiles * BM;
   const int ldn = co_tiles * bn;
-  const long Q = (long)p.N * p.OH * p.OW;
+  const long Q = (long)g.N * g.OH * g.OW;
   const int nchunks = (int)((Q + 31) / 32);
-  p.fd_ohw = make_fastdiv((unsigned)(p.OH * p.OW));
-  p.fd_ow = make_fastdiv((unsigned)p.OW);
+  g.fd_ohw = make_fastdiv((unsigned)(g.OH * g.OW));
+  g.fd_ow = make_fastdiv((unsigned)g.OW);
   float* pd = p.partial;                                 // [BND_SPLIT][Cout]
   float* base = pd + (size_t)BND_SPLIT * p.Cout;
   base += (16 - ((uintptr_t)base / sizeof(float)) % 16) % 16;  // keep the slabs 64-byte aligned
   const size_t fixed = (size_t)(base - p.partial);
-  const size_t per_split = (size_t)ldn + (size_t)p.Mpad * ldn;
+  const size_t per_split = (size_t)ldn + (size_t)g.Mpad * ldn;
   if (p.partial_floats < fixed + per_split) {
     set_error("wgrad: workspace too small (%zu < %zu floats)", p.partial_floats, fixed + per_split);
     return UDET_ERR_ARG;
@@ -427,12 +471,12 @@ int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream) {
   if (nsplit < 1) nsplit = 1;
   const size_t wsz = (size_t)T * p.Cin * p.Cout;
   if (p.ntaps < T) UDET_HIP(hipMemsetAsync(p.dw, 0, wsz * sizeof(float), stream));  // culled taps have zero gradient
-  const long total = (long)(Mreal + 1) * p.Cout;
+  const long total = (long)(Mreal + 1) * g.Cout;
   const bool dma_ok = p.ya == nullptr && p.zero16 != nullptr && !(reinterpret_cast<uintptr_t>(p.zero16) & 15);
   auto run = [&](int cfg) {
     const int ns = cfg & 0xfffff;
     const bool dma = dma_ok && (cfg >> 20) != 0;
-    WgradParams q = p;
+    WgradParams q = g;
     q.pbias = base;                              // [ns][ldn]
     q.partial = base + (size_t)ns * ldn;        // [ns][Mpad][ldn]
     if (bn == 128) wgrad_launch<128, 128, 2, 2>(q, m_tiles, co_tiles, ns, dma, stream);
@@ -447,7 +491,7 @@ int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream) {
   };
   // autotuned split count (see conv_igemm.hip): kernel + reduction timed together
   {
-    const int f[] = {p.N, p.H, p.W, p.up_shift, p.Cin, p.Cout, p.ntaps, p.OH, p.OW, p.isy, p.ya ? 1 : 0, p.ldx, p.ldy, cap, dma_ok ? 1 : 0};
+    const int f[] = {p.N, p.H, p.W, p.up_shift, p.Cin, p.Cout, p.ntaps, p.OH, p.OW, p.isy, p.ya ? 1 : 0, p.ldx, p.ldy, cap, dma_ok ? 1 : 0, g.swapped};
     uint64_t key = 1469598103934665603ull;
     for (int v : f) { key ^= (uint64_t)(uint32_t)v; key *= 1099511628211ull; }
     bool have = false;
