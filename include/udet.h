@@ -132,6 +132,9 @@ int udet_forward(udet_plan* plan, const float* img1, const float* img2, int ncal
  * img1/img2 must stay valid until that join.  One prefetch may be pending at a time. */
 int udet_prefetch_flow(udet_plan* plan, const float* img1, const float* img2, void* workspace, void* stream);
 int udet_forward_prefetched(udet_plan* plan, int ncalls, void* workspace, void* stream);
+/* the first half of udet_forward_prefetched alone (join + staging -> "image"/"flow"); follow it with the NEXT
+ * udet_prefetch_flow and then udet_forward_from_flow: the next pair's PWC flow then also overlaps this step's forward */
+int udet_prefetch_consume(udet_plan* plan, void* workspace, void* stream);
 /* same but starting from caller-filled "image" and "flow" buffers (generator_net/recover_net surface, nets.py:4,45) */
 int udet_forward_from_flow(udet_plan* plan, int ncalls, void* workspace, void* stream);
 /* generator_net(images, flows) alone (models/nets.py:4-42): reads "image","flow", writes "mask" (flow standardisation

@@ -82,6 +82,9 @@ int udet_prefetch_flow(udet_plan* h, const float* img1, const float* img2, void*
   if (!img1 || !img2) { set_error("prefetch_flow: null image pointer"); return UDET_ERR_ARG; }
   return plan_prefetch(h->p, img1, img2, (float*)ws, (hipStream_t)stream);
 }
+int udet_prefetch_consume(udet_plan* h, void* ws, void* stream) {
+  return plan_prefetch_consume(h->p, (float*)ws, (hipStream_t)stream);
+}
 int udet_forward_prefetched(udet_plan* h, int ncalls, void* ws, void* stream) {
   if (ncalls < 0 || ncalls > 3) { set_error("forward: ncalls must be 0..3"); return UDET_ERR_ARG; }
   return plan_forward(h->p, nullptr, nullptr, ncalls, (float*)ws, (hipStream_t)stream, true);

@@ -112,6 +112,7 @@ int plan_forward(Plan* P, const float* img1, const float* img2, int ncalls, floa
 // PWC flow + resizes of the NEXT step's pair into staging buffers, on lanes 4/5, concurrent with whatever the caller
 // enqueues next (PWC-Net is frozen: adversarial_learner.py:211-214); consumed by plan_forward(.., prefetched=true)
 int plan_prefetch(Plan* P, const float* img1, const float* img2, float* ws, hipStream_t s);
+int plan_prefetch_consume(Plan* P, float* ws, hipStream_t s);
 int plan_generator_forward(Plan* P, float* ws, hipStream_t s);
 int plan_recover_forward(Plan* P, int ncalls, float* ws, hipStream_t s, bool inputs_prepacked = false, bool skip_enc_a = false);
 int plan_losses(Plan* P, float* ws, hipStream_t s);

@@ -468,21 +468,27 @@ int plan_losses(Plan* P, float* ws, hipStream_t s) {
                        c.batch, c.cbn, c.epsilon, (float)(c.img_w * c.img_h * c.batch), sm + 8192, sm, sm + 16, sm + 1024, s);
 }
 
+// join the pending prefetch and move its staging buffers into "flow" / "image"
+int plan_prefetch_consume(Plan* P, float* ws, hipStream_t s) {
+  if (!P->prefetch_pending) {
+    set_error("forward_prefetched: no udet_prefetch_flow is pending");
+    return UDET_ERR_ARG;
+  }
+  (void)hipStreamWaitEvent(s, P->prefetch_ev, 0);
+  P->prefetch_pending = false;
+  const Buf &fn = P->buf(P->bid("flow.next")), &in = P->buf(P->bid("image.next"));
+  UDET_HIP(hipMemcpyAsync(ws + P->buf(P->bid("flow")).off, ws + fn.off, fn.floats() * sizeof(float), hipMemcpyDeviceToDevice, s));
+  UDET_HIP(hipMemcpyAsync(ws + P->buf(P->bid("image")).off, ws + in.off, in.floats() * sizeof(float), hipMemcpyDeviceToDevice, s));
+  return UDET_OK;
+}
+
 // adversarial_learner.py:83-204.  Lane 1 carries the image branch (image resize, recover encoder A) beside
 // PWC-Net and the generator on the caller's stream.
 int plan_forward(Plan* P, const float* img1, const float* img2, int ncalls, float* ws, hipStream_t s, bool prefetched) {
   P->ev_next = 0;
   const Lane L0 = lane_of(P, s, 0), LI = lane_of(P, s, 1);
   if (prefetched) {
-    if (!P->prefetch_pending) {
-      set_error("forward_prefetched: no udet_prefetch_flow is pending");
-      return UDET_ERR_ARG;
-    }
-    (void)hipStreamWaitEvent(s, P->prefetch_ev, 0);
-    P->prefetch_pending = false;
-    const Buf &fn = P->buf(P->bid("flow.next")), &in = P->buf(P->bid("image.next"));
-    UDET_HIP(hipMemcpyAsync(ws + P->buf(P->bid("flow")).off, ws + fn.off, fn.floats() * sizeof(float), hipMemcpyDeviceToDevice, s));
-    UDET_HIP(hipMemcpyAsync(ws + P->buf(P->bid("image")).off, ws + in.off, in.floats() * sizeof(float), hipMemcpyDeviceToDevice, s));
+    UDET_TRY(plan_prefetch_consume(P, ws, s));
     img1 = img2 = nullptr;
   }
   order_after(P, L0, LI);

@@ -38,6 +38,7 @@ for _n, _a in (("udet_pack_pwc", [c_p, c_p, c_p, c_p]), ("udet_pack_trainable", 
                ("udet_forward_from_flow", [c_p, c_i, c_p, c_p]), ("udet_generator_forward", [c_p, c_p, c_p]),
                ("udet_recover_forward", [c_p, c_i, c_p, c_p]),
                ("udet_prefetch_flow", [c_p, c_p, c_p, c_p, c_p]), ("udet_forward_prefetched", [c_p, c_i, c_p, c_p]),
+               ("udet_prefetch_consume", [c_p, c_p, c_p]),
                ("udet_backward", [c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
                ("udet_apply", [c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
                ("udet_train_step", [c_p, c_i] + [c_p] * 12)):
@@ -146,6 +147,15 @@ class Engine:
         is enqueued next.  Keep img1/img2 alive until forward_prefetched()."""
         self._prefetch_keep = (img1, img2)
         check(lib.udet_prefetch_flow(self._h, _ptr(img1), _ptr(img2), self.ws.data_ptr(), self._stream()))
+
+    def prefetch_consume(self):
+        """join the pending prefetch and move its flow / image into place (then: prefetch_flow(next), forward_in_place())"""
+        check(lib.udet_prefetch_consume(self._h, self.ws.data_ptr(), self._stream()))
+        self._prefetch_keep = None
+
+    def forward_in_place(self, ncalls=3):
+        """generator + recover forward + losses from the "image" / "flow" buffers as they are"""
+        check(lib.udet_forward_from_flow(self._h, ncalls, self.ws.data_ptr(), self._stream()))
 
     def forward_prefetched(self, ncalls=3):
         check(lib.udet_forward_prefetched(self._h, ncalls, self.ws.data_ptr(), self._stream()))

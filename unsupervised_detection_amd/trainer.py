@@ -57,13 +57,17 @@ def train_step(st: TrainState, img1, img2, which: int = BOTH, group=None, next_p
         p1, p2 = st._prefetched
         if p1.data_ptr() != img1.data_ptr() or p2.data_ptr() != img2.data_ptr():
             raise ValueError("train_step: this step's pair is not the one prefetched by the previous call")
-        e.forward_prefetched(3)
+        e.prefetch_consume()
         st._prefetched = None
+        if next_pair is not None:  # fork the next pair's PWC flow here: it then overlaps this step's forward as well
+            e.prefetch_flow(next_pair[0], next_pair[1])
+            st._prefetched = (next_pair[0], next_pair[1])
+        e.forward_in_place(3)
     else:
         e.forward(img1, img2, 3)
-    if next_pair is not None:
-        e.prefetch_flow(next_pair[0], next_pair[1])
-        st._prefetched = (next_pair[0], next_pair[1])
+        if next_pair is not None:
+            e.prefetch_flow(next_pair[0], next_pair[1])
+            st._prefetched = (next_pair[0], next_pair[1])
     # one call: with BOTH the two backward passes run concurrently on the plan's side streams (udet_backward)
     e.backward(which, st.w_gen, st.w_rec, st.g_gen, st.g_rec)
     works = []
