@@ -740,7 +740,8 @@ static ConvCfg tune_cfg(ConvParams& p, hipStream_t stream) {
   ConvCfg best = h;
   float best_ms = 1e30f;
   for (auto& c : cand) {
-    const float ms = time_cfg(p, c, 3, stream);
+    float ms = time_cfg(p, c, 3, stream);
+    if (ms < best_ms * 1.15f && ms < 0.25f) ms = 0.5f * (ms + time_cfg(p, c, 6, stream));  // short launches: re-time the contenders
     if (ms < best_ms) { best_ms = ms; best = c; }
   }
   ConvCfg alt = best;
