@@ -53,6 +53,14 @@ int udet_cost_volume(const float* c1, const float* warp, float* out, int n, int 
 int udet_resize_bilinear_legacy_fwd(const float* x, float* y, int n, int h, int w, int c, int oh, int ow, void* stream);
 int udet_resize_bilinear_legacy_bwd(const float* dy, float* dx, int n, int h, int w, int c, int oh, int ow, void* stream);
 
+/* Evaluation tail ("next" row N2): the per-sample sums behind compute_boundary_score / disambiguate_forw_back /
+ * tf_iou_computation / compute_all_IoU (models/utils/general_utils.py:89-159) and compute_IoU / compute_mae
+ * (test_generator.py:19-40).  pred_masks, gt_masks [n,h,w,1] device float32; stats8 [n][8] device doubles =
+ * {border sum (two-pixel strips, corners twice), |pred|, |gt|, |pred & gt|, sum pred*|gt-1|, sum (1-pred)*|gt|,
+ *  sum (1-pred)*|gt-1|, sum pred*|gt|} with pred = mask > threshold, gt = gt_mask > gt_threshold. */
+int udet_mask_stats(const float* pred_masks, const float* gt_masks, int n, int h, int w, float threshold, float gt_threshold,
+                    double* stats8, void* stream);
+
 /* tf.nn.conv2d / tf.layers.conv2d, padding='SAME', + bias + activation
  * (models/utils/convolution_utils.py:46,81-84; models/PWCNet/model_pwcnet.py:161-165,484-504,562-574).
  * upsample2x != 0 first applies tf.image.resize_nearest_neighbor(x2, align_corners=True)

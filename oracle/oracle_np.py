@@ -165,3 +165,46 @@ def cost_volume(c1, warp, r=4):
                     out[:, y, x, dy * d + dx] = (c1[:, y, x].astype(np.float64) *
                                                  warp[:, yy, xx].astype(np.float64)).sum(-1) / c
     return np.where(out > 0, out, 0.1 * out)
+
+
+# --------------------------------------------------------------------------
+# evaluation tail
+# --------------------------------------------------------------------------
+def compute_boundary_score(segmentation):
+    """models/utils/general_utils.py:122-138: fraction of the four 2-pixel image borders covered by the mask (the
+    corner pixels are counted by both the horizontal and the vertical strips, numerator and denominator alike)."""
+    seg = np.asarray(segmentation).astype(np.float64)
+    h, w = seg.shape[0], seg.shape[1]
+    up, bottom, left, right = seg[0:2, :], seg[h - 2:h, :], seg[:, 0:2], seg[:, w - 2:w]
+    return (up.sum() + bottom.sum() + left.sum() + right.sum()) / float(up.size + bottom.size + left.size + right.size)
+
+
+def compute_IoU(gt_mask, pred_mask_f, threshold=0.1, mask_threshold=0.6):
+    """test_generator.py:19-35: threshold the soft mask, flip it when it covers the image borders (>= mask_threshold),
+    IoU against the boolean ground truth; 1 when both are empty.  Returns (iou, annotation) like the reference (a
+    bare 1 in the empty/empty case)."""
+    gt = np.asarray(gt_mask).astype(bool)
+    pred = np.asarray(pred_mask_f) > threshold
+    annotation = pred if compute_boundary_score(pred) < mask_threshold else np.logical_not(pred)
+    if np.isclose(np.sum(annotation), 0) and np.isclose(np.sum(gt), 0):
+        return 1
+    return np.sum(annotation & gt) / np.sum(annotation | gt, dtype=np.float32), annotation
+
+
+def compute_mae(gt_mask, pred_mask_f):
+    """test_generator.py:38-40."""
+    return np.mean(np.abs(np.asarray(gt_mask, dtype=np.float64) - np.asarray(pred_mask_f, dtype=np.float64)))
+
+
+def compute_all_IoU(pred_masks, gt_masks, threshold=0.1, border_th=0.6, epsilon=1e-8):
+    """general_utils.py:89-120,140-159 (the TF graph used for the validation IoU, adversarial_learner.py:135-139):
+    gt > 0.01, mask > threshold, flipped when its border score >= 0.6, IoU = |and| / (|or| + 1e-8) per sample."""
+    pred = (np.asarray(pred_masks) > threshold).astype(np.float32)
+    gt = np.asarray(gt_masks) > 0.01
+    out = np.zeros(pred.shape[0], np.float64)
+    for b in range(pred.shape[0]):
+        fg = compute_boundary_score(pred[b]) < border_th
+        obj = pred[b] if fg else 1.0 - pred[b]
+        ob = obj.astype(bool)
+        out[b] = np.logical_and(gt[b], ob).sum() / (np.logical_or(gt[b], ob).sum() + epsilon)
+    return out

@@ -66,6 +66,12 @@ int udet_resize_bilinear_legacy_bwd(const float* dy, float* dx, int n, int h, in
   return launch_resize_bilinear_bwd(dy, c, 0, n, oh, ow, dx, c, 0, h, w, c, 0, (hipStream_t)stream);
 }
 
+int udet_mask_stats(const float* pred_masks, const float* gt_masks, int n, int h, int w, float threshold, float gt_threshold,
+                    double* stats8, void* stream) {
+  if (n < 1 || h < 4 || w < 4 || !pred_masks || !gt_masks || !stats8) { set_error("mask_stats: bad argument"); return UDET_ERR_ARG; }
+  return launch_mask_stats(pred_masks, gt_masks, n, h, w, threshold, gt_threshold, stats8, (hipStream_t)stream);
+}
+
 size_t udet_conv2d_workspace_bytes(int n, int h, int w, int cin, int cout, int kh, int kw, int upsample2x) {
   const int kc = round_up(cin > cout ? cin : cout, 8), ldw = round_up(cin > cout ? cin : cout, 4);
   const size_t pix_in = (size_t)n * h * w, pix_out = pix_in * (upsample2x ? 4 : 1);

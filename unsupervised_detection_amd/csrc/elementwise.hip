@@ -529,6 +529,45 @@ int launch_fill_uniform(float* x, long n, uint64_t seed, float lo, float hi, hip
   UDET_HIP(hipGetLastError());
   return UDET_OK;
 }
+// ---------------------------------------------------------------------------
+// evaluation tail (models/utils/general_utils.py:89-159, test_generator.py:19-40): everything both IoU variants and
+// the MAE need, per sample, in one pass:  out[n][8] = {border sum, |pred|, |gt|, |pred & gt|,
+//   sum pred*|gt-1|, sum (1-pred)*|gt|, sum (1-pred)*|gt-1|, sum pred*|gt|}   with pred = mask > threshold,
+// gt = gt_mask > gt_threshold; the border sum adds the two top / bottom rows and the two left / right columns
+// (corner pixels twice, like the reference's four overlapping strips).  Counts are exact (double accumulation).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void mask_stats_kernel(const float* __restrict__ pred, const float* __restrict__ gt, int H, int W,
+                                                         float threshold, float gt_threshold, double* __restrict__ out) {
+  __shared__ double sm[4];
+  const int n = blockIdx.x;
+  const long HW = (long)H * W;
+  double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (long q = threadIdx.x; q < HW; q += 256) {
+    const int y = (int)(q / W), x = (int)(q - (long)y * W);
+    const float g = gt[n * HW + q];
+    const bool pr = pred[n * HW + q] > threshold, gb = g > gt_threshold;
+    const int strips = (y < 2) + (y >= H - 2) + (x < 2) + (x >= W - 2);
+    const double a1 = fabs((double)g - 1.0), a0 = fabs((double)g);
+    if (pr) {
+      v[0] += strips; v[1] += 1.0; v[4] += a1; v[7] += a0;
+      if (gb) v[3] += 1.0;
+    } else {
+      v[5] += a0; v[6] += a1;
+    }
+    if (gb) v[2] += 1.0;
+  }
+  for (int k = 0; k < 8; ++k) {
+    const double s = block_sum(v[k], sm);
+    if (threadIdx.x == 0) out[(long)n * 8 + k] = s;
+    __syncthreads();
+  }
+}
+int launch_mask_stats(const float* pred, const float* gt, int N, int H, int W, float threshold, float gt_threshold, double* out,
+                      hipStream_t s) {
+  hipLaunchKernelGGL(mask_stats_kernel, dim3(N), dim3(256), 0, s, pred, gt, H, W, threshold, gt_threshold, out);
+  UDET_HIP(hipGetLastError());
+  return UDET_OK;
+}
 int launch_adam(float* w, float* g, float* m, float* v, long n, float lr_t, float b1, float b2, float eps, float clip,
                 const float* flag, uint64_t seed, uint64_t step, hipStream_t s) {
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, s, w, g, m, v, n, lr_t, b1, b2, eps, clip, flag, seed,

@@ -114,10 +114,38 @@ class AdversarialLearner(object):
                     print("-------------------------------")
                     break
 
+    def validation_iou(self, source, n_steps=None):
+        """Sum of compute_all_IoU over the validation batches / (steps * batch_size) (:422-433, :135-139): the test
+        graph's generator on each pair, disambiguated masks against gt > 0.01."""
+        from .evaluation import compute_all_IoU
+        e = self.engine
+        total, steps = 0.0, 0
+        for batch in source:
+            if n_steps is not None and steps >= n_steps:
+                break
+            if batch.get("gt_mask") is None:
+                continue
+            e.forward(batch["img1"], batch["img2"], 0)
+            total += float(compute_all_IoU(e.buffer("mask").contiguous(), batch["gt_mask"].contiguous()).sum())
+            steps += 1
+        return total / max(steps * self.config.batch_size, 1)
+
     def epoch_end_callback(self, epoch_num):
-        """Checkpointing of :443-448 (trainable variables only; Adam slots are not saved by the reference)."""
+        """:422-448: validation IoU over `config.val_source` (when given), 'best' checkpoint when it improves, periodic
+        checkpoint every save_freq epochs (trainable variables only; Adam slots are not saved by the reference)."""
         import os
         ckdir = getattr(self.config, "checkpoint_dir", "")
+        val_source = getattr(self.config, "val_source", None)
+        if val_source is not None:
+            print("\nComputing Validation IoU")
+            viou = self.validation_iou(val_source, getattr(self, "val_steps_per_epoch", None))
+            print("Epoch [{}] Validation IoU: {}".format(epoch_num, viou))
+            self.last_val_iou = viou
+            if viou > getattr(self, "min_val_iou", -1.0e12):
+                if ckdir:
+                    os.makedirs(ckdir, exist_ok=True)
+                    self.save(ckdir, "best")
+                self.min_val_iou = viou
         if ckdir and epoch_num % getattr(self.config, "save_freq", 5) == 0:
             os.makedirs(ckdir, exist_ok=True)
             self.save(ckdir, epoch_num)
