@@ -53,6 +53,14 @@ int udet_cost_volume(const float* c1, const float* warp, float* out, int n, int 
 int udet_resize_bilinear_legacy_fwd(const float* x, float* y, int n, int h, int w, int c, int oh, int ow, void* stream);
 int udet_resize_bilinear_legacy_bwd(const float* dy, float* dx, int n, int h, int w, int c, int oh, int ow, void* stream);
 
+/* Input stage ("next" row N1): the readers' per-image pipeline in one pass -- optional uint8 -> v/div + add
+ * (preprocess_image / preprocess_mask, data/davis2016_data_utils.py:86-99; identical in fbms_/segtrackv2_data_utils.py),
+ * flip (data/aug_flips.py:3-16), crop window (tf.random_crop :101-127 / tf.image.central_crop :129-133), TF-1.13
+ * legacy bilinear or nearest-neighbour resize (tf.image.resize_images) to [oh,ow].  src [n,h,w,c] uint8 or float32,
+ * dst [n,oh,ow,c] float32, params6 device int32 [n][6] = {y0, x0, crop_h, crop_w, flip_lr, flip_td} or NULL. */
+int udet_crop_flip_resize(const void* src, int src_is_u8, int nearest, int n, int h, int w, int c, const int* params6,
+                          float* dst, int oh, int ow, float div, float add, void* stream);
+
 /* Evaluation tail ("next" row N2): the per-sample sums behind compute_boundary_score / disambiguate_forw_back /
  * tf_iou_computation / compute_all_IoU (models/utils/general_utils.py:89-159) and compute_IoU / compute_mae
  * (test_generator.py:19-40).  pred_masks, gt_masks [n,h,w,1] device float32; stats8 [n][8] device doubles =

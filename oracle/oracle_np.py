@@ -208,3 +208,71 @@ def compute_all_IoU(pred_masks, gt_masks, threshold=0.1, border_th=0.6, epsilon=
         ob = obj.astype(bool)
         out[b] = np.logical_and(gt[b], ob).sum() / (np.logical_or(gt[b], ob).sum() + epsilon)
     return out
+
+
+# --------------------------------------------------------------------------
+# input stage
+# --------------------------------------------------------------------------
+def resize_nearest_legacy(x, oh, ow):
+    """TF-1.13 ResizeNearestNeighbor, align_corners=False: in = min(floor(out * in/out), in-1)
+    (preprocess_mask: data/davis2016_data_utils.py:93-99)."""
+    n, h, w, c = x.shape
+    y = np.empty((n, oh, ow, c), x.dtype)
+    sy, sx = f32(h) / f32(oh), f32(w) / f32(ow)
+    for i in range(oh):
+        yi = min(int(np.floor(f32(i) * sy)), h - 1)
+        for j in range(ow):
+            xi = min(int(np.floor(f32(j) * sx)), w - 1)
+            y[:, i, j] = x[:, yi, xi]
+    return y
+
+
+def central_crop_box(h, w, frac):
+    """tf.image.central_crop (TF 1.13): start = int((size - size*frac)/2), extent = size - 2*start
+    (data/davis2016_data_utils.py:129-133)."""
+    if frac >= 1.0:
+        return 0, 0, h, w
+    y0, x0 = int((h - h * frac) / 2), int((w - w * frac) / 2)
+    return y0, x0, h - 2 * y0, w - 2 * x0
+
+
+def preprocess_image(img_u8, oh=384, ow=640):
+    """data/davis2016_data_utils.py:86-91: cast / 255 - 0.5, then legacy bilinear resize."""
+    x = img_u8.astype(f32) / f32(255.0) - f32(0.5)
+    return resize_bilinear_legacy(x, oh, ow)
+
+
+def preprocess_mask(mask_u8, oh=384, ow=640):
+    """data/davis2016_data_utils.py:93-99: cast / 255, nearest-neighbour resize."""
+    return resize_nearest_legacy(mask_u8.astype(f32) / f32(255.0), oh, ow)
+
+
+def flip_crop_resize(x, y0, x0, ch, cw, flip_lr, flip_td, nearest=False):
+    """flip (data/aug_flips.py:3-16), crop window, resize back to the input size
+    (random_crop_image_pair :101-127 / central_cropping :129-133)."""
+    n, h, w, c = x.shape
+    if flip_td:
+        x = x[:, ::-1]
+    if flip_lr:
+        x = x[:, :, ::-1]
+    crop = np.ascontiguousarray(x[:, y0:y0 + ch, x0:x0 + cw])
+    return resize_nearest_legacy(crop, h, w) if nearest else resize_bilinear_legacy(crop, h, w)
+
+
+def pair_table(seq_lengths, t_len, training):
+    """The (frame index, direction) table of image_inputs (:196-214) / test_inputs (:252-276): forward pairs from the first
+    frames, backward pairs from the last ones, over the concatenated sequences."""
+    first, last, n = [], [], 0
+    for ln in seq_lengths:
+        if training:
+            last.append(np.arange(n + t_len, n + ln))
+            first.append(np.arange(n, n + ln - t_len))
+        elif t_len < 0:
+            last.append(np.arange(n + abs(t_len), n + ln))
+            first.append(np.arange(n, n + abs(t_len)))
+        else:
+            first.append(np.arange(n, n + ln - t_len))
+            last.append(np.arange(n + ln - t_len, n + ln))
+        n += ln
+    first, last = np.concatenate(first), np.concatenate(last)
+    return np.vstack([np.stack([first, np.ones_like(first)], 1), np.stack([last, -np.ones_like(last)], 1)]).astype(np.float32)

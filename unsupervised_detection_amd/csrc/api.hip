@@ -66,6 +66,12 @@ int udet_resize_bilinear_legacy_bwd(const float* dy, float* dx, int n, int h, in
   return launch_resize_bilinear_bwd(dy, c, 0, n, oh, ow, dx, c, 0, h, w, c, 0, (hipStream_t)stream);
 }
 
+int udet_crop_flip_resize(const void* src, int src_is_u8, int nearest, int n, int h, int w, int c, const int* params6,
+                          float* dst, int oh, int ow, float div, float add, void* stream) {
+  if (n < 1 || h < 1 || w < 1 || c < 1 || oh < 1 || ow < 1 || !src || !dst) { set_error("crop_flip_resize: bad argument"); return UDET_ERR_ARG; }
+  return launch_crop_flip_resize(src, src_is_u8, nearest, n, h, w, c, params6, dst, oh, ow, div, add, (hipStream_t)stream);
+}
+
 int udet_mask_stats(const float* pred_masks, const float* gt_masks, int n, int h, int w, float threshold, float gt_threshold,
                     double* stats8, void* stream) {
   if (n < 1 || h < 4 || w < 4 || !pred_masks || !gt_masks || !stats8) { set_error("mask_stats: bad argument"); return UDET_ERR_ARG; }

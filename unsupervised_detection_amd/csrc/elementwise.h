@@ -25,6 +25,8 @@ int launch_grad_absmean(const float* g, const long* seg_off, const long* seg_len
                         float* out, hipStream_t s);
 int launch_adam(float* w, float* g, float* m, float* v, long n, float lr_t, float b1, float b2, float eps, float clip,
                 const float* flag, uint64_t seed, uint64_t step, hipStream_t s);
+int launch_crop_flip_resize(const void* src, int src_u8, int nearest, int N, int H, int W, int C, const int* prm, float* dst, int OH,
+                            int OW, float div, float add, hipStream_t s);
 int launch_mask_stats(const float* pred, const float* gt, int N, int H, int W, float threshold, float gt_threshold, double* out,
                       hipStream_t s);
 int launch_fill_uniform(float* x, long n, uint64_t seed, float lo, float hi, hipStream_t s);

@@ -69,6 +69,62 @@ __global__ __launch_bounds__(256) void resize_bilinear_fwd_kernel(const float* _
     y[pix * ldy + y_coff + c] = v;
   }
 }
+// ---------------------------------------------------------------------------
+// Input stage ("next" row N1): the readers' per-image pipeline fused into one pass --
+//   [uint8 -> v/div + add]  (preprocess_image / preprocess_mask: data/davis2016_data_utils.py:86-99)
+//   flip (left-right / top-down: data/aug_flips.py:3-16)  ->  crop window (tf.random_crop / tf.image.central_crop:
+//   :101-133)  ->  legacy bilinear or nearest-neighbour resize to (OH, OW)  (tf.image.resize_images).
+// prm[n] = {y0, x0, crop_h, crop_w, flip_lr, flip_td} per sample (null: whole image, no flip).  The conversion is
+// applied to every tap BEFORE interpolation, as the reference converts before it resizes (same float32 op order).
+// ---------------------------------------------------------------------------
+template <typename T, int NEAREST>
+__global__ __launch_bounds__(256) void crop_flip_resize_kernel(const T* __restrict__ src, int N, int H, int W, int C,
+                                                               const int* __restrict__ prm, float* __restrict__ dst, int OH, int OW,
+                                                               float div, float add) {
+  const long total = (long)N * OH * OW * C;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int c = (int)(e % C);
+    const long pix = e / C;
+    const int ox = (int)(pix % OW), oy = (int)((pix / OW) % OH), n = (int)(pix / ((long)OW * OH));
+    int y0 = 0, x0 = 0, ch = H, cw = W, flr = 0, ftd = 0;
+    if (prm) { y0 = prm[n * 6]; x0 = prm[n * 6 + 1]; ch = prm[n * 6 + 2]; cw = prm[n * 6 + 3]; flr = prm[n * 6 + 4]; ftd = prm[n * 6 + 5]; }
+    const float sy = (float)ch / (float)OH, sx = (float)cw / (float)OW;
+    auto tap = [&](int cy, int cx) -> float {
+      int yy = y0 + cy, xx = x0 + cx;
+      if (ftd) yy = H - 1 - yy;
+      if (flr) xx = W - 1 - xx;
+      float v = (float)src[(((long)n * H + yy) * W + xx) * C + c];
+      if (div != 1.f) v = v / div;
+      return v + add;
+    };
+    float v;
+    if (NEAREST) {  // ResizeNearestNeighbor, align_corners=False: min(floor(i*scale), in-1)
+      const int cy = min((int)floorf((float)oy * sy), ch - 1), cx = min((int)floorf((float)ox * sx), cw - 1);
+      v = tap(cy, cx);
+    } else {
+      int ly, hy, lx, hx;
+      float ty, tx;
+      legacy_coord(oy, sy, ch, ly, hy, ty);
+      legacy_coord(ox, sx, cw, lx, hx, tx);
+      const float tl = tap(ly, lx), tr = tap(ly, hx), bl = tap(hy, lx), br = tap(hy, hx);
+      const float top = tl + (tr - tl) * tx, bot = bl + (br - bl) * tx;
+      v = top + (bot - top) * ty;
+    }
+    dst[e] = v;
+  }
+}
+int launch_crop_flip_resize(const void* src, int src_u8, int nearest, int N, int H, int W, int C, const int* prm, float* dst, int OH,
+                            int OW, float div, float add, hipStream_t s) {
+  const long total = (long)N * OH * OW * C;
+  const dim3 g(grid_for(total, 8192)), b(256);
+  if (src_u8 && nearest) hipLaunchKernelGGL((crop_flip_resize_kernel<unsigned char, 1>), g, b, 0, s, (const unsigned char*)src, N, H, W, C, prm, dst, OH, OW, div, add);
+  else if (src_u8) hipLaunchKernelGGL((crop_flip_resize_kernel<unsigned char, 0>), g, b, 0, s, (const unsigned char*)src, N, H, W, C, prm, dst, OH, OW, div, add);
+  else if (nearest) hipLaunchKernelGGL((crop_flip_resize_kernel<float, 1>), g, b, 0, s, (const float*)src, N, H, W, C, prm, dst, OH, OW, div, add);
+  else hipLaunchKernelGGL((crop_flip_resize_kernel<float, 0>), g, b, 0, s, (const float*)src, N, H, W, C, prm, dst, OH, OW, div, add);
+  UDET_HIP(hipGetLastError());
+  return UDET_OK;
+}
+
 int launch_resize_bilinear_fwd(const float* x, int ldx, int x_coff, int N, int H, int W, float* y, int ldy, int y_coff,
                                int OH, int OW, int C, float mul, float div, hipStream_t s) {
   const long total = (long)N * OH * OW * C;

@@ -178,13 +178,7 @@ class AdversarialLearner(object):
 
     def _central_crop_resize(self, img, frac):
         """tf.image.central_crop + resize back to 384x640 (data/davis2016_data_utils.py:129-133,328-354)."""
-        n, h, w, c = img.shape
-        if frac >= 1.0:
-            return img
-        oy, ox = int((h - h * frac) / 2), int((w - w * frac) / 2)
-        crop = img[:, oy:h - oy, ox:w - ox].contiguous()
-        from . import ops
-        return ops.resize_bilinear_legacy(crop, h, w)
+        return _data.central_cropping(img, frac)
 
     def inference(self, sess=None):
         """Outputs a dictionary with the results of the required operations (:606-623).  `sess` is accepted and
