@@ -109,3 +109,31 @@ def test_evaluate_masks_report(monkeypatch):
     res = E.evaluate_masks(FakeLearner(), verbose=False)
     assert res["frames"] == 4 and res["dataset_iou"] == 1.0 and res["dataset_mae"] == 0.0
     assert set(res["category_iou"]) == {"bear", "camel"} and res["sequence_iou"] == 1.0
+
+
+@pytest.mark.gpu
+def test_ensemble_report_and_mat_buffers(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import scipy.io as sio
+    from unsupervised_detection_amd import evaluation as E
+
+    class FakeLearner:
+        test_crops = [0.9, 1.0]
+        test_samples = 2
+
+        def __init__(self):
+            self.k = 0
+
+        def inference(self, sess):
+            self.k += 1
+            g = np.zeros((16, 24, 1), np.float32); g[4:10, 6:14] = 1.0
+            outs = {"pred_masks": {c: g * 0.8 for c in self.test_crops}, "gt_masks": {c: g.copy() for c in self.test_crops},
+                    "img_1s": {c: np.zeros((16, 24, 3), np.float32) for c in self.test_crops}}
+            return {"outs": outs, "img_fname": b"fbms/cars1/%05d.jpg" % self.k}
+
+    res = E.evaluate_ensemble(FakeLearner(), save_dir=str(tmp_path), verbose=False)
+    assert res["frames"] == 2 and res["dataset_iou"] == 1.0 and res["category_iou"] == {"cars1": 1.0}
+    m = sio.loadmat(str(tmp_path / "cars1" / "result_2.mat"))
+    assert {"img_1_090", "pred_mask_090", "gt_mask_090", "img_1_100", "pred_mask_100", "gt_mask_100"} <= set(m)
+    assert m["pred_mask_100"].sum() == 48

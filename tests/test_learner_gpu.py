@@ -87,3 +87,24 @@ def test_functional_surface_matches_oracle(gpu):
     pred = hp.recover_net(image.cuda(), fm.cuda(), mref.cuda(), scope="FlownetS/").cpu()
     ref = O.recover_net(pr, image, fm, mref)
     assert (pred - ref).abs().max() < 1e-3 * max(1.0, float(ref.abs().max()))
+
+
+def test_cli_entry_points_run_on_synthetic_data(gpu, monkeypatch, capsys):
+    """train / test_generator / test_generator_ensemble with the reference's flags; no dataset under --root_dir ->
+    synthetic pairs.  The training loop runs pipelined (one batch of look-ahead) with a validation pass per epoch."""
+    from unsupervised_detection_amd import cli
+    from unsupervised_detection_amd import learner as Lr
+    monkeypatch.setattr(Lr, "_engine_config", lambda config, batch=None, in_hw=(128, 192): Lr.EngineConfig(
+        batch_size=batch or config.batch_size, in_height=128, in_width=192, img_height=config.img_height, img_width=config.img_width))
+    monkeypatch.setattr(Lr._data, "synthetic_davis_pairs", lambda b, seed, h=128, w=192, max_disp=8.0:
+                        tuple(np.random.default_rng(seed + k).integers(0, 255, (b, 128, 192, 3), dtype=np.uint8) for k in (0, 1)))
+    monkeypatch.setattr(Lr._data, "READER_H", 128)
+    monkeypatch.setattr(Lr._data, "READER_W", 192)
+    monkeypatch.setattr(Lr._data, "preprocess_image", lambda f, out_h=128, out_w=192: Lr._data.crop_flip_resize(f, 128, 192, None, False, 255.0, -0.5))
+    common = ["--img_height", "64", "--img_width", "128", "--batch_size", "2", "--root_dir", "/nonexistent"]
+    assert cli.main(["train"] + common + ["--num_samples_train", "8", "--max_epochs", "1", "--summary_freq", "2"]) == 0
+    out = capsys.readouterr().out
+    assert "Training completed successfully" in out and "loss_generator" in out
+    assert cli.main(["test_generator"] + common) == 0
+    assert cli.main(["test_generator_ensemble"] + common) == 0
+    assert cli.main(["bogus"]) == 2

@@ -1,0 +1,81 @@
+"""Entry points with the reference's command-line flags (common_flags.py), for the three scripts that drive the hot path:
+
+  python -m unsupervised_detection_amd.cli train --dataset DAVIS2016 --root_dir ... [--flow_ckpt ...]        (train.py)
+  python -m unsupervised_detection_amd.cli test_generator --root_dir ... --ckpt_file ...                    (test_generator.py)
+  python -m unsupervised_detection_amd.cli test_generator_ensemble --root_dir ... --test_save_dir ...       (test_generator_ensemble.py)
+
+The TF-specific lines of the originals (tf.train.Saver / Supervisor, `train.py:19`, `test_generator.py:45-55`) have no
+counterpart; checkpoints are torch.save'd {tf_name: tensor} dicts.  Without a dataset under
+--root_dir the learner falls back to synthetic DAVIS-shaped pairs."""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+
+
+def _sources(flags, mode):
+    """data_source / val_source of the learner from the dataset flags (DAVIS2016 layout; adversarial_learner.py:45-70)."""
+    from . import data
+    root = getattr(flags, "root_dir", "")
+    if not (root and os.path.isfile(os.path.join(root, "ImageSets", "480p", "val.txt"))):
+        return
+    rd = data.Davis2016Reader(root, max_temporal_len=flags.max_temporal_len, min_temporal_len=flags.min_temporal_len,
+                              num_threads=flags.num_threads, seed=8964)
+    if mode == "train":
+        flags.data_source = rd.image_inputs(batch_size=flags.batch_size, partition=flags.train_partition, train_crop=flags.train_crop)
+
+        class _Val:
+            def __iter__(self_inner):
+                return iter(rd.test_inputs(batch_size=flags.batch_size, partition="val", t_len=1, test_crop=1.0))
+        flags.val_source = _Val()
+    elif mode == "test":
+        src = list(rd.test_inputs(batch_size=flags.batch_size, partition=flags.test_partition, t_len=flags.test_temporal_shift,
+                                  with_fname=True, test_crop=flags.test_crop))
+
+        class _S(list):
+            n = len(src)
+        flags.data_source = _S(src)
+    else:
+        src = list(rd.test_inputs(batch_size=1, partition=flags.test_partition, t_len=flags.test_temporal_shift, with_fname=True,
+                                  test_crop=1.0))
+
+        class _S(list):
+            n = len(src)
+        flags.data_source = _S(src)
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    if not argv or argv[0] not in ("train", "test_generator", "test_generator_ensemble"):
+        print(__doc__)
+        return 2
+    from .config import parse_flags
+    from .learner import AdversarialLearner
+    cmd, flags = argv[0], parse_flags(argv[1:])
+    np.random.seed(8964)  # train.py:18
+    learner = AdversarialLearner()
+    if cmd == "train":
+        _sources(flags, "train")
+        learner.train(flags)
+        return 0
+    if cmd == "test_generator":
+        if flags.ckpt_file:
+            flags.full_model_ckpt = flags.ckpt_file
+        _sources(flags, "test")
+        learner.setup_inference(flags, aug_test=False)
+        from .evaluation import evaluate_masks
+        evaluate_masks(learner)
+        return 0
+    if flags.ckpt_file:
+        flags.full_model_ckpt = flags.ckpt_file
+    _sources(flags, "ensemble")
+    learner.setup_inference(flags, aug_test=True)
+    from .evaluation import evaluate_ensemble
+    evaluate_ensemble(learner, save_dir=flags.test_save_dir if flags.generate_visualization else None)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -363,6 +363,7 @@ static int pwc_forward_on(Plan* P, const float* img1, const float* img2, float* 
 
 int plan_pwc_forward(Plan* P, const float* img1, const float* img2, float* ws, hipStream_t s) {
   P->ev_next = 0;
+  if (P->prefetch_pending) (void)hipStreamWaitEvent(s, P->prefetch_ev, 0);  // the prefetch owns the PWC buffers until it is done
   return pwc_forward_on(P, img1, img2, ws, lane_of(P, s, 0), lane_of(P, s, 2));
 }
 
@@ -490,6 +491,10 @@ int plan_forward(Plan* P, const float* img1, const float* img2, int ncalls, floa
   if (prefetched) {
     UDET_TRY(plan_prefetch_consume(P, ws, s));
     img1 = img2 = nullptr;
+  } else if (img1 && P->prefetch_pending) {
+    // a stand-alone forward (validation between training steps) while a prefetch is in flight: the prefetch owns the
+    // PWC buffers until it is done; its staged result stays valid for the next udet_prefetch_consume
+    (void)hipStreamWaitEvent(s, P->prefetch_ev, 0);
   }
   order_after(P, L0, LI);
   if (img1) UDET_TRY(plan_prepare_image(P, img1, "image", ws, LI.s));

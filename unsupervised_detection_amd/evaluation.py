@@ -122,8 +122,9 @@ def evaluate_masks(learner, n_steps=None, verbose=True):
             if verbose:
                 print("End of testing dataset")
             break
-        gm = torch.as_tensor(np.ascontiguousarray(inf["gt_masks"], dtype=np.float32)).cuda()
         pm = torch.as_tensor(np.ascontiguousarray(inf["gen_masks"], dtype=np.float32)).cuda()
+        gm = torch.zeros_like(pm) if inf["gt_masks"] is None else \
+            torch.as_tensor(np.ascontiguousarray(inf["gt_masks"], dtype=np.float32)).cuda()  # (synthetic data: no annotation)
         iou, mae, _ = evaluate_batch(gm, pm)
         for b in range(pm.shape[0]):
             name = inf["img_fname"][b]
@@ -145,5 +146,73 @@ def evaluate_masks(learner, n_steps=None, verbose=True):
             print("Category {}: IoU is {} and MAE is {}".format(cat, res["category_iou"][cat], res["category_mae"][cat]))
         print("The Average over the dataset: IoU is {} and MAE is {}".format(res["dataset_iou"], res["dataset_mae"]))
         print("The Average over sequences IoU is {}".format(res["sequence_iou"]))
+        print("Success: Processed {} frames".format(frames))
+    return res
+
+
+def evaluate_ensemble(learner, n_steps=None, save_dir=None, verbose=True):
+    """The loop of test_generator_ensemble.py:_test_masks (:20-125) over learner.inference() of the augmented graph:
+    per frame the IoU / MAE of every central crop are averaged; with `save_dir` the per-frame buffers the offline
+    post-processing reads are written as result_<k>.mat with the reference's keys (img_1_%03d, pred_mask_%03d,
+    gt_mask_%03d, :101-111).  Like the reference, the first frame of a category enters its list with the LAST crop's
+    score instead of the crop mean (:70-75)."""
+    import os
+    cat_iou, cat_mae = {}, {}
+    crops = learner.test_crops
+    if n_steps is None:
+        n_steps = int(learner.test_samples)
+    frames = 0
+    for _ in range(n_steps):
+        try:
+            inf = learner.inference(None)
+        except StopIteration:
+            if verbose:
+                print("End of testing dataset")
+            break
+        outs, fname = inf["outs"], inf["img_fname"]
+        c_iou, c_mae = [], []
+        iou = mae = 0.0
+        for crop in crops:
+            gt, pm = outs["gt_masks"][crop], outs["pred_masks"][crop]
+            if gt is None:  # synthetic data: no annotation
+                gt = outs["gt_masks"][crop] = np.zeros_like(np.asarray(pm), dtype=np.float32)
+            res = compute_IoU(gt_mask=gt, pred_mask_f=pm)
+            if isinstance(res, tuple):
+                iou, out_mask = res
+            else:  # both empty: the reference returns a bare 1 (and would fail to unpack it); score it as 1 / all-background
+                iou, out_mask = 1.0, np.zeros_like(np.asarray(pm), dtype=bool)
+            outs["pred_masks"][crop] = out_mask
+            mae = compute_mae(gt_mask=gt, pred_mask_f=out_mask)
+            c_iou.append(iou)
+            c_mae.append(mae)
+        name = fname.decode("utf-8") if isinstance(fname, (bytes, bytearray)) else str(fname)
+        parts = name.split("/")
+        category = parts[-2] if len(parts) > 1 else "all"
+        if category in cat_iou:
+            cat_iou[category].append(float(np.mean(c_iou)))
+            cat_mae[category].append(float(np.mean(c_mae)))
+        else:
+            cat_iou[category], cat_mae[category] = [float(iou)], [float(mae)]
+        if save_dir:
+            import scipy.io as sio
+            d = os.path.join(save_dir, category)
+            os.makedirs(d, exist_ok=True)
+            mat = {}
+            for crop in crops:
+                k = int(crop * 100)
+                mat["img_1_{:03d}".format(k)] = outs["img_1s"][crop]
+                mat["pred_mask_{:03d}".format(k)] = outs["pred_masks"][crop]
+                mat["gt_mask_{:03d}".format(k)] = outs["gt_masks"][crop]
+            sio.savemat(os.path.join(d, "result_{}.mat".format(len(cat_iou[category]))), mat)
+        frames += 1
+    tot_iou = sum(sum(v) for v in cat_iou.values())
+    tot_mae = sum(sum(v) for v in cat_mae.values())
+    res = {"category_iou": {k: float(np.mean(v)) for k, v in cat_iou.items()},
+           "category_mae": {k: float(np.mean(v)) for k, v in cat_mae.items()},
+           "dataset_iou": tot_iou / max(frames, 1), "dataset_mae": tot_mae / max(frames, 1), "frames": frames}
+    if verbose:
+        for cat in cat_iou:
+            print("Category {}: IoU is {} and MAE is {}".format(cat, res["category_iou"][cat], res["category_mae"][cat]))
+        print("The Average over the dataset: IoU is {} and MAE is {}".format(res["dataset_iou"], res["dataset_mae"]))
         print("Success: Processed {} frames".format(frames))
     return res

@@ -89,16 +89,20 @@ class AdversarialLearner(object):
         source = getattr(config, "data_source", None) or _SyntheticSource(B, max_steps)
         self.global_step = 0
         it = iter(source)
+        # cross-step pipelining (trainer.train_step): one batch of look-ahead, so that the frozen PWC-Net's flow of the
+        # next batch is computed beside this step's backward pass
+        nxt = next(it, None)
         for step in count(start=1):
-            try:
-                batch = next(it)
-            except StopIteration:
+            batch = nxt
+            if batch is None:
                 break
+            nxt = next(it, None) if step < max_steps else None
             start_time = time.time()
             if step % sum_iters == 0:
                 self.global_step += 1
             which = REC if (step % sum_iters) < iters_rec else GEN
-            train_step(self.state, batch["img1"], batch["img2"], which)
+            train_step(self.state, batch["img1"], batch["img2"], which,
+                       next_pair=None if nxt is None else (nxt["img1"], nxt["img2"]))
             if step % config.summary_freq == 0:
                 L = self.engine.losses()
                 train_epoch = math.ceil(step / self.train_steps_per_epoch)
