@@ -157,7 +157,7 @@ int udet_forward_from_flow(udet_plan* plan, int ncalls, void* workspace, void* s
  * of models/utils/flow_utils.py:5-12 included). */
 int udet_generator_forward(udet_plan* plan, void* workspace, void* stream);
 /* recover_net(img1, flow_masked, mask) alone (models/nets.py:45-110) on n*B samples whose inputs the caller packed into
- * "rec.imgin" ([.,.,.,8]: image, 0..) and "rec.fin" ([.,.,.,8]: flow_masked(2), 1, 1-mask, 0..); writes "pred". */
+ * "rec.imgin" ([.,.,.,4]: image, 0) and "rec.fin" ([.,.,.,4]: flow_masked(2), 1, 1-mask); writes "pred". */
 int udet_recover_forward(udet_plan* plan, int n, void* workspace, void* stream);
 /* optimizer.compute_gradients of losses['generator'] w.r.t. MaskNet and/or losses['recover'] w.r.t. FlownetS
  * (models/utils/loss_utils.py:18; adversarial_learner.py:211-234) into the flat gradient buffers. */

@@ -224,15 +224,14 @@ int launch_emit_du(const float* d, const float* a, float* u, long P, int ld, int
 }
 
 // ---------------------------------------------------------------------------
-// PWC input: x8[2B,H,W,8] = [img1+0.5 | img2+0.5 | 0..]   (model_pwcnet.py:39-56 adapt_x)
+// PWC input: x8[2B,H,W,4] = [img+0.5 (3) | 0] for the 2B stacked images   (model_pwcnet.py:39-56 adapt_x)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pack_pwc_input_kernel(const float* __restrict__ i1, const float* __restrict__ i2,
                                                              float* __restrict__ x8, long P) {
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < 2 * P; e += (long)gridDim.x * 256) {
     const float* s = e < P ? i1 + e * 3 : i2 + (e - P) * 3;
     float4 a = make_float4(s[0] + 0.5f, s[1] + 0.5f, s[2] + 0.5f, 0.f);
-    *reinterpret_cast<float4*>(x8 + e * 8) = a;
-    *reinterpret_cast<float4*>(x8 + e * 8 + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(x8 + e * 4) = a;
   }
 }
 int launch_pack_pwc_input(const float* i1, const float* i2, float* x8, long P, hipStream_t s) {
@@ -312,19 +311,15 @@ __global__ __launch_bounds__(256) void mask_rec_inputs_kernel(const float* __res
     mask[q] = m;
     const float cm = 1.f - m;
     const float2 v = *reinterpret_cast<const float2*>(f + q * 2);
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
     const float a0 = 1.f - m, a1 = 1.f - cm;
     if (ncalls > 0) {
-      *reinterpret_cast<float4*>(fin + q * 8) = make_float4(v.x * a0, v.y * a0, 1.f, a0);
-      *reinterpret_cast<float4*>(fin + q * 8 + 4) = z;
+      *reinterpret_cast<float4*>(fin + q * 4) = make_float4(v.x * a0, v.y * a0, 1.f, a0);
     }
     if (ncalls > 1) {
-      *reinterpret_cast<float4*>(fin + (P + q) * 8) = make_float4(v.x * a1, v.y * a1, 1.f, a1);
-      *reinterpret_cast<float4*>(fin + (P + q) * 8 + 4) = z;
+      *reinterpret_cast<float4*>(fin + (P + q) * 4) = make_float4(v.x * a1, v.y * a1, 1.f, a1);
     }
     if (ncalls > 2) {
-      *reinterpret_cast<float4*>(fin + (2 * P + q) * 8) = make_float4(0.f, 0.f, 1.f, 0.f);
-      *reinterpret_cast<float4*>(fin + (2 * P + q) * 8 + 4) = z;
+      *reinterpret_cast<float4*>(fin + (2 * P + q) * 4) = make_float4(0.f, 0.f, 1.f, 0.f);
     }
   }
 }
@@ -333,16 +328,12 @@ int launch_mask_rec_inputs(const float* logits, const float* f, float* mask, flo
   UDET_HIP(hipGetLastError());
   return UDET_OK;
 }
-// imgin[call][q] = [image(3) | 0 x5] for the `ncalls` recover invocations (nets.py:57: the image encoder's input)
+// imgin[call][q] = [image(3) | 0] for the `ncalls` recover invocations (nets.py:57: the image encoder's input)
 __global__ __launch_bounds__(256) void pack_imgin_kernel(const float* __restrict__ img, float* __restrict__ imgin, long P,
                                                          int ncalls) {
   for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < P; q += (long)gridDim.x * 256) {
     const float4 im = make_float4(img[q * 3], img[q * 3 + 1], img[q * 3 + 2], 0.f);
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int k = 0; k < ncalls; ++k) {
-      *reinterpret_cast<float4*>(imgin + (k * P + q) * 8) = im;
-      *reinterpret_cast<float4*>(imgin + (k * P + q) * 8 + 4) = z;
-    }
+    for (int k = 0; k < ncalls; ++k) *reinterpret_cast<float4*>(imgin + (k * P + q) * 4) = im;
   }
 }
 int launch_pack_imgin(const float* img, float* imgin, long P, int ncalls, hipStream_t s) {
@@ -485,8 +476,8 @@ __global__ __launch_bounds__(256) void mask_bwd_kernel(const float* __restrict__
                                                        const float* __restrict__ f, const float* __restrict__ mask,
                                                        float* __restrict__ dlogits /*ld 8*/, long P) {
   for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < P; q += (long)gridDim.x * 256) {
-    const float4 g0 = *reinterpret_cast<const float4*>(dfin + q * 8);
-    const float4 g1 = *reinterpret_cast<const float4*>(dfin + (P + q) * 8);
+    const float4 g0 = *reinterpret_cast<const float4*>(dfin + q * 4);
+    const float4 g1 = *reinterpret_cast<const float4*>(dfin + (P + q) * 4);
     const float2 fl = *reinterpret_cast<const float2*>(f + q * 2);
     float dm = dmask[q];
     dm -= g0.x * fl.x + g0.y * fl.y + g0.w;

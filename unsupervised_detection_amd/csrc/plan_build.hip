@@ -159,7 +159,7 @@ static Layer mk_layer(int net, const std::string& name, const std::string& wname
   const NetParams& np = net_params(net);
   L.w_idx = np.find(wname);
   L.b_idx = np.find(bname);
-  L.Kc = round_up(cin, 8);
+  L.Kc = round_up(cin, cin <= 4 ? 4 : 8);  // 2..4-channel inputs (RGB, flows, recover's 4-channel input) are stored with ld = 4
   L.ldw = round_up(cout, 4);
   L.k_split = L.Kc;
   L.k_gap = 0;
@@ -194,7 +194,7 @@ Plan* plan_build(const Config& cfg) {
   // ======================= PWC-Net =======================
   {
     int h = cfg.in_h, w = cfg.in_w;
-    P->add_buf("pwc.x8", 2 * B, h, w, 8);
+    P->add_buf("pwc.x8", 2 * B, h, w, 4);
     int prev = P->bid("pwc.x8"), prev_c = 3;
     for (int l = 1; l <= 6; ++l) {
       h /= 2; w /= 2;
@@ -220,8 +220,8 @@ Plan* plan_build(const Config& cfg) {
       const int ld = l == 6 ? 536 : 536 + C;
       const int slab = P->add_buf(S("pwc.slab%d", l), B, hh, ww, ld);
       if (l != 6) P->add_buf(S("pwc.warp%d", l), B, hh, ww, C);
-      const int F = P->add_buf(S("pwc.flow%d", l), B, hh, ww, 8);
-      const int FR = P->add_buf(S("pwc.rflow%d", l), B, hh, ww, 8);
+      const int F = P->add_buf(S("pwc.flow%d", l), B, hh, ww, 4);
+      const int FR = P->add_buf(S("pwc.rflow%d", l), B, hh, ww, 4);
       const int starts[5] = {448, 320, 192, 96, 32}, outs[5] = {320, 192, 96, 32, 0};
       int x = l == 6 ? 81 : 81 + C + 4;
       for (int i = 0; i < 5; ++i) {
@@ -330,9 +330,9 @@ Plan* plan_build(const Config& cfg) {
   // ======================= recover (3 calls batched) =======================
   {
     const int N = 3 * B;
-    const int imgin = P->add_buf("rec.imgin", N, H, W, 8);
-    const int fin = P->add_buf("rec.fin", N, H, W, 8);
-    P->add_buf("rec.d.fin", N, H, W, 8);
+    const int imgin = P->add_buf("rec.imgin", N, H, W, 4);
+    const int fin = P->add_buf("rec.fin", N, H, W, 4);
+    P->add_buf("rec.d.fin", N, H, W, 4);
     const int hs[7] = {H, H / 2, H / 4, H / 8, H / 16, H / 32, H / 64}, wsz[7] = {W, W / 2, W / 4, W / 8, W / 16, W / 32, W / 64};
     // concat slabs: [deconv | bconv | aconv | upflow(2)+pad(6)]
     const int cc[6] = {0, 16, 32, 64, 128, 128};  // channels of the skip at level k (bconv1,2,31,41,51)
@@ -393,8 +393,8 @@ Plan* plan_build(const Config& cfg) {
         P->rec.push_back(L);
       }
       if (k < 5) {
-        const int rf = P->add_buf(S("rec.rf%d", k + 1), N, hs[k], wsz[k], 8);
-        P->add_buf(S("rec.d.rf%d", k + 1), N, hs[k], wsz[k], 8);
+        const int rf = P->add_buf(S("rec.rf%d", k + 1), N, hs[k], wsz[k], 4);
+        P->add_buf(S("rec.d.rf%d", k + 1), N, hs[k], wsz[k], 4);
         const std::string nm = S("upflow%d", k);
         Layer L = mk_layer(NET_REC, nm, "FlownetS/" + nm + "/weights", "FlownetS/" + nm + "/biases", 4, 2, 2, 1, 1, ACT_NONE, 0.f);
         L.x = rf; L.y = concat[k]; L.y_coff = 3 * cc[k]; L.H = hs[k]; L.W = wsz[k];
@@ -407,8 +407,8 @@ Plan* plan_build(const Config& cfg) {
         Layer L = mk_layer(NET_REC, nm, "FlownetS/" + nm + "/weights", "FlownetS/" + nm + "/biases", k == 1 ? 5 : 3, cin, 2, 1, 1,
                            ACT_NONE, 0.f);
         L.x = concat[k]; L.Kc = P->buf(concat[k]).ld;
-        L.y = P->add_buf(S("rec.flow%d", k), N, hs[k], wsz[k], 8);
-        P->add_buf(S("rec.d.flow%d", k), N, hs[k], wsz[k], 8);
+        L.y = P->add_buf(S("rec.flow%d", k), N, hs[k], wsz[k], 4);
+        P->add_buf(S("rec.d.flow%d", k), N, hs[k], wsz[k], 4);
         L.H = hs[k]; L.W = wsz[k];
         flow_prev = L.y;
         P->rec.push_back(L);
@@ -456,7 +456,7 @@ Plan* plan_build(const Config& cfg) {
     L.scale_off = off; off = align64(off + L.cout);
     if (L.col2im) { L.wz_off = off; off = align64(off + (size_t)L.Kc * L.ldz); }
     if (trainable) {
-      L.KcT = round_up(L.cout, 8);
+      L.KcT = round_up(L.cout, (L.cout <= 4 && L.net == NET_REC) ? 4 : 8);  // recover's 2-channel outputs live in ld = 4 buffers
       L.ldwT = round_up(L.cin, 4);
       L.wpT_off = off; off = align64(off + (size_t)T * L.KcT * L.ldwT);
     }
