@@ -125,8 +125,49 @@ int launch_crop_flip_resize(const void* src, int src_u8, int nearest, int N, int
   return UDET_OK;
 }
 
+// the same resize, four channels per thread (channel windows that are float4-aligned: every slab of the decoder)
+__global__ __launch_bounds__(256) void resize_bilinear_fwd4_kernel(const float* __restrict__ x, int ldx, int x_coff, int N, int H,
+                                                                   int W, float* __restrict__ y, int ldy, int y_coff, int OH,
+                                                                   int OW, int C4, float mul, float div) {
+  const float sy = (float)H / (float)OH, sx = (float)W / (float)OW;
+  const long total = (long)N * OH * OW * C4;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int c4 = (int)(e % C4);
+    const long pix = e / C4;
+    const int ox = (int)(pix % OW), oy = (int)((pix / OW) % OH), n = (int)(pix / ((long)OW * OH));
+    int y0, y1, x0, x1;
+    float ty, tx;
+    legacy_coord(oy, sy, H, y0, y1, ty);
+    legacy_coord(ox, sx, W, x0, x1, tx);
+    const float* b = x + x_coff + c4 * 4;
+    const float4 tl = *reinterpret_cast<const float4*>(b + (((long)n * H + y0) * W + x0) * ldx);
+    const float4 tr = *reinterpret_cast<const float4*>(b + (((long)n * H + y0) * W + x1) * ldx);
+    const float4 bl = *reinterpret_cast<const float4*>(b + (((long)n * H + y1) * W + x0) * ldx);
+    const float4 br = *reinterpret_cast<const float4*>(b + (((long)n * H + y1) * W + x1) * ldx);
+    auto lerp = [&](float a, float bq, float c, float d) {
+      const float top = a + (bq - a) * tx, bot = c + (d - c) * tx;
+      float v = (top + (bot - top) * ty) * mul;
+      if (div != 1.f) v = v / div;
+      return v;
+    };
+    float4 o;
+    o.x = lerp(tl.x, tr.x, bl.x, br.x);
+    o.y = lerp(tl.y, tr.y, bl.y, br.y);
+    o.z = lerp(tl.z, tr.z, bl.z, br.z);
+    o.w = lerp(tl.w, tr.w, bl.w, br.w);
+    *reinterpret_cast<float4*>(y + pix * ldy + y_coff + c4 * 4) = o;
+  }
+}
 int launch_resize_bilinear_fwd(const float* x, int ldx, int x_coff, int N, int H, int W, float* y, int ldy, int y_coff,
                                int OH, int OW, int C, float mul, float div, hipStream_t s) {
+  if (C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && x_coff % 4 == 0 && y_coff % 4 == 0 &&
+      !((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15)) {
+    const long total4 = (long)N * OH * OW * (C / 4);
+    hipLaunchKernelGGL(resize_bilinear_fwd4_kernel, dim3(grid_for(total4, 8192)), dim3(256), 0, s, x, ldx, x_coff, N, H, W, y, ldy,
+                       y_coff, OH, OW, C / 4, mul, div);
+    UDET_HIP(hipGetLastError());
+    return UDET_OK;
+  }
   const long total = (long)N * OH * OW * C;
   hipLaunchKernelGGL(resize_bilinear_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, x, ldx, x_coff, N, H, W, y, ldy,
                      y_coff, OH, OW, C, mul, div);
@@ -170,8 +211,49 @@ __global__ __launch_bounds__(256) void resize_bilinear_bwd_kernel(const float* _
     *d = accumulate ? *d + acc : acc;
   }
 }
+// Adjoint of the exact 2x legacy up-resize (every resize of the recover decoder): out[2a] = in[a],
+// out[2a+1] = in[a] + (in[min(a+1,n-1)] - in[a])/2, so din[a] = dout[2a] + w+ * dout[2a+1] + dout[2a-1]/2 with
+// w+ = 1/2 (1 in the last row / column, where both taps are in[a]).  Four channels per thread.
+__global__ __launch_bounds__(256) void resize2x_bwd4_kernel(const float* __restrict__ dy, int ldy, int y_coff, int N, int H, int W,
+                                                            float* __restrict__ dx, int ldx, int x_coff, int C4, int accumulate) {
+  const int OH = 2 * H, OW = 2 * W;
+  const long total = (long)N * H * W * C4;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int c4 = (int)(e % C4);
+    const long pix = e / C4;
+    const int ix = (int)(pix % W), iy = (int)((pix / W) % H), n = (int)(pix / ((long)W * H));
+    float wy[3], wx[3];
+    wy[0] = iy > 0 ? 0.5f : 0.f; wy[1] = 1.f; wy[2] = iy == H - 1 ? 1.f : 0.5f;
+    wx[0] = ix > 0 ? 0.5f : 0.f; wx[1] = 1.f; wx[2] = ix == W - 1 ? 1.f : 0.5f;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const int oy = 2 * iy - 1 + a;
+      if (oy < 0) continue;
+#pragma unroll
+      for (int b = 0; b < 3; ++b) {
+        const int ox = 2 * ix - 1 + b;
+        if (ox < 0) continue;
+        const float w = wy[a] * wx[b];
+        const float4 g = *reinterpret_cast<const float4*>(dy + (((long)n * OH + oy) * OW + ox) * ldy + y_coff + c4 * 4);
+        acc.x += w * g.x; acc.y += w * g.y; acc.z += w * g.z; acc.w += w * g.w;
+      }
+    }
+    float4* d = reinterpret_cast<float4*>(dx + pix * ldx + x_coff + c4 * 4);
+    if (accumulate) { const float4 o = *d; acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w; }
+    *d = acc;
+  }
+}
 int launch_resize_bilinear_bwd(const float* dy, int ldy, int y_coff, int N, int OH, int OW, float* dx, int ldx, int x_coff,
                                int H, int W, int C, int accumulate, hipStream_t s) {
+  if (OH == 2 * H && OW == 2 * W && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0 && x_coff % 4 == 0 && y_coff % 4 == 0 &&
+      !((reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(dy)) & 15)) {
+    const long total4 = (long)N * H * W * (C / 4);
+    hipLaunchKernelGGL(resize2x_bwd4_kernel, dim3(grid_for(total4, 8192)), dim3(256), 0, s, dy, ldy, y_coff, N, H, W, dx, ldx, x_coff,
+                       C / 4, accumulate);
+    UDET_HIP(hipGetLastError());
+    return UDET_OK;
+  }
   const long total = (long)N * H * W * C;
   hipLaunchKernelGGL(resize_bilinear_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, s, dy, ldy, y_coff, N, OH, OW, dx,
                      ldx, x_coff, H, W, C, accumulate);

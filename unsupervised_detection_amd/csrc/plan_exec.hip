@@ -560,7 +560,7 @@ static int rec_backward(Plan* P, int N, const char* dp, bool with_wgrad, bool ne
       if (with_wgrad) UDET_TRY(wgrad(*uf, dconcat, false));  // linear layer: raw gradient
       UDET_TRY(run_dgrad(P, *uf, N, dconcat, false, D_(S("rf%d", k + 1)), 0, 0, -1, none, ws, LD));
       const Buf &drf = P->buf(D_(S("rf%d", k + 1))), &dfn = P->buf(D_(S("flow%d", k + 1)));
-      UDET_TRY(launch_resize_bilinear_bwd(ws + drf.off, drf.ld, 0, N, drf.h, drf.w, ws + dfn.off, dfn.ld, 0, dfn.h, dfn.w, 2, 0, s));
+      UDET_TRY(launch_resize_bilinear_bwd(ws + drf.off, drf.ld, 0, N, drf.h, drf.w, ws + dfn.off, dfn.ld, 0, dfn.h, dfn.w, drf.ld, 0, s));
     }
     if (with_wgrad) UDET_TRY(wgrad(*dc, uconcat, true));
     const int dr = D_(S("r%d", k + 1));
