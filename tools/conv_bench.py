@@ -26,7 +26,14 @@ SHAPES = [
     ("pwc.dc_conv22", 4, 96, 160, 128, 128, 3, 1, 2, False),
     ("pwc.dc_conv31", 4, 48, 80, 600, 128, 3, 1, 1, False),
     ("pwc.dc_conv41", 4, 24, 40, 632, 128, 3, 1, 1, False),
+    ("pwc.conv1a", 8, 384, 640, 3, 16, 3, 2, 1, False),
     ("pwc.conv1aa", 8, 192, 320, 16, 16, 3, 1, 1, False),
+    ("pwc.conv2a", 8, 192, 320, 16, 32, 3, 2, 1, False),
+    ("pwc.conv2aa", 8, 96, 160, 32, 32, 3, 1, 1, False),
+    ("gen.conv1", 4, 192, 384, 5, 32, 5, 1, 1, False),
+    ("gen.conv17", 4, 192, 384, 16, 2, 3, 1, 1, False),
+    ("rec.aconv1", 12, 192, 384, 3, 16, 7, 2, 1, False),
+    ("rec.aconv2", 12, 96, 192, 16, 32, 5, 2, 1, False),
     ("gen.conv5", 4, 48, 96, 128, 128, 3, 1, 1, False),
     ("gen.conv3", 4, 96, 192, 64, 64, 3, 1, 1, False),
     ("gen.conv15_up", 4, 96, 192, 64, 32, 3, 1, 1, True),
@@ -39,7 +46,7 @@ SHAPES = [
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--cfg", action="append", default=[], help="bm,bn,ks forced configuration (repeatable; bm+65536 selects the non-specialised 256-thread kernel, bm+131072 the LDS-DMA kernel); "
+    ap.add_argument("--cfg", action="append", default=[], help="bm,bn,ks forced configuration (repeatable; bm+65536 selects the non-specialised 256-thread kernel, bm+131072 the LDS-DMA kernel, 262144+{8,4} the tile-resident kernel with that tile height); "
                     "the default heuristics always run")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default="")
@@ -76,7 +83,7 @@ def main():
                 if y_ref is None:
                     y_ref = y
                 err = float((y - y_ref).abs().max())
-                tag = "auto" if cfg is None else "x".join(map(str, (cfg[0] & 0xffff,) + cfg[1:])) + ("n" if (cfg[0] >> 16) & 1 else "") + ("d" if (cfg[0] >> 17) & 1 else "")
+                tag = "auto" if cfg is None else "x".join(map(str, (cfg[0] & 0xffff,) + cfg[1:])) + ("n" if (cfg[0] >> 16) & 1 else "") + ("d" if (cfg[0] >> 17) & 1 else "") + ("t" if (cfg[0] >> 18) & 1 else "")
                 line += f" {tag:>11s}: {us_:7.1f}us {gflop / us_ * 1e3:6.1f}TF" + (f" ERR={err:.1e}" if err > 1e-4 else "") + " |"
             except Exception as ex:  # unsupported forced tile
                 line += f" {'x'.join(map(str, cfg))}: n/a |"

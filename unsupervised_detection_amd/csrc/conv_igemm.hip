@@ -613,7 +613,7 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const ConvPar
 static int g_force_bm = 0, g_force_bn = 0, g_force_ks = -1, g_force_ws = -1;
 void conv_force_config(int bm, int bn, int ks) {
   g_force_bm = bm & 0xffff; g_force_bn = bn; g_force_ks = ks;
-  g_force_ws = (bm >> 16) & 1 ? 0 : ((bm >> 17) & 1 ? 2 : -1);  // bit 16 of bm: non-specialised kernel; bit 17: LDS-DMA kernel
+  g_force_ws = (bm >> 16) & 1 ? 0 : ((bm >> 17) & 1 ? 2 : ((bm >> 18) & 1 ? 3 : -1));  // bit 16: non-specialised, 17: LDS-DMA, 18: tile kernel
 }
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
@@ -657,6 +657,13 @@ static int max_ksplit(const ConvParams& p) {  // capacity / minimum-work bound o
   while (ks > 1 && per_split * ks > p.partial_cap) --ks;
   return ks < 1 ? 1 : ks;
 }
+struct TileGeom;
+size_t conv_tile_lds_bytes(const ConvParams& p, int th, TileGeom* gout);
+int launch_conv_tile(const ConvParams& p, int th, hipStream_t stream);
+static bool tile_ok(const ConvParams& p, int th) {
+  const size_t b = conv_tile_lds_bytes(p, th, nullptr);
+  return b > 0 && b <= 96 * 1024 && p.Kc <= 64;
+}
 static bool dma_ok(const ConvParams& p) { return p.xa == nullptr && p.zero16 != nullptr && !(reinterpret_cast<uintptr_t>(p.zero16) & 15); }
 static ConvCfg heuristic_cfg(const ConvParams& p) {
   // N tile from the channel count; M tile shrunk while the launch would leave CUs without a workgroup
@@ -676,6 +683,10 @@ static ConvCfg heuristic_cfg(const ConvParams& p) {
   return c;
 }
 static int run_cfg(ConvParams& p, const ConvCfg& c, hipStream_t stream) {
+  if (c.ws == 3) {  // tile-resident direct convolution (conv_tile.hip); bm carries the tile height
+    p.ksplit = 1;
+    return launch_conv_tile(p, c.bm, stream);
+  }
   p.ksplit = c.ks > 1 ? c.ks : 1;
   if (p.ksplit > 1) p.ldp = (p.Cout + 3) & ~3;
   if (c.bm == 256 && c.bn == 32) return launch_cfg<256, 32, 32, 4, 1>(p, c.ws, stream);
@@ -760,6 +771,15 @@ static ConvCfg tune_cfg(ConvParams& p, hipStream_t stream) {
     }
     b = a;
   }
+  for (int th : {8, 4}) {  // thin layers: tile-resident direct convolution
+    if (!tile_ok(p, th)) continue;
+    const ConvCfg d = {th, 32, 1, 3};
+    const float ms = time_cfg(p, d, 3, stream);
+    if (ms < a * 0.97f) {
+      const float ms5 = time_cfg(p, d, 5, stream);
+      if (ms5 < a * 0.97f) { a = b = ms5; best = d; }
+    }
+  }
   if (getenv("UDET_TUNE_LOG"))
     fprintf(stderr, "[udet tune] N=%d %dx%d Kc=%d taps=%d cls=%d Cout=%d -> %dx%d ks=%d ws=%d  %.1f us (heuristic %dx%d ks=%d)\n", p.N,
             p.OHq, p.OWq, p.Kc, p.ntaps, p.ncls, p.Cout, best.bm, best.bn, best.ks, best.ws, (a < b ? a : b) * 1e3f, h.bm, h.bn, h.ks);
@@ -811,6 +831,8 @@ int launch_conv(ConvParams& p, hipStream_t stream) {
   if (g_force_ks >= 0) c.ks = g_force_ks > max_ksplit(p) ? max_ksplit(p) : g_force_ks;
   if (g_force_ws >= 0) c.ws = g_force_ws;
   if (c.ws == 2 && !dma_ok(p)) c.ws = 1;
+  if (g_force_ws == 3) { c.ws = 3; c.bm = (g_force_bm == 4) ? 4 : 8; }
+  if (c.ws == 3 && !tile_ok(p, c.bm)) { c = heuristic_cfg(p); }
   return run_cfg(p, c, stream);
 }
 

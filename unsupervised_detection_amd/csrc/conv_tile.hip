@@ -1,0 +1,159 @@
+// Tile-resident direct convolution for the thin layers (few input channels, large spatial extent: PWC pyramid levels 1-2,
+// generator conv1/16/17, the 7x7 / 5x5 stride-2 first layers of the recover encoders).  These launches are HBM/latency-bound
+// in the implicit-GEMM kernel: their K axis is 4..9 LDS stages long, so every workgroup pays one global->LDS round trip
+// per stage for a handful of MFMAs.  Here a workgroup
+//   1. loads the input halo tile of its TH x 32 output pixels ONCE (every input byte read 1.1-1.3x instead of once per tap),
+//      channel-major into LDS ([c][tile pixel]: the K-major image the MFMA A fragment wants, conflict-free for stride 1),
+//   2. loads the launch's packed weights for its 32 output channels ([tap][c][32]) into LDS,
+//   3. walks taps x channels with v_mfma_f32_32x32x2_f32 reading the A fragment at tap-shifted tile addresses
+//      (im2col never materialised), 4 waves x (TH/4) tile rows each,
+//   4. runs the common epilogue (bias / activation / residual / second output / dU emission).
+// Same ConvParams contract as conv_igemm (tap list, NN x2 read, TF SAME padding through the tap offsets); one parity
+// class only (forward convolutions and stride-1 backward-data).
+#include "common.h"
+
+namespace udet {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ void tile_epilogue(const ConvParams& p, int off, int n, float v) {
+  if (p.bias) v += p.bias[n];
+  v = act_fwd(v, p.act, p.alpha);
+  if (p.y2) p.y2[(size_t)off * p.ldy2 + p.y2_coff + n] = v;
+  if (p.res) v += p.res[(size_t)off * p.ldres + p.res_coff + n];
+  float* dst = p.y + (size_t)off * p.ldy + p.y_coff + n;
+  if (p.accumulate) v += *dst;
+  *dst = v;
+  if (p.uo && n >= p.u_c0 && n < p.u_c1)
+    p.uo[(size_t)off * p.ldu + p.u_coff + n] = v * act_dfo(p.ua[(size_t)off * p.ldua + p.ua_coff + n], p.uact, p.ualpha);
+}
+
+struct TileGeom {
+  int min_dy, min_dx, PH, PW;  // tile origin offset and extent on the (logical, post-upsample) input grid
+};
+
+template <int TH>
+__global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams p, const TileGeom g) {
+  constexpr int TW = 32;
+  constexpr int TM = TH / 4;  // tile rows (MFMA M blocks) per wave
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int PIX = g.PH * g.PW;
+  const int PIXP = PIX | 1;                       // odd row stride: the 4 transposing stores of a float4 spread over banks
+  float* T = smem;                                // [Kc][PIXP]
+  float* Wl = smem + (size_t)p.Kc * PIXP;         // [ntaps*Kc][32]
+  int* tapoff = reinterpret_cast<int*>(Wl + (size_t)p.ntaps * p.Kc * 32);  // [ntaps]
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, lh = lane >> 5;
+  const int tiles_x = (p.OWq + TW - 1) / TW, tiles_y = (p.OHq + TH - 1) / TH;
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y, n = bid / (tiles_x * tiles_y);
+  const int oy0 = ty * TH, ox0 = tx * TW;
+  const int n0 = blockIdx.y * 32;
+  const int iy0 = oy0 * p.isy + g.min_dy, ix0 = ox0 * p.isx + g.min_dx;  // logical input coords of tile pixel (0,0)
+  const int Hs = p.H >> p.up_shift, Ws = p.W >> p.up_shift;
+
+  // ---- 1. input halo tile, transposed to channel-major -----------------------------------------------------------
+  const int KQ = p.Kc >> 2;
+  const float* xb = p.x + (size_t)n * Hs * Ws * p.ldx + p.x_coff;
+  for (int e = t; e < PIX * KQ; e += 256) {
+    const int c4 = e % KQ, pix = e / KQ;
+    const int py = pix / g.PW, px = pix - py * g.PW;
+    int iy = iy0 + py, ix = ix0 + px;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
+      iy >>= p.up_shift;
+      ix >>= p.up_shift;
+      v = *reinterpret_cast<const float4*>(xb + (size_t)(iy * Ws + ix) * p.ldx + c4 * 4);
+    }
+    float* d = T + (size_t)(c4 * 4) * PIXP + pix;
+    d[0] = v.x; d[PIXP] = v.y; d[2 * PIXP] = v.z; d[3 * PIXP] = v.w;
+  }
+  // ---- 2. weights [tap][c][32 columns of this N tile] -----------------------------------------------------------
+  for (int e = t; e < p.ntaps * p.Kc * 8; e += 256) {
+    const int c4 = e & 7, row = e >> 3;                 // row = tap*Kc + c
+    const int tap = row / p.Kc, c = row - tap * p.Kc;
+    const int nn = n0 + c4 * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (nn < p.ldw) v = *reinterpret_cast<const float4*>(p.wp + ((size_t)p.taps[tap].widx * p.Kc + c) * p.ldw + nn);
+    *reinterpret_cast<float4*>(Wl + (size_t)row * 32 + c4 * 4) = v;
+  }
+  for (int i = t; i < p.ntaps; i += 256) tapoff[i] = (p.taps[i].dy - g.min_dy) * g.PW + (p.taps[i].dx - g.min_dx);
+  __syncthreads();
+
+  // ---- 3. taps x channels -----------------------------------------------------------------------------------------
+  floatx16 acc[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  int abase[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) abase[i] = ((wave * TM + i) * p.isy) * g.PW + li * p.isx + lh * PIXP;  // + lh: channel 2kk+lh
+  const int kpairs = p.Kc >> 1;
+  for (int tap = 0; tap < p.ntaps; ++tap) {
+    const int off = tapoff[tap];
+    const float* wrow = Wl + (size_t)(tap * p.Kc + lh) * 32 + li;
+    for (int kk = 0; kk < kpairs; ++kk) {
+      const float b = wrow[(size_t)kk * 64];
+      const float* ta = T + (size_t)kk * 2 * PIXP + off;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[abase[i]], b, acc[i], 0, 0, 0);
+    }
+  }
+
+  // ---- 4. epilogue --------------------------------------------------------------------------------------------------
+  const int nn = n0 + li;
+  if (nn >= p.Cout) return;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int oy = oy0 + wave * TM + i;
+    if (oy >= p.OHq) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (ox >= p.OWq) continue;
+      const int off = (n * p.OH + oy * p.osy + p.ooy) * p.OW + ox * p.osx + p.oox;
+      tile_epilogue(p, off, nn, acc[i][r]);
+    }
+  }
+}
+
+// LDS bytes of the tile kernel for this launch at tile height th (0: not eligible)
+size_t conv_tile_lds_bytes(const ConvParams& p, int th, TileGeom* gout) {
+  if (p.ncls > 1 || p.ntaps < 1 || p.xa != nullptr || p.Kc % 4 != 0 || p.isy != p.isx || p.isy < 1 || p.isy > 2) return 0;
+  int mn_y = 1 << 30, mx_y = -(1 << 30), mn_x = 1 << 30, mx_x = -(1 << 30);
+  for (int t = 0; t < p.ntaps; ++t) {
+    mn_y = p.taps[t].dy < mn_y ? p.taps[t].dy : mn_y; mx_y = p.taps[t].dy > mx_y ? p.taps[t].dy : mx_y;
+    mn_x = p.taps[t].dx < mn_x ? p.taps[t].dx : mn_x; mx_x = p.taps[t].dx > mx_x ? p.taps[t].dx : mx_x;
+  }
+  TileGeom g;
+  g.min_dy = mn_y; g.min_dx = mn_x;
+  g.PH = (th - 1) * p.isy + (mx_y - mn_y) + 1;
+  g.PW = 31 * p.isx + (mx_x - mn_x) + 1;
+  if (gout) *gout = g;
+  const size_t pixp = (size_t)(g.PH * g.PW) | 1;
+  return ((size_t)p.Kc * pixp + (size_t)p.ntaps * p.Kc * 32 + p.ntaps + 8) * sizeof(float);
+}
+
+int launch_conv_tile(const ConvParams& p, int th, hipStream_t stream) {
+  TileGeom g;
+  const size_t lds = conv_tile_lds_bytes(p, th, &g);
+  if (lds == 0 || lds > 96 * 1024 || (th != 8 && th != 4)) {
+    set_error("conv_tile: launch not eligible");
+    return UDET_ERR_UNSUPPORTED;
+  }
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tile_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tile_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    attr_set = true;
+  }
+  const int tiles = ((p.OWq + 31) / 32) * ((p.OHq + th - 1) / th) * p.N;
+  dim3 grid(tiles, (p.Cout + 31) / 32);
+  if (th == 8) hipLaunchKernelGGL(conv_tile_kernel<8>, grid, dim3(256), lds, stream, p, g);
+  else hipLaunchKernelGGL(conv_tile_kernel<4>, grid, dim3(256), lds, stream, p, g);
+  UDET_HIP(hipGetLastError());
+  return UDET_OK;
+}
+
+}  // namespace udet
