@@ -118,6 +118,100 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams p, cons
   }
 }
 
+// <= 16 output channels: the same kernel on v_mfma_f32_16x16x4_f32 (16-wide N: no padded MFMA columns; same FLOP rate).
+// A fragment: lane -> pixel (l&15) of a 16-pixel half row, channel 4*kk + (l>>4); B: column l&15, same channel.
+// The tile's channel stride is == 16 (mod 32) so the four channel groups of a wave read disjoint banks.
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+template <int TH>
+__global__ __launch_bounds__(256) void conv_tile16_kernel(const ConvParams p, const TileGeom g) {
+  constexpr int TW = 32;
+  constexpr int TM = TH / 4;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int PIX = g.PH * g.PW;
+  const int PIXP = ((PIX + 15) & ~31) + 16;       // >= PIX, == 16 (mod 32)
+  float* T = smem;                                // [Kc][PIXP]
+  float* Wl = smem + (size_t)p.Kc * PIXP;         // [ntaps*Kc][16]
+  int* tapoff = reinterpret_cast<int*>(Wl + (size_t)p.ntaps * p.Kc * 16);
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lp = lane & 15, lg = lane >> 4;
+  const int tiles_x = (p.OWq + TW - 1) / TW, tiles_y = (p.OHq + TH - 1) / TH;
+  const int bid = blockIdx.x;
+  const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y, n = bid / (tiles_x * tiles_y);
+  const int oy0 = ty * TH, ox0 = tx * TW;
+  const int n0 = blockIdx.y * 16;
+  const int iy0 = oy0 * p.isy + g.min_dy, ix0 = ox0 * p.isx + g.min_dx;
+  const int Hs = p.H >> p.up_shift, Ws = p.W >> p.up_shift;
+
+  const int KQ = p.Kc >> 2;
+  const float* xb = p.x + (size_t)n * Hs * Ws * p.ldx + p.x_coff;
+  for (int e = t; e < PIX * KQ; e += 256) {
+    const int c4 = e % KQ, pix = e / KQ;
+    const int py = pix / g.PW, px = pix - py * g.PW;
+    int iy = iy0 + py, ix = ix0 + px;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
+      iy >>= p.up_shift;
+      ix >>= p.up_shift;
+      v = *reinterpret_cast<const float4*>(xb + (size_t)(iy * Ws + ix) * p.ldx + c4 * 4);
+    }
+    float* d = T + (size_t)(c4 * 4) * PIXP + pix;
+    d[0] = v.x; d[PIXP] = v.y; d[2 * PIXP] = v.z; d[3 * PIXP] = v.w;
+  }
+  for (int e = t; e < p.ntaps * p.Kc * 4; e += 256) {
+    const int c4 = e & 3, row = e >> 2;
+    const int tap = row / p.Kc, c = row - tap * p.Kc;
+    const int nn = n0 + c4 * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (nn < p.ldw) v = *reinterpret_cast<const float4*>(p.wp + ((size_t)p.taps[tap].widx * p.Kc + c) * p.ldw + nn);
+    *reinterpret_cast<float4*>(Wl + (size_t)row * 16 + c4 * 4) = v;
+  }
+  for (int i = t; i < p.ntaps; i += 256) tapoff[i] = (p.taps[i].dy - g.min_dy) * g.PW + (p.taps[i].dx - g.min_dx);
+  __syncthreads();
+
+  floatx4 acc[TM][2];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][h][r] = 0.f;
+  int abase[TM][2];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) abase[i][h] = ((wave * TM + i) * p.isy) * g.PW + (h * 16 + lp) * p.isx + lg * PIXP;
+  const int kquads = p.Kc >> 2;
+  for (int tap = 0; tap < p.ntaps; ++tap) {
+    const int off = tapoff[tap];
+    const float* wrow = Wl + (size_t)(tap * p.Kc + lg) * 16 + lp;
+    for (int kk = 0; kk < kquads; ++kk) {
+      const float b = wrow[(size_t)kk * 64];
+      const float* ta = T + (size_t)kk * 4 * PIXP + off;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) acc[i][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[abase[i][h]], b, acc[i][h], 0, 0, 0);
+    }
+  }
+
+  const int nn = n0 + lp;
+  if (nn >= p.Cout) return;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int oy = oy0 + wave * TM + i;
+    if (oy >= p.OHq) continue;
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int ox = ox0 + h * 16 + lg * 4 + r;
+        if (ox >= p.OWq) continue;
+        const int off = (n * p.OH + oy * p.osy + p.ooy) * p.OW + ox * p.osx + p.oox;
+        tile_epilogue(p, off, nn, acc[i][h][r]);
+      }
+  }
+}
+
 // LDS bytes of the tile kernel for this launch at tile height th (0: not eligible)
 size_t conv_tile_lds_bytes(const ConvParams& p, int th, TileGeom* gout) {
   if (p.ncls > 1 || p.ntaps < 1 || p.xa != nullptr || p.Kc % 4 != 0 || p.isy != p.isx || p.isy < 1 || p.isy > 2) return 0;
@@ -131,6 +225,10 @@ size_t conv_tile_lds_bytes(const ConvParams& p, int th, TileGeom* gout) {
   g.PH = (th - 1) * p.isy + (mx_y - mn_y) + 1;
   g.PW = 31 * p.isx + (mx_x - mn_x) + 1;
   if (gout) *gout = g;
+  if (p.Cout <= 16) {  // 16-wide variant
+    const size_t pixp = (size_t)(((g.PH * g.PW + 15) & ~31) + 16);
+    return ((size_t)p.Kc * pixp + (size_t)p.ntaps * p.Kc * 16 + p.ntaps + 8) * sizeof(float);
+  }
   const size_t pixp = (size_t)(g.PH * g.PW) | 1;
   return ((size_t)p.Kc * pixp + (size_t)p.ntaps * p.Kc * 32 + p.ntaps + 8) * sizeof(float);
 }
@@ -146,9 +244,18 @@ int launch_conv_tile(const ConvParams& p, int th, hipStream_t stream) {
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tile_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tile_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tile16_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tile16_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     attr_set = true;
   }
   const int tiles = ((p.OWq + 31) / 32) * ((p.OHq + th - 1) / th) * p.N;
+  if (p.Cout <= 16) {
+    dim3 grid16(tiles, 1);
+    if (th == 8) hipLaunchKernelGGL(conv_tile16_kernel<8>, grid16, dim3(256), lds, stream, p, g);
+    else hipLaunchKernelGGL(conv_tile16_kernel<4>, grid16, dim3(256), lds, stream, p, g);
+    UDET_HIP(hipGetLastError());
+    return UDET_OK;
+  }
   dim3 grid(tiles, (p.Cout + 31) / 32);
   if (th == 8) hipLaunchKernelGGL(conv_tile_kernel<8>, grid, dim3(256), lds, stream, p, g);
   else hipLaunchKernelGGL(conv_tile_kernel<4>, grid, dim3(256), lds, stream, p, g);
