@@ -662,7 +662,7 @@ size_t conv_tile_lds_bytes(const ConvParams& p, int th, TileGeom* gout);
 int launch_conv_tile(const ConvParams& p, int th, hipStream_t stream);
 static bool tile_ok(const ConvParams& p, int th) {
   const size_t b = conv_tile_lds_bytes(p, th, nullptr);
-  return b > 0 && b <= 96 * 1024 && p.Kc <= 64;
+  return b > 0 && b <= 96 * 1024 && p.Kc <= 256 && p.Cout <= 64;
 }
 static bool dma_ok(const ConvParams& p) { return p.xa == nullptr && p.zero16 != nullptr && !(reinterpret_cast<uintptr_t>(p.zero16) & 15); }
 static ConvCfg heuristic_cfg(const ConvParams& p) {

@@ -7,6 +7,7 @@
 //   2. loads the launch's packed weights for its 32 output channels ([tap][c][32]) into LDS,
 //   3. walks taps x channels with v_mfma_f32_32x32x2_f32 reading the A fragment at tap-shifted tile addresses
 //      (im2col never materialised), 4 waves x (TH/4) tile rows each,
+//      (layers deeper than 32 channels repeat 1-3 per block of 32 channels, accumulating in registers),
 //   4. runs the common epilogue (bias / activation / residual / second output / dU emission).
 // Same ConvParams contract as conv_igemm (tap list, NN x2 read, TF SAME padding through the tap offsets); one parity
 // class only (forward convolutions and stride-1 backward-data).
@@ -39,9 +40,11 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams p, cons
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int PIX = g.PH * g.PW;
   const int PIXP = PIX | 1;                       // odd row stride: the 4 transposing stores of a float4 spread over banks
-  float* T = smem;                                // [Kc][PIXP]
-  float* Wl = smem + (size_t)p.Kc * PIXP;         // [ntaps*Kc][32]
-  int* tapoff = reinterpret_cast<int*>(Wl + (size_t)p.ntaps * p.Kc * 32);  // [ntaps]
+  const int CB = p.Kc < 32 ? p.Kc : 32;           // channels resident per pass (deep layers walk Kc in blocks of 32)
+  float* T = smem;                                // [CB][PIXP]
+  float* Wl = smem + (size_t)CB * PIXP;           // [ntaps*CB][32]
+  int* tapoff = reinterpret_cast<int*>(Wl + (size_t)p.ntaps * CB * 32);  // [ntaps]
+  int* pixoff = tapoff + p.ntaps;                 // [PIX]
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, lh = lane >> 5;
   const int tiles_x = (p.OWq + TW - 1) / TW, tiles_y = (p.OHq + TH - 1) / TH;
@@ -51,36 +54,18 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams p, cons
   const int n0 = blockIdx.y * 32;
   const int iy0 = oy0 * p.isy + g.min_dy, ix0 = ox0 * p.isx + g.min_dx;  // logical input coords of tile pixel (0,0)
   const int Hs = p.H >> p.up_shift, Ws = p.W >> p.up_shift;
-
-  // ---- 1. input halo tile, transposed to channel-major -----------------------------------------------------------
-  const int KQ = p.Kc >> 2;
   const float* xb = p.x + (size_t)n * Hs * Ws * p.ldx + p.x_coff;
-  for (int e = t; e < PIX * KQ; e += 256) {
-    const int c4 = e % KQ, pix = e / KQ;
-    const int py = pix / g.PW, px = pix - py * g.PW;
-    int iy = iy0 + py, ix = ix0 + px;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
-      iy >>= p.up_shift;
-      ix >>= p.up_shift;
-      v = *reinterpret_cast<const float4*>(xb + (size_t)(iy * Ws + ix) * p.ldx + c4 * 4);
-    }
-    float* d = T + (size_t)(c4 * 4) * PIXP + pix;
-    d[0] = v.x; d[PIXP] = v.y; d[2 * PIXP] = v.z; d[3 * PIXP] = v.w;
-  }
-  // ---- 2. weights [tap][c][32 columns of this N tile] -----------------------------------------------------------
-  for (int e = t; e < p.ntaps * p.Kc * 8; e += 256) {
-    const int c4 = e & 7, row = e >> 3;                 // row = tap*Kc + c
-    const int tap = row / p.Kc, c = row - tap * p.Kc;
-    const int nn = n0 + c4 * 4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (nn < p.ldw) v = *reinterpret_cast<const float4*>(p.wp + ((size_t)p.taps[tap].widx * p.Kc + c) * p.ldw + nn);
-    *reinterpret_cast<float4*>(Wl + (size_t)row * 32 + c4 * 4) = v;
-  }
-  for (int i = t; i < p.ntaps; i += 256) tapoff[i] = (p.taps[i].dy - g.min_dy) * g.PW + (p.taps[i].dx - g.min_dx);
-  __syncthreads();
 
-  // ---- 3. taps x channels -----------------------------------------------------------------------------------------
+  // tap -> tile offset; tile pixel -> global element offset (-1: zero padding), once per workgroup
+  for (int i = t; i < p.ntaps; i += 256) tapoff[i] = (p.taps[i].dy - g.min_dy) * g.PW + (p.taps[i].dx - g.min_dx);
+  for (int pix = t; pix < PIX; pix += 256) {
+    const int py = pix / g.PW, px = pix - py * g.PW;
+    const int iy = iy0 + py, ix = ix0 + px;
+    int o = -1;
+    if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) o = ((iy >> p.up_shift) * Ws + (ix >> p.up_shift)) * p.ldx;
+    pixoff[pix] = o;
+  }
+
   floatx16 acc[TM];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -89,15 +74,44 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams p, cons
   int abase[TM];
 #pragma unroll
   for (int i = 0; i < TM; ++i) abase[i] = ((wave * TM + i) * p.isy) * g.PW + li * p.isx + lh * PIXP;  // + lh: channel 2kk+lh
-  const int kpairs = p.Kc >> 1;
-  for (int tap = 0; tap < p.ntaps; ++tap) {
-    const int off = tapoff[tap];
-    const float* wrow = Wl + (size_t)(tap * p.Kc + lh) * 32 + li;
-    for (int kk = 0; kk < kpairs; ++kk) {
-      const float b = wrow[(size_t)kk * 64];
-      const float* ta = T + (size_t)kk * 2 * PIXP + off;
+
+  for (int c0 = 0; c0 < p.Kc; c0 += CB) {
+    const int cw = p.Kc - c0 < CB ? p.Kc - c0 : CB;
+    __syncthreads();  // offset tables written / previous pass's fragments read
+    // ---- 1. input halo tile of channels [c0, c0+cw), transposed to channel-major ---------------------------------
+    const int KQ = cw >> 2;
+    const int kq_shift = (KQ & (KQ - 1)) == 0 ? __builtin_ctz(KQ) : -1;
+    for (int e = t; e < PIX * KQ; e += 256) {
+      const int pix = kq_shift >= 0 ? e >> kq_shift : e / KQ, c4 = e - pix * KQ;
+      const int o = pixoff[pix];
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (o >= 0) v = *reinterpret_cast<const float4*>(xb + (size_t)o + c0 + c4 * 4);
+      float* d = T + (size_t)(c4 * 4) * PIXP + pix;
+      d[0] = v.x; d[PIXP] = v.y; d[2 * PIXP] = v.z; d[3 * PIXP] = v.w;
+    }
+    // ---- 2. weights [tap][c][32 columns of this N tile] ---------------------------------------------------------
+    const int cw_shift = (cw & (cw - 1)) == 0 ? __builtin_ctz(cw) : -1;
+    for (int e = t; e < p.ntaps * cw * 8; e += 256) {
+      const int c4 = e & 7, row = e >> 3;                 // row = tap*cw + c
+      const int tap = cw_shift >= 0 ? row >> cw_shift : row / cw, c = row - tap * cw;
+      const int nn = n0 + c4 * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (nn < p.ldw) v = *reinterpret_cast<const float4*>(p.wp + ((size_t)p.taps[tap].widx * p.Kc + c0 + c) * p.ldw + nn);
+      *reinterpret_cast<float4*>(Wl + (size_t)row * 32 + c4 * 4) = v;
+    }
+    __syncthreads();
+
+    // ---- 3. taps x channels -------------------------------------------------------------------------------------
+    const int kpairs = cw >> 1;
+    for (int tap = 0; tap < p.ntaps; ++tap) {
+      const int off = tapoff[tap];
+      const float* wrow = Wl + (size_t)(tap * cw + lh) * 32 + li;
+      for (int kk = 0; kk < kpairs; ++kk) {
+        const float b = wrow[(size_t)kk * 64];
+        const float* ta = T + (size_t)kk * 2 * PIXP + off;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[abase[i]], b, acc[i], 0, 0, 0);
+        for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[abase[i]], b, acc[i], 0, 0, 0);
+      }
     }
   }
 
@@ -129,9 +143,11 @@ __global__ __launch_bounds__(256) void conv_tile16_kernel(const ConvParams p, co
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int PIX = g.PH * g.PW;
   const int PIXP = ((PIX + 15) & ~31) + 16;       // >= PIX, == 16 (mod 32)
-  float* T = smem;                                // [Kc][PIXP]
-  float* Wl = smem + (size_t)p.Kc * PIXP;         // [ntaps*Kc][16]
-  int* tapoff = reinterpret_cast<int*>(Wl + (size_t)p.ntaps * p.Kc * 16);
+  const int CB = p.Kc < 32 ? p.Kc : 32;
+  float* T = smem;                                // [CB][PIXP]
+  float* Wl = smem + (size_t)CB * PIXP;           // [ntaps*CB][16]
+  int* tapoff = reinterpret_cast<int*>(Wl + (size_t)p.ntaps * CB * 16);
+  int* pixoff = tapoff + p.ntaps;
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lp = lane & 15, lg = lane >> 4;
   const int tiles_x = (p.OWq + TW - 1) / TW, tiles_y = (p.OHq + TH - 1) / TH;
@@ -141,32 +157,16 @@ __global__ __launch_bounds__(256) void conv_tile16_kernel(const ConvParams p, co
   const int n0 = blockIdx.y * 16;
   const int iy0 = oy0 * p.isy + g.min_dy, ix0 = ox0 * p.isx + g.min_dx;
   const int Hs = p.H >> p.up_shift, Ws = p.W >> p.up_shift;
-
-  const int KQ = p.Kc >> 2;
   const float* xb = p.x + (size_t)n * Hs * Ws * p.ldx + p.x_coff;
-  for (int e = t; e < PIX * KQ; e += 256) {
-    const int c4 = e % KQ, pix = e / KQ;
-    const int py = pix / g.PW, px = pix - py * g.PW;
-    int iy = iy0 + py, ix = ix0 + px;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
-      iy >>= p.up_shift;
-      ix >>= p.up_shift;
-      v = *reinterpret_cast<const float4*>(xb + (size_t)(iy * Ws + ix) * p.ldx + c4 * 4);
-    }
-    float* d = T + (size_t)(c4 * 4) * PIXP + pix;
-    d[0] = v.x; d[PIXP] = v.y; d[2 * PIXP] = v.z; d[3 * PIXP] = v.w;
-  }
-  for (int e = t; e < p.ntaps * p.Kc * 4; e += 256) {
-    const int c4 = e & 3, row = e >> 2;
-    const int tap = row / p.Kc, c = row - tap * p.Kc;
-    const int nn = n0 + c4 * 4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (nn < p.ldw) v = *reinterpret_cast<const float4*>(p.wp + ((size_t)p.taps[tap].widx * p.Kc + c) * p.ldw + nn);
-    *reinterpret_cast<float4*>(Wl + (size_t)row * 16 + c4 * 4) = v;
-  }
+
   for (int i = t; i < p.ntaps; i += 256) tapoff[i] = (p.taps[i].dy - g.min_dy) * g.PW + (p.taps[i].dx - g.min_dx);
-  __syncthreads();
+  for (int pix = t; pix < PIX; pix += 256) {
+    const int py = pix / g.PW, px = pix - py * g.PW;
+    const int iy = iy0 + py, ix = ix0 + px;
+    int o = -1;
+    if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) o = ((iy >> p.up_shift) * Ws + (ix >> p.up_shift)) * p.ldx;
+    pixoff[pix] = o;
+  }
 
   floatx4 acc[TM][2];
 #pragma unroll
@@ -180,17 +180,43 @@ __global__ __launch_bounds__(256) void conv_tile16_kernel(const ConvParams p, co
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int h = 0; h < 2; ++h) abase[i][h] = ((wave * TM + i) * p.isy) * g.PW + (h * 16 + lp) * p.isx + lg * PIXP;
-  const int kquads = p.Kc >> 2;
-  for (int tap = 0; tap < p.ntaps; ++tap) {
-    const int off = tapoff[tap];
-    const float* wrow = Wl + (size_t)(tap * p.Kc + lg) * 16 + lp;
-    for (int kk = 0; kk < kquads; ++kk) {
-      const float b = wrow[(size_t)kk * 64];
-      const float* ta = T + (size_t)kk * 4 * PIXP + off;
+
+  for (int c0 = 0; c0 < p.Kc; c0 += CB) {
+    const int cw = p.Kc - c0 < CB ? p.Kc - c0 : CB;
+    __syncthreads();
+    const int KQ = cw >> 2;
+    const int kq_shift = (KQ & (KQ - 1)) == 0 ? __builtin_ctz(KQ) : -1;
+    for (int e = t; e < PIX * KQ; e += 256) {
+      const int pix = kq_shift >= 0 ? e >> kq_shift : e / KQ, c4 = e - pix * KQ;
+      const int o = pixoff[pix];
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (o >= 0) v = *reinterpret_cast<const float4*>(xb + (size_t)o + c0 + c4 * 4);
+      float* d = T + (size_t)(c4 * 4) * PIXP + pix;
+      d[0] = v.x; d[PIXP] = v.y; d[2 * PIXP] = v.z; d[3 * PIXP] = v.w;
+    }
+    const int cw_shift = (cw & (cw - 1)) == 0 ? __builtin_ctz(cw) : -1;
+    for (int e = t; e < p.ntaps * cw * 4; e += 256) {
+      const int c4 = e & 3, row = e >> 2;
+      const int tap = cw_shift >= 0 ? row >> cw_shift : row / cw, c = row - tap * cw;
+      const int nn = n0 + c4 * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (nn < p.ldw) v = *reinterpret_cast<const float4*>(p.wp + ((size_t)p.taps[tap].widx * p.Kc + c0 + c) * p.ldw + nn);
+      *reinterpret_cast<float4*>(Wl + (size_t)row * 16 + c4 * 4) = v;
+    }
+    __syncthreads();
+
+    const int kquads = cw >> 2;
+    for (int tap = 0; tap < p.ntaps; ++tap) {
+      const int off = tapoff[tap];
+      const float* wrow = Wl + (size_t)(tap * cw + lg) * 16 + lp;
+      for (int kk = 0; kk < kquads; ++kk) {
+        const float b = wrow[(size_t)kk * 64];
+        const float* ta = T + (size_t)kk * 4 * PIXP + off;
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) acc[i][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[abase[i][h]], b, acc[i][h], 0, 0, 0);
+          for (int h = 0; h < 2; ++h) acc[i][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[abase[i][h]], b, acc[i][h], 0, 0, 0);
+      }
     }
   }
 
@@ -225,12 +251,13 @@ size_t conv_tile_lds_bytes(const ConvParams& p, int th, TileGeom* gout) {
   g.PH = (th - 1) * p.isy + (mx_y - mn_y) + 1;
   g.PW = 31 * p.isx + (mx_x - mn_x) + 1;
   if (gout) *gout = g;
+  const size_t cb = p.Kc < 32 ? p.Kc : 32;  // channels resident per pass
   if (p.Cout <= 16) {  // 16-wide variant
     const size_t pixp = (size_t)(((g.PH * g.PW + 15) & ~31) + 16);
-    return ((size_t)p.Kc * pixp + (size_t)p.ntaps * p.Kc * 16 + p.ntaps + 8) * sizeof(float);
+    return (cb * pixp + (size_t)p.ntaps * cb * 16 + p.ntaps + (size_t)g.PH * g.PW + 8) * sizeof(float);
   }
   const size_t pixp = (size_t)(g.PH * g.PW) | 1;
-  return ((size_t)p.Kc * pixp + (size_t)p.ntaps * p.Kc * 32 + p.ntaps + 8) * sizeof(float);
+  return (cb * pixp + (size_t)p.ntaps * cb * 32 + p.ntaps + (size_t)g.PH * g.PW + 8) * sizeof(float);
 }
 
 int launch_conv_tile(const ConvParams& p, int th, hipStream_t stream) {
