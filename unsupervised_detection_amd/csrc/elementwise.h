@@ -5,6 +5,8 @@ int launch_resize_bilinear_fwd(const float* x, int ldx, int x_coff, int N, int H
                                int OH, int OW, int C, float mul, float div, hipStream_t s);
 int launch_resize_bilinear_bwd(const float* dy, int ldy, int y_coff, int N, int OH, int OW, float* dx, int ldx, int x_coff,
                                int H, int W, int C, int accumulate, hipStream_t s);
+int launch_share_samples(float* buf, long P, int ld, int coff, int C, int copies, hipStream_t s);
+int launch_fold_samples(float* buf, long P, int ld, int coff, int C, int copies, hipStream_t s);
 int launch_emit_du(const float* d, const float* a, float* u, long P, int ld, int coff, int C, int act, float alpha, hipStream_t s);
 int launch_pool2x2_sum(const float* du, float* dx, int N, int H, int W, int C, hipStream_t s);
 int launch_pack_pwc_input(const float* i1, const float* i2, float* x8, long P, hipStream_t s);

@@ -306,6 +306,63 @@ int launch_emit_du(const float* d, const float* a, float* u, long P, int ld, int
 }
 
 // ---------------------------------------------------------------------------
+// Shared image encoder of the batched recover calls (nets.py:57-65: every call of recover_net sees the same image, so
+// encoder A is evaluated for the first P pixels (B samples) only).
+//  share:  buf[(k*P + p)*ld + coff + c] = buf[p*ld + coff + c],  k = 1..copies-1      (forward: fan the skip tensors out)
+//  fold :  buf[p*ld + coff + c] += buf[(P+p)*ld + coff + c] + buf[(2P+p)*ld + coff + c] ...   (backward: sum the calls'
+//          output gradients; fixed order (x0 + x1) + x2)
+// ---------------------------------------------------------------------------
+template <int V, bool FOLD>
+__global__ __launch_bounds__(256) void share_fold_kernel(float* __restrict__ buf, long P, int ld, int coff, int C, int copies) {
+  const int CV = C / V;
+  const long total = P * CV;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long pix = e / CV;
+    const long o = pix * ld + coff + (e - pix * CV) * V;
+    if (V == 4) {
+      float4 v = *reinterpret_cast<const float4*>(buf + o);
+      for (int k = 1; k < copies; ++k) {
+        float4* q = reinterpret_cast<float4*>(buf + o + (long)k * P * ld);
+        if (FOLD) {
+          const float4 w = *q;
+          v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+        } else {
+          *q = v;
+        }
+      }
+      if (FOLD) *reinterpret_cast<float4*>(buf + o) = v;
+    } else {
+      float v = buf[o];
+      for (int k = 1; k < copies; ++k) {
+        if (FOLD) v += buf[o + (long)k * P * ld];
+        else buf[o + (long)k * P * ld] = v;
+      }
+      if (FOLD) buf[o] = v;
+    }
+  }
+}
+static int launch_share_fold(float* buf, long P, int ld, int coff, int C, int copies, bool fold, hipStream_t s) {
+  if (copies < 2 || C < 1) return UDET_OK;
+  const bool v4 = (ld % 4 == 0) && (coff % 4 == 0) && (C % 4 == 0);
+  const long n = P * (v4 ? C / 4 : C);
+  if (v4) {
+    if (fold) hipLaunchKernelGGL((share_fold_kernel<4, true>), dim3(grid_for(n)), dim3(256), 0, s, buf, P, ld, coff, C, copies);
+    else hipLaunchKernelGGL((share_fold_kernel<4, false>), dim3(grid_for(n)), dim3(256), 0, s, buf, P, ld, coff, C, copies);
+  } else {
+    if (fold) hipLaunchKernelGGL((share_fold_kernel<1, true>), dim3(grid_for(n)), dim3(256), 0, s, buf, P, ld, coff, C, copies);
+    else hipLaunchKernelGGL((share_fold_kernel<1, false>), dim3(grid_for(n)), dim3(256), 0, s, buf, P, ld, coff, C, copies);
+  }
+  UDET_HIP(hipGetLastError());
+  return UDET_OK;
+}
+int launch_share_samples(float* buf, long P, int ld, int coff, int C, int copies, hipStream_t s) {
+  return launch_share_fold(buf, P, ld, coff, C, copies, false, s);
+}
+int launch_fold_samples(float* buf, long P, int ld, int coff, int C, int copies, hipStream_t s) {
+  return launch_share_fold(buf, P, ld, coff, C, copies, true, s);
+}
+
+// ---------------------------------------------------------------------------
 // PWC input: x8[2B,H,W,4] = [img+0.5 (3) | 0] for the 2B stacked images   (model_pwcnet.py:39-56 adapt_x)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pack_pwc_input_kernel(const float* __restrict__ i1, const float* __restrict__ i2,

@@ -82,6 +82,9 @@ struct Plan {
   size_t ev_next = 0, ev_next_prefetch = 0;
   bool in_prefetch = false;
   bool concurrent = true;
+  // the last recover forward evaluated encoder A once for the B images and fanned its skip tensors out to the batched
+  // calls (true), or per sample on caller-packed inputs (false); the backward pass follows suit
+  bool enc_a_shared = false;
   size_t scratch_off[NLANE] = {}, scratch_floats = 0;   // split-K slabs
   size_t wgrad_off[NLANE] = {}, wgrad_floats = 0;       // wgrad partials (lanes that run filter gradients)
   ~Plan();

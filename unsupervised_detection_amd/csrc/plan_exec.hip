@@ -422,8 +422,17 @@ static int plan_rec_image_branch(Plan* P, int ncalls, float* ws, const Lane& ln)
   const Config& c = P->cfg;
   if (ncalls < 1) return UDET_OK;
   const long Ppix = (long)c.batch * c.img_h * c.img_w;
-  UDET_TRY(launch_pack_imgin(ws + P->buf(P->bid("image")).off, ws + P->buf(P->bid("rec.imgin")).off, Ppix, ncalls, ln.s));
-  for (int i = 0; i < 9; ++i) UDET_TRY(run_fwd(P, *find_layer(P->rec, std::string("a") + ENC_NAMES[i]), ncalls * c.batch, ws, ln));
+  // every call sees the same image: encoder A runs once on the B images, then the tensors the decoder reads (the slab
+  // segments aconv1/2/31/41/51 and aconv6) are fanned out to the other calls' samples
+  UDET_TRY(launch_pack_imgin(ws + P->buf(P->bid("image")).off, ws + P->buf(P->bid("rec.imgin")).off, Ppix, 1, ln.s));
+  for (int i = 0; i < 9; ++i) {
+    const Layer& L = *find_layer(P->rec, std::string("a") + ENC_NAMES[i]);
+    UDET_TRY(run_fwd(P, L, c.batch, ws, ln));
+    const Buf& y = P->buf(L.y);
+    if (ncalls > 1 && (y.name.find("concat") != std::string::npos || y.name == "rec.conv6"))
+      UDET_TRY(launch_share_samples(ws + y.off, (long)c.batch * y.h * y.w, y.ld, L.y_coff, L.cout, ncalls, ln.s));
+  }
+  P->enc_a_shared = true;
   return UDET_OK;
 }
 
@@ -438,8 +447,9 @@ int plan_recover_forward(Plan* P, int ncalls, float* ws, hipStream_t s, bool inp
                                     ws + P->buf(P->bid("mask")).off, ws + P->buf(P->bid("rec.fin")).off, Ppix, ncalls, s));
   if (ncalls < 1) return UDET_OK;
   if (!skip_enc_a) {
-    if (inputs_prepacked) {
+    if (inputs_prepacked) {  // caller-packed images may differ between the calls: per-sample encoder
       for (int i = 0; i < 9; ++i) UDET_TRY(run_fwd(P, *find_layer(P->rec, std::string("a") + ENC_NAMES[i]), N, ws, L0));
+      P->enc_a_shared = false;
     } else {
       UDET_TRY(plan_rec_image_branch(P, ncalls, ws, L0));
     }
@@ -532,10 +542,14 @@ static int rec_backward(Plan* P, int N, const char* dp, bool with_wgrad, bool ne
   auto D_ = [&](const std::string& n) { return P->bid(pre + n); };
   auto U_ = [&](const std::string& n) { return P->bid(upre + n); };
   auto Lr = [&](const std::string& n) { return find_layer(P->rec, n); };
-  auto wgrad = [&](const Layer& L, int dy, bool is_du) -> int {
+  auto wgrad = [&](const Layer& L, int dy, bool is_du, int n = -1) -> int {
     order_after(P, LD, LW);
-    return run_wgrad(P, L, N, dy, is_du, w_rec, g_rec, ws, LW);
+    return run_wgrad(P, L, n < 0 ? N : n, dy, is_du, w_rec, g_rec, ws, LW);
   };
+  // shared encoder A (plan_rec_image_branch): its activations exist for the B images only and are identical for every
+  // call, so the calls' output gradients are summed (fold) where they enter the encoder and its backward runs on B samples
+  const int ncopies = N / c.batch;
+  const bool a_shared = P->enc_a_shared && ncopies > 1;
   const Emit none;
   const float LEAK = 0.2f;
   // pred = resize(flow1)
@@ -582,7 +596,13 @@ static int rec_backward(Plan* P, int N, const char* dp, bool with_wgrad, bool ne
       if (e[0] == 'a' && !with_wgrad) continue;
       const Layer* L = Lr(std::string(e) + ENC_NAMES[i]);
       const int du = U_(P->buf(L->y).name.substr(4));  // dU of this layer's output (emitted by its consumer's dgrad)
-      if (with_wgrad) UDET_TRY(wgrad(*L, du, true));
+      const bool shared = e[0] == 'a' && a_shared;
+      const int Ne = shared ? c.batch : N;
+      if (shared && i == 8) {  // aconv6 half of conv6: dU was emitted per call above
+        const Buf& u = P->buf(du);
+        UDET_TRY(launch_fold_samples(ws + u.off, (long)c.batch * u.h * u.w, u.ld, L->y_coff, L->cout, ncopies, s));
+      }
+      if (with_wgrad) UDET_TRY(wgrad(*L, du, true, Ne));
       if (i == 0) {
         if (e[0] == 'b' && need_dfin) UDET_TRY(run_dgrad(P, *L, N, du, true, D_("fin"), 0, 0, -1, none, ws, LD));
         continue;
@@ -593,7 +613,11 @@ static int rec_backward(Plan* P, int N, const char* dp, bool with_wgrad, bool ne
       // this launch is the last writer of the previous encoder layer's output gradient: emit its dU
       Emit em;
       em.ubuf = U_(xname.substr(4)); em.abuf = L->x; em.c0 = 0; em.c1 = L->cin; em.act = ACT_LEAKY; em.alpha = LEAK;
-      UDET_TRY(run_dgrad(P, *L, N, du, true, dx, L->x_coff, slab_in ? 1 : 0, -1, em, ws, LD));
+      if (shared && slab_in) {  // the decoder's gradient of this skip segment, summed over the calls
+        const Buf& d = P->buf(dx);
+        UDET_TRY(launch_fold_samples(ws + d.off, (long)c.batch * d.h * d.w, d.ld, L->x_coff, L->cin, ncopies, s));
+      }
+      UDET_TRY(run_dgrad(P, *L, Ne, du, true, dx, L->x_coff, slab_in ? 1 : 0, -1, em, ws, LD));
     }
   return UDET_OK;
 }
