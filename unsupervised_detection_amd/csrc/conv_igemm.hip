@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "common.h"
+#include <algorithm>
 
 namespace udet {
 
@@ -741,8 +742,17 @@ static ConvCfg tune_cfg(ConvParams& p, hipStream_t stream) {
     if (p.Cout > 96 && bn < 64) continue;
     if (p.Cout > 96 && bn == 96 && p.Cout % 96 != 0 && p.Cout <= 128) continue;
     const long tiles = cfg_tiles(p, bm, bn);
-    for (int ks = 1; ks <= kcap; ks *= 2) {
-      if (ks > 1 && (tiles >= 512 || tiles * ks > 4096)) break;
+    std::vector<int> kss;
+    for (int ks = 1; ks <= kcap; ks *= 2) kss.push_back(ks);
+    // split counts that fill whole rounds of the 256 CUs (tiles*ks just below a multiple of 256): a 144-tile layer runs
+    // at 144/256 of the chip unsplit and at 1008/1024 with 7 splits
+    if (tiles < 512)
+      for (int k = 1; k <= 6; ++k) {
+        const int ks = (int)(256L * k / tiles);
+        if (ks >= 3 && ks <= kcap && (ks & (ks - 1)) != 0 && std::find(kss.begin(), kss.end(), ks) == kss.end()) kss.push_back(ks);
+      }
+    for (int ks : kss) {
+      if (ks > 1 && (tiles >= 512 || tiles * ks > 4096)) continue;
       if (tiles * ks < 96 && ks * 2 <= kcap) continue;  // hopelessly under-filled
       cand.push_back({bm, bn, ks, 1});
     }

@@ -9,6 +9,8 @@
 #include <unordered_map>
 
 #include "common.h"
+#include <algorithm>
+#include <vector>
 #include "conv_host.h"
 
 namespace udet {
@@ -506,8 +508,14 @@ int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream) {
       const int h = nsplit;
       float best_ms = 1e30f;
       int best = h;
+      // candidates: powers of two around the heuristic + the split counts that fill whole rounds of the 256 CUs
+      std::vector<int> nss = {h / 8, h / 4, h / 2, h, h * 2, h * 4};
+      for (int k : {1, 2, 3, 4, 6, 8}) {
+        const int ns = (int)(256L * k / tiles);
+        if (ns >= 1 && std::find(nss.begin(), nss.end(), ns) == nss.end()) nss.push_back(ns);
+      }
       for (int dma = 0; dma <= (dma_ok ? 1 : 0); ++dma)
-        for (int ns : {h / 8, h / 4, h / 2, h, h * 2, h * 4}) {
+        for (int ns : nss) {
           if (ns < 1 || ns > cap) continue;
           const int cfg = ns | (dma << 20);
           run(cfg);
