@@ -1,0 +1,66 @@
+"""Deterministic inputs / weights shared by oracle/make_golden.py (which produced tests/golden/*.npz from the reference's
+own Python) and the tests that replay them (TEST INFRASTRUCTURE ONLY).  Everything is drawn from numpy's frozen legacy
+generator (np.random.RandomState: stream guaranteed stable across numpy versions), so the fixtures only have to hold outputs."""
+from __future__ import annotations
+
+import zlib
+from collections import OrderedDict
+
+import numpy as np
+
+STEP_CFG = dict(batch_size=2, in_height=128, in_width=192, img_height=64, img_width=128, flow_normalizer=80.0, cbn=0.5,
+                epsilon=75.0, beta1=0.9)
+
+
+def tensor(name: str, shape, scale=1.0, offset=0.0):
+    """float32 array ~ offset + scale * N(0,1), seeded by the name."""
+    rs = np.random.RandomState(zlib.crc32(name.encode()) & 0x7fffffff)
+    return (offset + scale * rs.standard_normal(size=tuple(shape))).astype(np.float32)
+
+
+def params(specs):
+    """Weights for a (name, shape, init) spec list: fan-in scaled normal kernels, small random biases / beta, gamma ~ 1."""
+    out = OrderedDict()
+    for name, shape, _ in specs:
+        leaf = name.rsplit("/", 1)[1]
+        if leaf in ("kernel", "weights"):
+            fan_in = int(np.prod(shape[:-1]))
+            out[name] = tensor(name, shape, scale=(2.0 / fan_in) ** 0.5)
+        elif leaf == "gamma":
+            out[name] = tensor(name, shape, scale=0.1, offset=1.0)
+        else:  # bias / biases / beta
+            out[name] = tensor(name, shape, scale=0.05)
+    return out
+
+
+def smooth(name: str, shape, cell=16, passes=8):
+    """Low-frequency field in [0,1): random coarse grid, nearest-upsampled, box-filtered `passes` times (pure numpy)."""
+    n, h, w, c = shape
+    rs = np.random.RandomState(zlib.crc32(name.encode()) & 0x7fffffff)
+    hh, ww = h + 2 * passes, w + 2 * passes
+    g = rs.rand(n, -(-hh // cell), -(-ww // cell), c)
+    x = np.kron(g, np.ones((1, cell, cell, 1)))[:, :hh, :ww]
+    for _ in range(passes):
+        x = (x[:, :-2] + x[:, 1:-1] + x[:, 2:]) / 3.0
+        x = (x[:, :, :-2] + x[:, :, 1:-1] + x[:, :, 2:]) / 3.0
+    x = (x - x.min()) / (x.max() - x.min())
+    return x.astype(np.float32)
+
+
+def image_pair(batch=2, h=128, w=192):
+    """Two frames in [-0.5, 0.5]: the second is the first shifted by (2, 3) pixels plus 1 % noise."""
+    base = smooth("golden/frame", (batch, h + 8, w + 8, 3))
+    img1 = base[:, 4:4 + h, 4:4 + w] - 0.5
+    img2 = base[:, 2:2 + h, 1:1 + w] - 0.5 + 0.01 * tensor("golden/frame_noise", (batch, h, w, 3))
+    return np.ascontiguousarray(img1, np.float32), np.ascontiguousarray(img2, np.float32)
+
+
+def gt_mask(batch=2, h=128, w=192):
+    m = smooth("golden/gt", (batch, h, w, 1), cell=32, passes=4)
+    return (m > 0.55).astype(np.float32)
+
+
+def grad_summary(g: np.ndarray):
+    """What the fixtures keep of a gradient tensor: L2 norm, signed sum, the first 16 entries."""
+    f = np.asarray(g, np.float64).ravel()
+    return np.concatenate([[np.sqrt((f * f).sum()), f.sum()], np.pad(f[:16], (0, max(0, 16 - f.size)))]).astype(np.float64)

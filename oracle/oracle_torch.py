@@ -1,8 +1,10 @@
 """PyTorch-CPU restatement of the reference hot path (TEST INFRASTRUCTURE ONLY).
 
-PARITY UNPINNED (see oracle/__init__.py): no reference test / golden vector
-exists and TensorFlow 1.13.1 is not installable, so this file restates the
-reference *and* the TF-1.13 kernel semantics it relies on.
+PARITY (see oracle/__init__.py): pinned at the composition level by fixtures
+generated from the reference's own Python on a TF-1.13 stand-in
+(oracle/make_golden.py -> tests/golden/, tests/test_golden_reference.py); the
+TF-1.13 C++ kernel semantics (SAME padding, legacy resizes, inference BN) are
+restated here and in the stand-in, independently.
 
 All tensors are NHWC at this API (like the reference); convolution weights are
 HWIO.  ``dtype`` may be torch.float32 (the parity dtype) or torch.float64 (used

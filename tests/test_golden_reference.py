@@ -1,0 +1,232 @@
+"""Golden vectors produced by the REFERENCE's own Python (oracle/make_golden.py runs /root/reference's models/*.py on the
+eager TF-1.13 stand-in oracle/tf1_shim.py): they pin the oracle's composition on CPU and, under `-m gpu`, the HIP path
+directly.  /root/reference is not read here: inputs / weights are regenerated from oracle/golden_inputs.py, outputs come from
+tests/golden/*.npz.  Floating-point tolerance: 1e-3 relative to the tensor's scale (BASELINE.json north_star) for the HIP
+path; the CPU oracle (same arithmetic in a different op order) is held to 1e-4 / 1e-5; the warp is bit-exact."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import golden_inputs as G
+from oracle import oracle_np as ONP
+from oracle import oracle_torch as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+T = torch.from_numpy
+
+
+def gold(name):
+    return np.load(os.path.join(GOLD, name + ".npz"))
+
+
+def rel(a, ref):
+    a, ref = np.asarray(a, np.float64), np.asarray(ref, np.float64)
+    return float(np.abs(a - ref).max()) / max(1e-12, float(np.abs(ref).max()))
+
+
+def tparams(specs, dtype=torch.float32):
+    return {k: T(v).to(dtype) for k, v in G.params(specs).items()}
+
+
+class Cfg(O.Flags):
+    img_height, img_width, batch_size = G.STEP_CFG["img_height"], G.STEP_CFG["img_width"], G.STEP_CFG["batch_size"]
+    flow_normalizer, cbn, epsilon, beta1 = (G.STEP_CFG[k] for k in ("flow_normalizer", "cbn", "epsilon", "beta1"))
+
+
+def ops_inputs():
+    img = G.tensor("ops/warp_img", (2, 12, 16, 8))
+    flow = G.tensor("ops/warp_flow", (2, 12, 16, 2), scale=4.0)
+    flow[0, :2] = np.round(flow[0, :2])
+    return dict(img=img, flow=flow, c1=G.tensor("ops/cv_c1", (2, 10, 12, 16)), c2=G.tensor("ops/cv_c2", (2, 10, 12, 16)),
+                fl=G.tensor("ops/flow", (2, 16, 24, 2), scale=3.0, offset=0.7), pr=G.tensor("ops/pred", (2, 16, 24, 2), scale=3.0),
+                mk=np.abs(G.tensor("ops/mask", (2, 16, 24, 1), scale=0.4)).clip(0, 1))
+
+
+def eval_inputs():
+    pm = G.smooth("ops/pred_mask", (6, 32, 48, 1), cell=16, passes=3)
+    pm[1] = 1.0 - 0.5 * pm[1]
+    pm[2] = 0.05 * pm[2]
+    gm = (G.smooth("ops/gt_mask", (6, 32, 48, 1), cell=16, passes=3) > 0.5).astype(np.float32)
+    gm[2] = 0.0
+    return pm, gm
+
+
+# ----------------------------------------------------------------------------------------------- CPU: oracle vs reference
+
+def test_fixture_manifest_lists_the_references_variables():
+    with open(os.path.join(GOLD, "names.json")) as f:
+        m = json.load(f)["variables_created_by_the_reference"]
+    for key, specs in (("generator_net + recover_net", O.generator_param_specs() + O.recover_param_specs()),
+                       ("ModelPWCNet", O.pwc_param_specs())):
+        created = {v["canonical"]: tuple(v["shape"]) for v in m[key] if not v["canonical"].endswith(("moving_mean", "moving_variance"))}
+        assert created == {n: tuple(s) for n, s, _ in specs}
+    # the generator's scope string is the name scope "MaskNet/": TF variable names carry a double slash
+    assert m["generator_net + recover_net"][0]["tf"] == "MaskNet//conv1/kernel"
+
+
+def test_oracle_ops_match_reference():
+    g, x = gold("ops"), ops_inputs()
+    w = O.dense_image_warp(T(x["img"]), T(x["flow"])).numpy()
+    assert np.array_equal(w, g["warp"])  # same float32 expression order as core_warp.py:145-149
+    assert np.array_equal(ONP.dense_image_warp(x["img"], x["flow"]), g["warp"])
+    assert rel(O.cost_volume(T(x["c1"]), T(x["c2"])).numpy(), g["cost_volume"]) < 1e-6
+    assert rel(O.preprocess_flow_batch(T(x["fl"])).numpy(), g["preprocess_flow_batch"]) < 1e-5
+    for cbn in (0.5, 0.4, 1.0):
+        assert rel(O.charbonnier_loss(T(x["fl"]), T(x["pr"]), T(x["mk"]), cbn).numpy(), g["charbonnier_%g" % cbn]) < 1e-5
+
+
+def test_oracle_evaluation_matches_reference():
+    g = gold("ops")
+    pm, gm = eval_inputs()
+    bs = np.array([ONP.compute_boundary_score((pm[i, :, :, 0] > 0.1).astype(np.float32)) for i in range(6)])
+    assert np.allclose(bs, g["boundary_score_np"], atol=1e-7) and np.allclose(bs, g["boundary_score_tf"], atol=1e-6)
+    assert np.allclose(ONP.compute_all_IoU(pm, gm), g["all_iou"], atol=1e-6)
+    iou = [ONP.compute_IoU(gm[i, :, :, 0], pm[i, :, :, 0]) for i in range(6)]
+    iou = [float(r[0]) if isinstance(r, tuple) else float(r) for r in iou]
+    assert np.allclose(iou, g["test_generator_iou"], atol=1e-6)
+    assert np.allclose([ONP.compute_mae(gm[i, :, :, 0], pm[i, :, :, 0]) for i in range(6)], g["test_generator_mae"], atol=1e-6)
+
+
+def test_oracle_nets_match_reference():
+    g = gold("nets")
+    pg, pr = tparams(O.generator_param_specs()), tparams(O.recover_param_specs())
+    image = T(G.smooth("nets/image", (2, 64, 128, 3)) - 0.5)
+    flow = T(G.smooth("nets/flow", (2, 64, 128, 2)) * 2.0 - 1.0)
+    with torch.no_grad():
+        mask = O.generator_net(pg, image, O.preprocess_flow_batch(flow))
+        pred = O.recover_net(pr, image, flow * (1.0 - T(g["mask"])), T(g["mask"]))
+    assert float(np.abs(mask.numpy() - g["mask"]).max()) < 1e-5
+    assert rel(pred.numpy(), g["pred"]) < 1e-4
+
+
+def test_oracle_pwc_matches_reference():
+    g = gold("pwc")
+    img1, img2 = G.image_pair()
+    with torch.no_grad():
+        flow, _ = O.pwc_forward(tparams(O.pwc_param_specs()), T(img1), T(img2))
+    assert rel(flow.numpy(), g["flow"]) < 1e-4
+
+
+def _summaries_close(got: np.ndarray, ref: np.ndarray, tol, floor):
+    """got / ref = [L2 norm, sum, first 16 entries] of a gradient tensor; tolerance relative to the tensor's norm."""
+    scale = max(float(ref[0]), floor)
+    assert abs(got[0] - ref[0]) < tol * scale
+    assert float(np.abs(got[2:] - ref[2:]).max()) < tol * scale
+
+
+def test_oracle_step_matches_reference_build_train_graph():
+    g = gold("step")
+    c = G.STEP_CFG
+    img1, img2 = G.image_pair(c["batch_size"], c["in_height"], c["in_width"])
+    pp = tparams(O.pwc_param_specs())
+    with torch.no_grad():
+        image, flow, _ = O.prepare_inputs(pp, T(img1), T(img2), Cfg)
+    assert rel(image.numpy(), g["image"]) < 1e-6 and rel(flow.numpy(), g["flow"]) < 1e-4
+    pg = {k: v.requires_grad_(True) for k, v in tparams(O.generator_param_specs()).items()}
+    pr = {k: v.requires_grad_(True) for k, v in tparams(O.recover_param_specs()).items()}
+    out = O.forward_from_flow(pg, pr, T(g["image"]), T(g["flow"]), Cfg)
+    assert float(np.abs(out["mask"].detach().numpy() - g["mask"]).max()) < 1e-5
+    for k in ("generator", "recover", "red_rate", "red_rate_compl", "reconstruction_loss", "reconstruction_compl_loss",
+              "denominator_red_rate", "denominator_red_rate_compl"):
+        assert abs(float(out[k]) - float(g[k])) < 1e-4 * max(1.0, abs(float(g[k]))), k
+    m = out["mask"].detach()
+    pf = (out["pred"].detach() * m + T(g["flow"]) * (1 - m)).numpy()  # adversarial_learner.py:251
+    assert rel(pf, g["pred_flow"]) < 1e-4
+    for tag, loss, params in (("gen", out["generator"], pg), ("rec", out["recover"], pr)):
+        grads = O.grads_of(loss, params)
+        floor = 1e-3 * max(float(g["rawgrad/%s/%s" % (tag, k)][0]) for k in grads)
+        clipped, changed = O.clip_or_noise(grads, 0.2, tag == "gen")
+        assert not changed
+        for k in grads:
+            _summaries_close(G.grad_summary(grads[k].numpy()), g["rawgrad/%s/%s" % (tag, k)], 2e-3, floor)
+            _summaries_close(G.grad_summary(clipped[k].numpy()), g["grad/%s/%s" % (tag, k)], 2e-3, floor)
+
+
+# ----------------------------------------------------------------------------------------------- GPU: HIP path vs reference
+
+@pytest.fixture(scope="module")
+def gpu_env():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from unsupervised_detection_amd import weights as W
+    from unsupervised_detection_amd.engine import Engine, EngineConfig
+    c = G.STEP_CFG
+    eng = Engine(EngineConfig(batch_size=c["batch_size"], in_height=c["in_height"], in_width=c["in_width"], img_height=c["img_height"],
+                              img_width=c["img_width"]))
+    flat = {"pwc": W.from_dict(tparams(O.pwc_param_specs()), W.NET_PWC).cuda(),
+            "gen": W.from_dict(tparams(O.generator_param_specs()), W.NET_GEN).cuda(),
+            "rec": W.from_dict(tparams(O.recover_param_specs()), W.NET_REC).cuda()}
+    eng.pack_pwc(flat["pwc"])
+    eng.pack_trainable(flat["gen"], flat["rec"])
+    return dict(eng=eng, W=W, flat=flat)
+
+
+@pytest.mark.gpu
+def test_hip_ops_match_reference():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from unsupervised_detection_amd import ops
+    g, x = gold("ops"), ops_inputs()
+    w = ops.dense_image_warp(T(x["img"]).cuda(), T(x["flow"]).cuda()).cpu().numpy()
+    assert np.array_equal(w, g["warp"])  # bit-exact: index math and interpolation order of core_warp.py
+    cv = ops.cost_volume(T(x["c1"]).cuda(), T(x["c2"]).cuda()).cpu().numpy()
+    assert rel(cv, g["cost_volume"]) < 1e-5
+
+
+@pytest.mark.gpu
+def test_hip_evaluation_matches_reference():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from unsupervised_detection_amd import evaluation as E
+    g = gold("ops")
+    pm, gm = eval_inputs()
+    pmd, gmd = T(pm).cuda().contiguous(), T(gm).cuda().contiguous()
+    bs = [E.compute_boundary_score((pm[i, :, :, 0] > 0.1).astype(np.float32)) for i in range(6)]
+    assert np.allclose(bs, g["boundary_score_tf"], atol=1e-6)
+    assert np.array_equal(E.disambiguate_forw_back(pmd).cpu().numpy(), g["disambiguate"])
+    assert np.allclose(E.compute_all_IoU(pmd, gmd), g["all_iou"], atol=1e-6)
+    iou = [E.compute_IoU(gm[i, :, :, 0], pm[i, :, :, 0]) for i in range(6)]
+    iou = [float(r[0]) if isinstance(r, tuple) else float(r) for r in iou]
+    assert np.allclose(iou, g["test_generator_iou"], atol=1e-6)
+    assert np.allclose([E.compute_mae(gm[i, :, :, 0], pm[i, :, :, 0]) for i in range(6)], g["test_generator_mae"], atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_hip_pwc_matches_reference(gpu_env):
+    g = gold("pwc")
+    img1, img2 = G.image_pair()
+    flow = gpu_env["eng"].pwc_forward(T(img1).cuda(), T(img2).cuda()).cpu().numpy()
+    assert rel(flow, g["flow"]) < 1e-3
+
+
+@pytest.mark.gpu
+def test_hip_step_matches_reference_build_train_graph(gpu_env):
+    g = gold("step")
+    eng, W, flat = gpu_env["eng"], gpu_env["W"], gpu_env["flat"]
+    c = G.STEP_CFG
+    img1, img2 = G.image_pair(c["batch_size"], c["in_height"], c["in_width"])
+    eng.forward(T(img1).cuda(), T(img2).cuda(), 3)
+    assert rel(eng.buffer("image").cpu().numpy(), g["image"]) < 1e-5
+    assert rel(eng.buffer("flow").cpu().numpy(), g["flow"]) < 1e-3
+    # feed the reference's own flow so that PWC rounding (1e-4 of a sigmoid((l0-l1)/10)) does not leak into the rest
+    eng.forward_from_flow(T(g["image"]).cuda(), T(g["flow"]).cuda(), 3)
+    mask = eng.buffer("mask").cpu().numpy()
+    assert float(np.abs(mask - g["mask"]).max()) < 1e-3
+    B = c["batch_size"]
+    pred = eng.buffer("pred").cpu().numpy()[:B]
+    assert rel(pred * mask + g["flow"] * (1 - mask), g["pred_flow"]) < 1e-3
+    L = eng.losses()
+    for k in L:
+        assert abs(L[k] - float(g[k])) < 1e-3 * max(1.0, abs(float(g[k]))), (k, L[k], float(g[k]))
+    g_gen = torch.zeros(W.param_total(W.NET_GEN), device="cuda")
+    g_rec = torch.zeros(W.param_total(W.NET_REC), device="cuda")
+    eng.backward(3, flat["gen"], flat["rec"], g_gen, g_rec)
+    for tag, net, got in (("gen", W.NET_GEN, g_gen.cpu()), ("rec", W.NET_REC, g_rec.cpu())):
+        d = W.as_dict(got, net)
+        floor = 1e-3 * max(float(g["rawgrad/%s/%s" % (tag, k)][0]) for k in d)
+        for k, v in d.items():
+            _summaries_close(G.grad_summary(v.numpy()), g["rawgrad/%s/%s" % (tag, k)], 2e-3, floor)
+            _summaries_close(G.grad_summary(v.clamp(-0.2, 0.2).numpy()), g["grad/%s/%s" % (tag, k)], 2e-3, floor)
