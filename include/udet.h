@@ -181,8 +181,13 @@ int udet_train_step(udet_plan* plan, int which, const float* img1, const float* 
 int udet_autotune(udet_plan* plan, const float* w_gen, const float* w_rec, float* g_gen, float* g_rec, void* workspace,
                   void* stream);
 int udet_tuned_shapes(void);
-/* tuning hook used by tools/conv_bench.py: force (bm, bn, split-K) for every convolution launch; (0,0,-1) restores */
+/* tuning hook used by tools/conv_bench.py and the kernel-family tests: force (bm, bn, split-K) for every convolution launch
+ * (bm bit 16: non-specialised kernel, bit 17: LDS-DMA staging, bit 18: tile-resident kernel with bm & 0xffff = tile height);
+ * (0,0,-1) restores.  A forced family a launch is not eligible for falls back to the built-in choice. */
 void udet_debug_force_conv(int bm, int bn, int ks);
+/* what the most recent convolution launch actually ran: family (0 plain, 1 wave-specialised, 2 LDS-DMA, 3 tile-resident)
+ * | tile rows << 8 | split count << 20 */
+int udet_debug_last_conv(void);
 
 /* Measurement aid (bench.py): between begin/end every convolution / warp / cost-volume launch group is
  * bracketed by HIP events on the launch stream.  out[cat*4 + {0,1,2,3}] = {groups, total ms, algorithmic

@@ -127,6 +127,71 @@ def test_conv2d_transpose(ops, n, h, w, cin, cout):
     assert y.shape == ref.shape and (y - ref).abs().max() < 1e-4 * max(1.0, float(ref.abs().max()))
 
 
+# every convolution kernel family on the same problems (the autotuner picks among them per shape at run time):
+# bm bit 16 = non-specialised 256-thread kernel, bit 17 = LDS-DMA staging, bit 18 = tile-resident kernel (low bits = tile height)
+FAMILIES = {"plain": (128 + (1 << 16), 32, 1), "wave_spec": (128, 32, 1), "lds_dma": (128 + (1 << 17), 32, 1),
+            "lds_dma_split3": (128 + (1 << 17), 32, 3), "tile8": ((1 << 18) + 8, 0, 1), "tile4": ((1 << 18) + 4, 0, 1)}
+THIN_CASES = [
+    # n,h,w,cin,cout,k,s
+    (1, 32, 64, 16, 16, 3, 1),    # 16-wide MFMA tile kernel
+    (2, 16, 64, 32, 32, 3, 1),
+    (1, 32, 64, 104, 16, 4, 1),   # recover deconv1: four channel-block passes
+    (1, 32, 64, 64, 64, 3, 1),    # two N tiles
+    (1, 32, 48, 4, 16, 7, 2),     # stride-2 forward, 7x7 over the ld=4 input
+    (1, 32, 64, 16, 32, 5, 2),    # stride 2: backward-data runs four parity classes, 16 output channels
+    (1, 32, 64, 32, 64, 3, 2),
+]
+
+
+@pytest.fixture
+def force_conv():
+    import ctypes
+    from unsupervised_detection_amd._ffi import lib
+    lib.udet_debug_force_conv.restype = None
+    lib.udet_debug_force_conv.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    lib.udet_debug_last_conv.restype = ctypes.c_int
+    lib.udet_debug_last_conv.argtypes = []
+    yield lib
+    lib.udet_debug_force_conv(0, 0, -1)
+
+
+WS_OF = {"plain": 0, "wave_spec": 1, "lds_dma": 2, "lds_dma_split3": 2, "tile8": 3, "tile4": 3}
+
+
+@pytest.mark.parametrize("family", list(FAMILIES))
+@pytest.mark.parametrize("case", THIN_CASES)
+def test_conv_kernel_families(ops, force_conv, family, case):
+    n, h, w, cin, cout, k, s = case
+    x = rnd(n, h, w, cin, seed=21).double().requires_grad_(True)
+    wt = rnd(k, k, cin, cout, seed=22, scale=(2.0 / (k * k * cin)) ** 0.5).double()
+    b = rnd(cout, seed=23, scale=0.1).double()
+    y = _oracle_conv(x, wt, b, s, 1, "leaky", 0.1, False)
+    lin = O.conv2d_same(x, wt, None, s, 1)
+    dy = rnd(*y.shape, seed=24).double()
+    gx, = torch.autograd.grad((lin * dy).sum(), [x])
+    force_conv.udet_debug_force_conv(*FAMILIES[family])
+    got = ops.conv2d(x.detach().float().cuda(), wt.float().cuda(), b.float().cuda(), s, 1, "leaky", 0.1, False).cpu()
+    assert (force_conv.udet_debug_last_conv() & 0xff) == WS_OF[family]  # the family under test really ran
+    assert (got - y.detach().float()).abs().max() < 1e-4 * max(1.0, float(y.abs().max()))
+    # backward-data of the linear layer (no act' on load: the form the step uses, dU being materialised by its producer)
+    dx = ops.conv2d_backward_data(dy.float().cuda(), lin.detach().float().cuda(), wt.float().cuda(), (h, w), s, 1, "none", 0.0).cpu()
+    if WS_OF[family] != 3 or cin <= 64:  # the tile-resident kernel takes at most 64 output channels (= cin here)
+        assert (force_conv.udet_debug_last_conv() & 0xff) == WS_OF[family]
+    assert (dx - gx.float()).abs().max() < 2e-4 * max(1.0, float(gx.abs().max()))
+
+
+@pytest.mark.parametrize("family", list(FAMILIES))
+def test_conv2d_transpose_kernel_families(ops, force_conv, family):
+    x = rnd(2, 12, 20, 64, seed=25)
+    wt = rnd(4, 4, 32, 64, seed=26, scale=(1.0 / (16 * 64)) ** 0.5)
+    b = rnd(32, seed=27, scale=0.1)
+    ref = O.conv2d_transpose_k4s2_same(x.double(), wt.double(), b.double()).float()
+    force_conv.udet_debug_force_conv(*FAMILIES[family])
+    y = ops.conv2d_transpose4x4s2(x.cuda(), wt.cuda(), b.cuda()).cpu()
+    assert (force_conv.udet_debug_last_conv() & 0xff) == WS_OF[family]
+    assert (y - ref).abs().max() < 1e-4 * max(1.0, float(ref.abs().max()))
+
+
 def test_bad_arguments_raise(ops):
     x = torch.zeros(1, 4, 4, 6, device="cuda")
     with pytest.raises(ValueError):

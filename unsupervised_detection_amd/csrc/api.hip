@@ -42,6 +42,7 @@ using namespace udet;
 extern "C" {
 
 int udet_version(void) { return 101; }
+int udet_debug_last_conv(void) { return conv_last_config(); }
 void udet_debug_force_conv(int bm, int bn, int ks) { conv_force_config(bm, bn, ks); }
 const char* udet_last_error(void) { return g_err; }
 
@@ -146,7 +147,9 @@ int udet_conv2d_transpose4x4s2(const float* x, const float* w_hwoi, const float*
     ldx = kc;
   }
   float* part = ar.take(SPLITK_FLOATS);
-  if (!wp || !part) { set_error("conv2d_transpose: workspace too small"); return UDET_ERR_ARG; }
+  float* zero = ar.take(64);
+  if (!wp || !part || !zero) { set_error("conv2d_transpose: workspace too small"); return UDET_ERR_ARG; }
+  UDET_HIP(hipMemsetAsync(zero, 0, 64 * sizeof(float), stream));
   // w is [t][cout][cin]; B operand wants [t][k=cin][n=cout]  -> mode 1 with (R=cout, C=cin)
   UDET_TRY(launch_pack_weights(w_hwoi, wp, 16, cout, cin, kc, ldw, kc, 0, 1, nullptr, stream));
   for (int cls = 0; cls < conv_dgrad_classes(2, 2 * h, 2 * w); ++cls) {
@@ -156,6 +159,7 @@ int udet_conv2d_transpose4x4s2(const float* x, const float* w_hwoi, const float*
     p.x = xin; p.ldx = ldx; p.wp = wp; p.Kc = kc; p.ldw = ldw; p.bias = bias;
     p.y = y; p.ldy = cout; p.Cout = cout;
     p.partial = part; p.partial_cap = SPLITK_FLOATS;
+    p.zero16 = zero;
     UDET_TRY(launch_conv(p, stream));
   }
   return UDET_OK;
@@ -190,7 +194,9 @@ int udet_conv2d_backward_data(const float* dy, const float* y_saved, const float
     ldy = kc;
   }
   float* part = ar.take(SPLITK_FLOATS);
-  if (!wp || !part) { set_error("conv2d_backward_data: workspace too small"); return UDET_ERR_ARG; }
+  float* zero = ar.take(64);
+  if (!wp || !part || !zero) { set_error("conv2d_backward_data: workspace too small"); return UDET_ERR_ARG; }
+  UDET_HIP(hipMemsetAsync(zero, 0, 64 * sizeof(float), stream));
   UDET_TRY(launch_pack_weights(w_hwio, wp, kh * kw, cin, cout, kc, ldw, kc, 0, 1, nullptr, stream));
   for (int cls = 0; cls < conv_dgrad_classes(stride, h, w); ++cls) {
     ConvParams p;
@@ -200,6 +206,7 @@ int udet_conv2d_backward_data(const float* dy, const float* y_saved, const float
     p.wp = wp; p.Kc = kc; p.ldw = ldw;
     p.y = dx; p.ldy = cin; p.Cout = cin;
     p.partial = part; p.partial_cap = SPLITK_FLOATS;
+    p.zero16 = zero;
     UDET_TRY(launch_conv(p, stream));
   }
   return UDET_OK;

@@ -612,6 +612,8 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const ConvPar
 }
 
 static int g_force_bm = 0, g_force_bn = 0, g_force_ks = -1, g_force_ws = -1;
+static int g_last_cfg = 0;  // kernel family / tile / split count of the most recent launch_conv (debug query)
+int conv_last_config() { return g_last_cfg; }
 void conv_force_config(int bm, int bn, int ks) {
   g_force_bm = bm & 0xffff; g_force_bn = bn; g_force_ks = ks;
   g_force_ws = (bm >> 16) & 1 ? 0 : ((bm >> 17) & 1 ? 2 : ((bm >> 18) & 1 ? 3 : -1));  // bit 16: non-specialised, 17: LDS-DMA, 18: tile kernel
@@ -658,8 +660,8 @@ static int max_ksplit(const ConvParams& p) {  // capacity / minimum-work bound o
   while (ks > 1 && per_split * ks > p.partial_cap) --ks;
   return ks < 1 ? 1 : ks;
 }
-struct TileGeom;
-size_t conv_tile_lds_bytes(const ConvParams& p, int th, TileGeom* gout);
+struct TileGeoms;
+size_t conv_tile_lds_bytes(const ConvParams& p, int th, TileGeoms* gout);
 int launch_conv_tile(const ConvParams& p, int th, hipStream_t stream);
 static bool tile_ok(const ConvParams& p, int th) {
   const size_t b = conv_tile_lds_bytes(p, th, nullptr);
@@ -843,6 +845,7 @@ int launch_conv(ConvParams& p, hipStream_t stream) {
   if (c.ws == 2 && !dma_ok(p)) c.ws = 1;
   if (g_force_ws == 3) { c.ws = 3; c.bm = (g_force_bm == 4) ? 4 : 8; }
   if (c.ws == 3 && !tile_ok(p, c.bm)) { c = heuristic_cfg(p); }
+  g_last_cfg = (c.ws & 0xff) | ((c.bm & 0xfff) << 8) | ((c.ks & 0xff) << 20);
   return run_cfg(p, c, stream);
 }
 

@@ -9,8 +9,9 @@
 //      (im2col never materialised), 4 waves x (TH/4) tile rows each,
 //      (layers deeper than 32 channels repeat 1-3 per block of 32 channels, accumulating in registers),
 //   4. runs the common epilogue (bias / activation / residual / second output / dU emission).
-// Same ConvParams contract as conv_igemm (tap list, NN x2 read, TF SAME padding through the tap offsets); one parity
-// class only (forward convolutions and stride-1 backward-data).
+// Same ConvParams contract as conv_igemm (tap list, NN x2 read, TF SAME padding through the tap offsets).  The four
+// output-parity classes of a stride-2 backward-data pass / transposed convolution are blockIdx.z: each class is a stride-1
+// convolution over the dY grid with its own taps (and its own halo geometry) whose outputs land on one sub-lattice.
 #include "common.h"
 
 namespace udet {
@@ -32,19 +33,26 @@ __device__ __forceinline__ void tile_epilogue(const ConvParams& p, int off, int 
 struct TileGeom {
   int min_dy, min_dx, PH, PW;  // tile origin offset and extent on the (logical, post-upsample) input grid
 };
+struct TileGeoms {
+  TileGeom g[4];  // per output-parity class
+};
 
 template <int TH>
-__global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams p, const TileGeom g) {
+__global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams p, const TileGeoms gs) {
   constexpr int TW = 32;
   constexpr int TM = TH / 4;  // tile rows (MFMA M blocks) per wave
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int cls = blockIdx.z;
+  const TileGeom g = gs.g[cls];
+  const int tap0 = p.cls_tap[cls], ntc = p.cls_tap[cls + 1] - tap0;
+  const int ooy = p.ncls > 1 ? (cls >> 1) : p.ooy, oox = p.ncls > 1 ? (cls & 1) : p.oox;
   const int PIX = g.PH * g.PW;
   const int PIXP = PIX | 1;                       // odd row stride: the 4 transposing stores of a float4 spread over banks
   const int CB = p.Kc < 32 ? p.Kc : 32;           // channels resident per pass (deep layers walk Kc in blocks of 32)
   float* T = smem;                                // [CB][PIXP]
   float* Wl = smem + (size_t)CB * PIXP;           // [ntaps*CB][32]
-  int* tapoff = reinterpret_cast<int*>(Wl + (size_t)p.ntaps * CB * 32);  // [ntaps]
-  int* pixoff = tapoff + p.ntaps;                 // [PIX]
+  int* tapoff = reinterpret_cast<int*>(Wl + (size_t)ntc * CB * 32);  // [ntc]
+  int* pixoff = tapoff + ntc;                 // [PIX]
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, lh = lane >> 5;
   const int tiles_x = (p.OWq + TW - 1) / TW, tiles_y = (p.OHq + TH - 1) / TH;
@@ -57,7 +65,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams p, cons
   const float* xb = p.x + (size_t)n * Hs * Ws * p.ldx + p.x_coff;
 
   // tap -> tile offset; tile pixel -> global element offset (-1: zero padding), once per workgroup
-  for (int i = t; i < p.ntaps; i += 256) tapoff[i] = (p.taps[i].dy - g.min_dy) * g.PW + (p.taps[i].dx - g.min_dx);
+  for (int i = t; i < ntc; i += 256) tapoff[i] = (p.taps[tap0 + i].dy - g.min_dy) * g.PW + (p.taps[tap0 + i].dx - g.min_dx);
   for (int pix = t; pix < PIX; pix += 256) {
     const int py = pix / g.PW, px = pix - py * g.PW;
     const int iy = iy0 + py, ix = ix0 + px;
@@ -91,19 +99,19 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams p, cons
     }
     // ---- 2. weights [tap][c][32 columns of this N tile] ---------------------------------------------------------
     const int cw_shift = (cw & (cw - 1)) == 0 ? __builtin_ctz(cw) : -1;
-    for (int e = t; e < p.ntaps * cw * 8; e += 256) {
+    for (int e = t; e < ntc * cw * 8; e += 256) {
       const int c4 = e & 7, row = e >> 3;                 // row = tap*cw + c
       const int tap = cw_shift >= 0 ? row >> cw_shift : row / cw, c = row - tap * cw;
       const int nn = n0 + c4 * 4;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (nn < p.ldw) v = *reinterpret_cast<const float4*>(p.wp + ((size_t)p.taps[tap].widx * p.Kc + c0 + c) * p.ldw + nn);
+      if (nn < p.ldw) v = *reinterpret_cast<const float4*>(p.wp + ((size_t)p.taps[tap0 + tap].widx * p.Kc + c0 + c) * p.ldw + nn);
       *reinterpret_cast<float4*>(Wl + (size_t)row * 32 + c4 * 4) = v;
     }
     __syncthreads();
 
     // ---- 3. taps x channels -------------------------------------------------------------------------------------
     const int kpairs = cw >> 1;
-    for (int tap = 0; tap < p.ntaps; ++tap) {
+    for (int tap = 0; tap < ntc; ++tap) {
       const int off = tapoff[tap];
       const float* wrow = Wl + (size_t)(tap * cw + lh) * 32 + li;
       for (int kk = 0; kk < kpairs; ++kk) {
@@ -126,7 +134,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams p, cons
     for (int r = 0; r < 16; ++r) {
       const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
       if (ox >= p.OWq) continue;
-      const int off = (n * p.OH + oy * p.osy + p.ooy) * p.OW + ox * p.osx + p.oox;
+      const int off = (n * p.OH + oy * p.osy + ooy) * p.OW + ox * p.osx + oox;
       tile_epilogue(p, off, nn, acc[i][r]);
     }
   }
@@ -137,17 +145,21 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams p, cons
 // The tile's channel stride is == 16 (mod 32) so the four channel groups of a wave read disjoint banks.
 typedef float floatx4 __attribute__((ext_vector_type(4)));
 template <int TH>
-__global__ __launch_bounds__(256) void conv_tile16_kernel(const ConvParams p, const TileGeom g) {
+__global__ __launch_bounds__(256) void conv_tile16_kernel(const ConvParams p, const TileGeoms gs) {
   constexpr int TW = 32;
   constexpr int TM = TH / 4;
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int cls = blockIdx.z;
+  const TileGeom g = gs.g[cls];
+  const int tap0 = p.cls_tap[cls], ntc = p.cls_tap[cls + 1] - tap0;
+  const int ooy = p.ncls > 1 ? (cls >> 1) : p.ooy, oox = p.ncls > 1 ? (cls & 1) : p.oox;
   const int PIX = g.PH * g.PW;
   const int PIXP = ((PIX + 15) & ~31) + 16;       // >= PIX, == 16 (mod 32)
   const int CB = p.Kc < 32 ? p.Kc : 32;
   float* T = smem;                                // [CB][PIXP]
   float* Wl = smem + (size_t)CB * PIXP;           // [ntaps*CB][16]
-  int* tapoff = reinterpret_cast<int*>(Wl + (size_t)p.ntaps * CB * 16);
-  int* pixoff = tapoff + p.ntaps;
+  int* tapoff = reinterpret_cast<int*>(Wl + (size_t)ntc * CB * 16);
+  int* pixoff = tapoff + ntc;
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lp = lane & 15, lg = lane >> 4;
   const int tiles_x = (p.OWq + TW - 1) / TW, tiles_y = (p.OHq + TH - 1) / TH;
@@ -159,7 +171,7 @@ __global__ __launch_bounds__(256) void conv_tile16_kernel(const ConvParams p, co
   const int Hs = p.H >> p.up_shift, Ws = p.W >> p.up_shift;
   const float* xb = p.x + (size_t)n * Hs * Ws * p.ldx + p.x_coff;
 
-  for (int i = t; i < p.ntaps; i += 256) tapoff[i] = (p.taps[i].dy - g.min_dy) * g.PW + (p.taps[i].dx - g.min_dx);
+  for (int i = t; i < ntc; i += 256) tapoff[i] = (p.taps[tap0 + i].dy - g.min_dy) * g.PW + (p.taps[tap0 + i].dx - g.min_dx);
   for (int pix = t; pix < PIX; pix += 256) {
     const int py = pix / g.PW, px = pix - py * g.PW;
     const int iy = iy0 + py, ix = ix0 + px;
@@ -195,18 +207,18 @@ __global__ __launch_bounds__(256) void conv_tile16_kernel(const ConvParams p, co
       d[0] = v.x; d[PIXP] = v.y; d[2 * PIXP] = v.z; d[3 * PIXP] = v.w;
     }
     const int cw_shift = (cw & (cw - 1)) == 0 ? __builtin_ctz(cw) : -1;
-    for (int e = t; e < p.ntaps * cw * 4; e += 256) {
+    for (int e = t; e < ntc * cw * 4; e += 256) {
       const int c4 = e & 3, row = e >> 2;
       const int tap = cw_shift >= 0 ? row >> cw_shift : row / cw, c = row - tap * cw;
       const int nn = n0 + c4 * 4;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (nn < p.ldw) v = *reinterpret_cast<const float4*>(p.wp + ((size_t)p.taps[tap].widx * p.Kc + c0 + c) * p.ldw + nn);
+      if (nn < p.ldw) v = *reinterpret_cast<const float4*>(p.wp + ((size_t)p.taps[tap0 + tap].widx * p.Kc + c0 + c) * p.ldw + nn);
       *reinterpret_cast<float4*>(Wl + (size_t)row * 16 + c4 * 4) = v;
     }
     __syncthreads();
 
     const int kquads = cw >> 2;
-    for (int tap = 0; tap < p.ntaps; ++tap) {
+    for (int tap = 0; tap < ntc; ++tap) {
       const int off = tapoff[tap];
       const float* wrow = Wl + (size_t)(tap * cw + lg) * 16 + lp;
       for (int kk = 0; kk < kquads; ++kk) {
@@ -232,36 +244,43 @@ __global__ __launch_bounds__(256) void conv_tile16_kernel(const ConvParams p, co
       for (int r = 0; r < 4; ++r) {
         const int ox = ox0 + h * 16 + lg * 4 + r;
         if (ox >= p.OWq) continue;
-        const int off = (n * p.OH + oy * p.osy + p.ooy) * p.OW + ox * p.osx + p.oox;
+        const int off = (n * p.OH + oy * p.osy + ooy) * p.OW + ox * p.osx + oox;
         tile_epilogue(p, off, nn, acc[i][h][r]);
       }
   }
 }
 
-// LDS bytes of the tile kernel for this launch at tile height th (0: not eligible)
-size_t conv_tile_lds_bytes(const ConvParams& p, int th, TileGeom* gout) {
-  if (p.ncls > 1 || p.ntaps < 1 || p.xa != nullptr || p.Kc % 4 != 0 || p.isy != p.isx || p.isy < 1 || p.isy > 2) return 0;
-  int mn_y = 1 << 30, mx_y = -(1 << 30), mn_x = 1 << 30, mx_x = -(1 << 30);
-  for (int t = 0; t < p.ntaps; ++t) {
-    mn_y = p.taps[t].dy < mn_y ? p.taps[t].dy : mn_y; mx_y = p.taps[t].dy > mx_y ? p.taps[t].dy : mx_y;
-    mn_x = p.taps[t].dx < mn_x ? p.taps[t].dx : mn_x; mx_x = p.taps[t].dx > mx_x ? p.taps[t].dx : mx_x;
-  }
-  TileGeom g;
-  g.min_dy = mn_y; g.min_dx = mn_x;
-  g.PH = (th - 1) * p.isy + (mx_y - mn_y) + 1;
-  g.PW = 31 * p.isx + (mx_x - mn_x) + 1;
-  if (gout) *gout = g;
+// LDS bytes of the tile kernel for this launch at tile height th (0: not eligible); the maximum over the parity classes
+size_t conv_tile_lds_bytes(const ConvParams& p, int th, TileGeoms* gout) {
+  if (p.ntaps < 1 || p.xa != nullptr || p.Kc % 4 != 0 || p.isy != p.isx || p.isy < 1 || p.isy > 2) return 0;
+  const int ncls = p.ncls > 1 ? p.ncls : 1;
+  if (ncls > 4) return 0;
   const size_t cb = p.Kc < 32 ? p.Kc : 32;  // channels resident per pass
-  if (p.Cout <= 16) {  // 16-wide variant
-    const size_t pixp = (size_t)(((g.PH * g.PW + 15) & ~31) + 16);
-    return (cb * pixp + (size_t)p.ntaps * cb * 16 + p.ntaps + (size_t)g.PH * g.PW + 8) * sizeof(float);
+  size_t worst = 0;
+  for (int c = 0; c < ncls; ++c) {
+    const int t0 = ncls > 1 ? p.cls_tap[c] : 0, t1 = ncls > 1 ? p.cls_tap[c + 1] : p.ntaps;
+    int mn_y = 0, mx_y = 0, mn_x = 0, mx_x = 0;
+    for (int t = t0; t < t1; ++t) {
+      if (t == t0 || p.taps[t].dy < mn_y) mn_y = p.taps[t].dy;
+      if (t == t0 || p.taps[t].dy > mx_y) mx_y = p.taps[t].dy;
+      if (t == t0 || p.taps[t].dx < mn_x) mn_x = p.taps[t].dx;
+      if (t == t0 || p.taps[t].dx > mx_x) mx_x = p.taps[t].dx;
+    }
+    TileGeom g;
+    g.min_dy = mn_y; g.min_dx = mn_x;
+    g.PH = (th - 1) * p.isy + (mx_y - mn_y) + 1;
+    g.PW = 31 * p.isx + (mx_x - mn_x) + 1;
+    if (gout) gout->g[c] = g;
+    const size_t pix = (size_t)g.PH * g.PW, ntc = (size_t)(t1 - t0);
+    const size_t pixp = p.Cout <= 16 ? (size_t)(((pix + 15) & ~(size_t)31) + 16) : (pix | 1);
+    const size_t bytes = (cb * pixp + ntc * cb * (p.Cout <= 16 ? 16 : 32) + ntc + pix + 8) * sizeof(float);
+    worst = bytes > worst ? bytes : worst;
   }
-  const size_t pixp = (size_t)(g.PH * g.PW) | 1;
-  return (cb * pixp + (size_t)p.ntaps * cb * 32 + p.ntaps + (size_t)g.PH * g.PW + 8) * sizeof(float);
+  return worst;
 }
 
 int launch_conv_tile(const ConvParams& p, int th, hipStream_t stream) {
-  TileGeom g;
+  TileGeoms g;
   const size_t lds = conv_tile_lds_bytes(p, th, &g);
   if (lds == 0 || lds > 96 * 1024 || (th != 8 && th != 4)) {
     set_error("conv_tile: launch not eligible");
@@ -276,14 +295,15 @@ int launch_conv_tile(const ConvParams& p, int th, hipStream_t stream) {
     attr_set = true;
   }
   const int tiles = ((p.OWq + 31) / 32) * ((p.OHq + th - 1) / th) * p.N;
+  const int ncls = p.ncls > 1 ? p.ncls : 1;
   if (p.Cout <= 16) {
-    dim3 grid16(tiles, 1);
+    dim3 grid16(tiles, 1, ncls);
     if (th == 8) hipLaunchKernelGGL(conv_tile16_kernel<8>, grid16, dim3(256), lds, stream, p, g);
     else hipLaunchKernelGGL(conv_tile16_kernel<4>, grid16, dim3(256), lds, stream, p, g);
     UDET_HIP(hipGetLastError());
     return UDET_OK;
   }
-  dim3 grid(tiles, (p.Cout + 31) / 32);
+  dim3 grid(tiles, (p.Cout + 31) / 32, ncls);
   if (th == 8) hipLaunchKernelGGL(conv_tile_kernel<8>, grid, dim3(256), lds, stream, p, g);
   else hipLaunchKernelGGL(conv_tile_kernel<4>, grid, dim3(256), lds, stream, p, g);
   UDET_HIP(hipGetLastError());
