@@ -661,10 +661,10 @@ static int max_ksplit(const ConvParams& p) {  // capacity / minimum-work bound o
   return ks < 1 ? 1 : ks;
 }
 struct TileGeoms;
-size_t conv_tile_lds_bytes(const ConvParams& p, int th, TileGeoms* gout);
+size_t conv_tile_lds_bytes(const ConvParams& p, int th, TileGeoms* gout, bool* big);
 int launch_conv_tile(const ConvParams& p, int th, hipStream_t stream);
 static bool tile_ok(const ConvParams& p, int th) {
-  const size_t b = conv_tile_lds_bytes(p, th, nullptr);
+  const size_t b = conv_tile_lds_bytes(p, th, nullptr, nullptr);
   return b > 0 && b <= 96 * 1024 && p.Kc <= 256 && p.Cout <= 64;
 }
 static bool dma_ok(const ConvParams& p) { return p.xa == nullptr && p.zero16 != nullptr && !(reinterpret_cast<uintptr_t>(p.zero16) & 15); }

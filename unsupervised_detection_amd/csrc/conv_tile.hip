@@ -2,11 +2,11 @@
 // generator conv1/16/17, the 7x7 / 5x5 stride-2 first layers of the recover encoders).  These launches are HBM/latency-bound
 // in the implicit-GEMM kernel: their K axis is 4..9 LDS stages long, so every workgroup pays one global->LDS round trip
 // per stage for a handful of MFMAs.  Here a workgroup
-//   1. loads the input halo tile of its TH x 32 output pixels ONCE (every input byte read 1.1-1.3x instead of once per tap),
-//      channel-major into LDS ([c][tile pixel]: the K-major image the MFMA A fragment wants, conflict-free for stride 1),
-//   2. loads the launch's packed weights for its 32 output channels ([tap][c][32]) into LDS,
-//   3. walks taps x channels with v_mfma_f32_32x32x2_f32 reading the A fragment at tap-shifted tile addresses
-//      (im2col never materialised), 4 waves x (TH/4) tile rows each,
+//   1. loads the input halo tile of its TH x 32 output pixels ONCE (every input byte read 1.1-1.3x instead of once per tap)
+//      into LDS as [channel quad][tile pixel] float4s,
+//   2. loads the launch's packed weights for its 32 (16) output channels into LDS as [(tap, channel quad)][column] float4s,
+//   3. walks (tap, channel quad) with MFMAs whose A fragment is read at tap-shifted tile addresses (im2col never
+//      materialised): one ds_read_b128 per operand feeds four MFMAs; 4 waves x (TH/4) tile rows each,
 //      (layers deeper than 32 channels repeat 1-3 per block of 32 channels, accumulating in registers),
 //   4. runs the common epilogue (bias / activation / residual / second output / dU emission).
 // Same ConvParams contract as conv_igemm (tap list, NN x2 read, TF SAME padding through the tap offsets).  The four
@@ -37,29 +37,53 @@ struct TileGeoms {
   TileGeom g[4];  // per output-parity class
 };
 
-template <int TH>
+// NW = 32: v_mfma_f32_32x32x2_f32 (two lane halves share a K step); NW = 16: v_mfma_f32_16x16x4_f32 for <= 16 output channels
+// (four lane groups share a K step, no padded MFMA columns; same FLOP rate).
+//
+// LDS layout: the K axis of one channel pass is cut into QUADS of 4 consecutive channels of one tap,
+//   T4[c4][tile pixel]  (float4: channels 4*c4 .. 4*c4+3 of that pixel; odd row stride PIXP)
+//   W4[quad][column]    (float4: the quad's 4 weights of that output channel)     quad = tap * (cw/4) + c4
+// so a global float4 (4 channels of a pixel) is ONE ds_write_b128, and a lane fetches the A (and B) operands of FOUR MFMAs with
+// one ds_read_b128.  Lane group `grp` of a wave walks quads grp, grp+NG, ...; any assignment of K indices to (MFMA, lane group)
+// is valid as long as A and B agree, and a group that runs past the last quad multiplies by a zero quad.
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+// register staging capacity per thread and channel pass: TILE_MT float4 halo loads, TILE_MW weight items (4 float4 each).
+// The small variant keeps the VGPR count low enough for 3-4 workgroups per CU on the single-pass thin layers.
+#define TILE_MT_BIG 16
+#define TILE_MW_BIG 3
+#define TILE_MT_SMALL 8
+#define TILE_MW_SMALL 2
+template <int NW> struct TileAcc;
+template <> struct TileAcc<32> { floatx16 v; };
+template <> struct TileAcc<16> { floatx4 v[2]; };
+
+template <int TH, int NW, int TILE_MT, int TILE_MW>
 __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams p, const TileGeoms gs) {
   constexpr int TW = 32;
-  constexpr int TM = TH / 4;  // tile rows (MFMA M blocks) per wave
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int TM = TH / 4;     // tile rows per wave
+  constexpr int NG = 64 / NW;    // lane groups sharing one MFMA K step
+  constexpr int NQ4 = NW / 4;    // float4s per weight row
+  extern __shared__ __attribute__((aligned(16))) float4 smem4[];
   const int cls = blockIdx.z;
   const TileGeom g = gs.g[cls];
   const int tap0 = p.cls_tap[cls], ntc = p.cls_tap[cls + 1] - tap0;
   const int ooy = p.ncls > 1 ? (cls >> 1) : p.ooy, oox = p.ncls > 1 ? (cls & 1) : p.oox;
   const int PIX = g.PH * g.PW;
-  const int PIXP = PIX | 1;                       // odd row stride: the 4 transposing stores of a float4 spread over banks
+  const int PIXP = PIX | 1;                       // odd: the b128 stores of one pixel's channel quads spread over all banks
   const int CB = p.Kc < 32 ? p.Kc : 32;           // channels resident per pass (deep layers walk Kc in blocks of 32)
-  float* T = smem;                                // [CB][PIXP]
-  float* Wl = smem + (size_t)CB * PIXP;           // [ntaps*CB][32]
-  int* tapoff = reinterpret_cast<int*>(Wl + (size_t)ntc * CB * 32);  // [ntc]
-  int* pixoff = tapoff + ntc;                 // [PIX]
+  const int CQB = CB >> 2;
+  float4* T4 = smem4;                             // [CQB][PIXP]
+  float4* W4 = smem4 + (size_t)CQB * PIXP;        // [ntc*CQB + 1][NW]   (last used row: the zero quad)
+  int* tapoff = reinterpret_cast<int*>(W4 + ((size_t)ntc * CQB + 1) * NW);  // [ntc]
+  int* pixoff = tapoff + ntc;                     // [PIX]
 
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, lh = lane >> 5;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int col = lane & (NW - 1), grp = lane / NW;
   const int tiles_x = (p.OWq + TW - 1) / TW, tiles_y = (p.OHq + TH - 1) / TH;
-  int bid = blockIdx.x;
+  const int bid = blockIdx.x;
   const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y, n = bid / (tiles_x * tiles_y);
   const int oy0 = ty * TH, ox0 = tx * TW;
-  const int n0 = blockIdx.y * 32;
+  const int n0 = blockIdx.y * NW;
   const int iy0 = oy0 * p.isy + g.min_dy, ix0 = ox0 * p.isx + g.min_dx;  // logical input coords of tile pixel (0,0)
   const int Hs = p.H >> p.up_shift, Ws = p.W >> p.up_shift;
   const float* xb = p.x + (size_t)n * Hs * Ws * p.ldx + p.x_coff;
@@ -74,184 +98,173 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams p, cons
     pixoff[pix] = o;
   }
 
-  floatx16 acc[TM];
+  TileAcc<NW> acc[TM];
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int i = 0; i < TM; ++i) {
+    if constexpr (NW == 32) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[i].v[r] = 0.f;
+    } else {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i].v[h][r] = 0.f;
+    }
+  }
+  // tile pixel (in float4 units) of this lane's A rows: 32-wide: pixel `col` of tile row i; 16-wide: pixels col, 16+col
   int abase[TM];
 #pragma unroll
-  for (int i = 0; i < TM; ++i) abase[i] = ((wave * TM + i) * p.isy) * g.PW + li * p.isx + lh * PIXP;  // + lh: channel 2kk+lh
+  for (int i = 0; i < TM; ++i) abase[i] = ((wave * TM + i) * p.isy) * g.PW + col * p.isx;
+  const int ahalf = 16 * p.isx;
 
+  // Global -> registers -> LDS in two steps: `fetch` issues every load of a channel pass back to back (one memory latency per
+  // pass instead of one per loop trip) and `commit` writes them to LDS.  The next pass is fetched right before this pass's
+  // MFMA loop, so its latency hides behind the arithmetic.
+  float4 tv[TILE_MT];
+  float4 wv[TILE_MW][4];
+  auto fetch = [&](int c0, int cw) {
+    const int cq = cw >> 2, NQ = ntc * cq;
+    const int cq_shift = (cq & (cq - 1)) == 0 ? __builtin_ctz(cq) : -1;
+#pragma unroll
+    for (int u = 0; u < TILE_MT; ++u) {
+      const int e = t + u * 256;
+      tv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < PIX * cq) {
+        const int pix = cq_shift >= 0 ? e >> cq_shift : e / cq, c4 = e - pix * cq;
+        const int o = pixoff[pix];
+        if (o >= 0) tv[u] = *reinterpret_cast<const float4*>(xb + (size_t)o + c0 + c4 * 4);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < TILE_MW; ++u) {
+      const int e = t + u * 256;
+      wv[u][0] = wv[u][1] = wv[u][2] = wv[u][3] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < NQ * NQ4) {
+        const int n4 = e % NQ4, q = e / NQ4;
+        const int tap = cq_shift >= 0 ? q >> cq_shift : q / cq, c4 = q - tap * cq;
+        const int nn = n0 + n4 * 4;
+        if (nn < p.ldw) {
+          const float* src = p.wp + ((size_t)p.taps[tap0 + tap].widx * p.Kc + c0 + c4 * 4) * p.ldw + nn;
+          wv[u][0] = *reinterpret_cast<const float4*>(src);
+          wv[u][1] = *reinterpret_cast<const float4*>(src + p.ldw);
+          wv[u][2] = *reinterpret_cast<const float4*>(src + 2 * (size_t)p.ldw);
+          wv[u][3] = *reinterpret_cast<const float4*>(src + 3 * (size_t)p.ldw);
+        }
+      }
+    }
+  };
+  auto commit = [&](int cw) {
+    const int cq = cw >> 2, NQ = ntc * cq;
+    const int cq_shift = (cq & (cq - 1)) == 0 ? __builtin_ctz(cq) : -1;
+    // input halo tile: one b128 store per global float4
+#pragma unroll
+    for (int u = 0; u < TILE_MT; ++u) {
+      const int e = t + u * 256;
+      if (e < PIX * cq) {
+        const int pix = cq_shift >= 0 ? e >> cq_shift : e / cq, c4 = e - pix * cq;
+        T4[(size_t)c4 * PIXP + pix] = tv[u];
+      }
+    }
+    // weights: rows 4*c4 .. 4*c4+3 of a tap, 4 columns each, transposed to [quad][column][4 channels]
+#pragma unroll
+    for (int u = 0; u < TILE_MW; ++u) {
+      const int e = t + u * 256;
+      if (e < NQ * NQ4) {
+        const int n4 = e % NQ4, q = e / NQ4;
+        float4* d = W4 + (size_t)q * NW + n4 * 4;
+        d[0] = make_float4(wv[u][0].x, wv[u][1].x, wv[u][2].x, wv[u][3].x);
+        d[1] = make_float4(wv[u][0].y, wv[u][1].y, wv[u][2].y, wv[u][3].y);
+        d[2] = make_float4(wv[u][0].z, wv[u][1].z, wv[u][2].z, wv[u][3].z);
+        d[3] = make_float4(wv[u][0].w, wv[u][1].w, wv[u][2].w, wv[u][3].w);
+      }
+    }
+    for (int e = t; e < NW; e += 256) W4[(size_t)NQ * NW + e] = make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+
+  __syncthreads();  // offset tables written
+  fetch(0, p.Kc < CB ? p.Kc : CB);
   for (int c0 = 0; c0 < p.Kc; c0 += CB) {
     const int cw = p.Kc - c0 < CB ? p.Kc - c0 : CB;
-    __syncthreads();  // offset tables written / previous pass's fragments read
-    // ---- 1. input halo tile of channels [c0, c0+cw), transposed to channel-major ---------------------------------
-    const int KQ = cw >> 2;
-    const int kq_shift = (KQ & (KQ - 1)) == 0 ? __builtin_ctz(KQ) : -1;
-    for (int e = t; e < PIX * KQ; e += 256) {
-      const int pix = kq_shift >= 0 ? e >> kq_shift : e / KQ, c4 = e - pix * KQ;
-      const int o = pixoff[pix];
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (o >= 0) v = *reinterpret_cast<const float4*>(xb + (size_t)o + c0 + c4 * 4);
-      float* d = T + (size_t)(c4 * 4) * PIXP + pix;
-      d[0] = v.x; d[PIXP] = v.y; d[2 * PIXP] = v.z; d[3 * PIXP] = v.w;
-    }
-    // ---- 2. weights [tap][c][32 columns of this N tile] ---------------------------------------------------------
-    const int cw_shift = (cw & (cw - 1)) == 0 ? __builtin_ctz(cw) : -1;
-    for (int e = t; e < ntc * cw * 8; e += 256) {
-      const int c4 = e & 7, row = e >> 3;                 // row = tap*cw + c
-      const int tap = cw_shift >= 0 ? row >> cw_shift : row / cw, c = row - tap * cw;
-      const int nn = n0 + c4 * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (nn < p.ldw) v = *reinterpret_cast<const float4*>(p.wp + ((size_t)p.taps[tap0 + tap].widx * p.Kc + c0 + c) * p.ldw + nn);
-      *reinterpret_cast<float4*>(Wl + (size_t)row * 32 + c4 * 4) = v;
-    }
+    const int cq = cw >> 2, NQ = ntc * cq;
+    if (c0) __syncthreads();  // previous pass's fragments read
+    commit(cw);
     __syncthreads();
+    if (c0 + CB < p.Kc) fetch(c0 + CB, p.Kc - (c0 + CB) < CB ? p.Kc - (c0 + CB) : CB);  // in flight during the MFMA loop
 
-    // ---- 3. taps x channels -------------------------------------------------------------------------------------
-    const int kpairs = cw >> 1;
-    for (int tap = 0; tap < ntc; ++tap) {
-      const int off = tapoff[tap];
-      const float* wrow = Wl + (size_t)(tap * cw + lh) * 32 + li;
-      for (int kk = 0; kk < kpairs; ++kk) {
-        const float b = wrow[(size_t)kk * 64];
-        const float* ta = T + (size_t)kk * 2 * PIXP + off;
+    // ---- 3. quads: one b128 per operand feeds four MFMAs ---------------------------------------------------------
+    int q = grp, tap = 0, c4 = grp;
+    while (c4 >= cq) { c4 -= cq; ++tap; }
+    const int steps = (NQ + NG - 1) / NG;
+    for (int j = 0; j < steps; ++j) {
+      const bool ok = q < NQ;
+      const float4 b = W4[(size_t)(ok ? q : NQ) * NW + col];
+      const float4* ta = T4 + (ok ? (size_t)c4 * PIXP + tapoff[tap] : 0);
+      if constexpr (NW == 32) {
+        float4 a[TM];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[abase[i]], b, acc[i], 0, 0, 0);
+        for (int i = 0; i < TM; ++i) a[i] = ta[abase[i]];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          acc[i].v = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b.x, acc[i].v, 0, 0, 0);
+          acc[i].v = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b.y, acc[i].v, 0, 0, 0);
+          acc[i].v = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b.z, acc[i].v, 0, 0, 0);
+          acc[i].v = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b.w, acc[i].v, 0, 0, 0);
+        }
+      } else {
+        float4 a[TM][2];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          a[i][0] = ta[abase[i]];
+          a[i][1] = ta[abase[i] + ahalf];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            acc[i].v[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][h].x, b.x, acc[i].v[h], 0, 0, 0);
+            acc[i].v[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][h].y, b.y, acc[i].v[h], 0, 0, 0);
+            acc[i].v[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][h].z, b.z, acc[i].v[h], 0, 0, 0);
+            acc[i].v[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][h].w, b.w, acc[i].v[h], 0, 0, 0);
+          }
       }
+      q += NG;
+      c4 += NG;
+      while (c4 >= cq) { c4 -= cq; ++tap; }
     }
   }
 
   // ---- 4. epilogue --------------------------------------------------------------------------------------------------
-  const int nn = n0 + li;
+  const int nn = n0 + col;
   if (nn >= p.Cout) return;
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int oy = oy0 + wave * TM + i;
     if (oy >= p.OHq) continue;
+    if constexpr (NW == 32) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      if (ox >= p.OWq) continue;
-      const int off = (n * p.OH + oy * p.osy + ooy) * p.OW + ox * p.osx + oox;
-      tile_epilogue(p, off, nn, acc[i][r]);
-    }
-  }
-}
-
-// <= 16 output channels: the same kernel on v_mfma_f32_16x16x4_f32 (16-wide N: no padded MFMA columns; same FLOP rate).
-// A fragment: lane -> pixel (l&15) of a 16-pixel half row, channel 4*kk + (l>>4); B: column l&15, same channel.
-// The tile's channel stride is == 16 (mod 32) so the four channel groups of a wave read disjoint banks.
-typedef float floatx4 __attribute__((ext_vector_type(4)));
-template <int TH>
-__global__ __launch_bounds__(256) void conv_tile16_kernel(const ConvParams p, const TileGeoms gs) {
-  constexpr int TW = 32;
-  constexpr int TM = TH / 4;
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int cls = blockIdx.z;
-  const TileGeom g = gs.g[cls];
-  const int tap0 = p.cls_tap[cls], ntc = p.cls_tap[cls + 1] - tap0;
-  const int ooy = p.ncls > 1 ? (cls >> 1) : p.ooy, oox = p.ncls > 1 ? (cls & 1) : p.oox;
-  const int PIX = g.PH * g.PW;
-  const int PIXP = ((PIX + 15) & ~31) + 16;       // >= PIX, == 16 (mod 32)
-  const int CB = p.Kc < 32 ? p.Kc : 32;
-  float* T = smem;                                // [CB][PIXP]
-  float* Wl = smem + (size_t)CB * PIXP;           // [ntaps*CB][16]
-  int* tapoff = reinterpret_cast<int*>(Wl + (size_t)ntc * CB * 16);
-  int* pixoff = tapoff + ntc;
-
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, lp = lane & 15, lg = lane >> 4;
-  const int tiles_x = (p.OWq + TW - 1) / TW, tiles_y = (p.OHq + TH - 1) / TH;
-  const int bid = blockIdx.x;
-  const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y, n = bid / (tiles_x * tiles_y);
-  const int oy0 = ty * TH, ox0 = tx * TW;
-  const int n0 = blockIdx.y * 16;
-  const int iy0 = oy0 * p.isy + g.min_dy, ix0 = ox0 * p.isx + g.min_dx;
-  const int Hs = p.H >> p.up_shift, Ws = p.W >> p.up_shift;
-  const float* xb = p.x + (size_t)n * Hs * Ws * p.ldx + p.x_coff;
-
-  for (int i = t; i < ntc; i += 256) tapoff[i] = (p.taps[tap0 + i].dy - g.min_dy) * g.PW + (p.taps[tap0 + i].dx - g.min_dx);
-  for (int pix = t; pix < PIX; pix += 256) {
-    const int py = pix / g.PW, px = pix - py * g.PW;
-    const int iy = iy0 + py, ix = ix0 + px;
-    int o = -1;
-    if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) o = ((iy >> p.up_shift) * Ws + (ix >> p.up_shift)) * p.ldx;
-    pixoff[pix] = o;
-  }
-
-  floatx4 acc[TM][2];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[i][h][r] = 0.f;
-  int abase[TM][2];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int h = 0; h < 2; ++h) abase[i][h] = ((wave * TM + i) * p.isy) * g.PW + (h * 16 + lp) * p.isx + lg * PIXP;
-
-  for (int c0 = 0; c0 < p.Kc; c0 += CB) {
-    const int cw = p.Kc - c0 < CB ? p.Kc - c0 : CB;
-    __syncthreads();
-    const int KQ = cw >> 2;
-    const int kq_shift = (KQ & (KQ - 1)) == 0 ? __builtin_ctz(KQ) : -1;
-    for (int e = t; e < PIX * KQ; e += 256) {
-      const int pix = kq_shift >= 0 ? e >> kq_shift : e / KQ, c4 = e - pix * KQ;
-      const int o = pixoff[pix];
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (o >= 0) v = *reinterpret_cast<const float4*>(xb + (size_t)o + c0 + c4 * 4);
-      float* d = T + (size_t)(c4 * 4) * PIXP + pix;
-      d[0] = v.x; d[PIXP] = v.y; d[2 * PIXP] = v.z; d[3 * PIXP] = v.w;
-    }
-    const int cw_shift = (cw & (cw - 1)) == 0 ? __builtin_ctz(cw) : -1;
-    for (int e = t; e < ntc * cw * 4; e += 256) {
-      const int c4 = e & 3, row = e >> 2;
-      const int tap = cw_shift >= 0 ? row >> cw_shift : row / cw, c = row - tap * cw;
-      const int nn = n0 + c4 * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (nn < p.ldw) v = *reinterpret_cast<const float4*>(p.wp + ((size_t)p.taps[tap0 + tap].widx * p.Kc + c0 + c) * p.ldw + nn);
-      *reinterpret_cast<float4*>(Wl + (size_t)row * 16 + c4 * 4) = v;
-    }
-    __syncthreads();
-
-    const int kquads = cw >> 2;
-    for (int tap = 0; tap < ntc; ++tap) {
-      const int off = tapoff[tap];
-      const float* wrow = Wl + (size_t)(tap * cw + lg) * 16 + lp;
-      for (int kk = 0; kk < kquads; ++kk) {
-        const float b = wrow[(size_t)kk * 64];
-        const float* ta = T + (size_t)kk * 4 * PIXP + off;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int h = 0; h < 2; ++h) acc[i][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(ta[abase[i][h]], b, acc[i][h], 0, 0, 0);
-      }
-    }
-  }
-
-  const int nn = n0 + lp;
-  if (nn >= p.Cout) return;
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int oy = oy0 + wave * TM + i;
-    if (oy >= p.OHq) continue;
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ox = ox0 + h * 16 + lg * 4 + r;
+      for (int r = 0; r < 16; ++r) {
+        const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * grp;
         if (ox >= p.OWq) continue;
         const int off = (n * p.OH + oy * p.osy + ooy) * p.OW + ox * p.osx + oox;
-        tile_epilogue(p, off, nn, acc[i][h][r]);
+        tile_epilogue(p, off, nn, acc[i].v[r]);
       }
+    } else {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int ox = ox0 + h * 16 + grp * 4 + r;
+          if (ox >= p.OWq) continue;
+          const int off = (n * p.OH + oy * p.osy + ooy) * p.OW + ox * p.osx + oox;
+          tile_epilogue(p, off, nn, acc[i].v[h][r]);
+        }
+    }
   }
 }
 
 // LDS bytes of the tile kernel for this launch at tile height th (0: not eligible); the maximum over the parity classes
-size_t conv_tile_lds_bytes(const ConvParams& p, int th, TileGeoms* gout) {
+size_t conv_tile_lds_bytes(const ConvParams& p, int th, TileGeoms* gout, bool* big) {
+  if (big) *big = false;
   if (p.ntaps < 1 || p.xa != nullptr || p.Kc % 4 != 0 || p.isy != p.isx || p.isy < 1 || p.isy > 2) return 0;
   const int ncls = p.ncls > 1 ? p.ncls : 1;
   if (ncls > 4) return 0;
@@ -271,9 +284,10 @@ size_t conv_tile_lds_bytes(const ConvParams& p, int th, TileGeoms* gout) {
     g.PH = (th - 1) * p.isy + (mx_y - mn_y) + 1;
     g.PW = 31 * p.isx + (mx_x - mn_x) + 1;
     if (gout) gout->g[c] = g;
-    const size_t pix = (size_t)g.PH * g.PW, ntc = (size_t)(t1 - t0);
-    const size_t pixp = p.Cout <= 16 ? (size_t)(((pix + 15) & ~(size_t)31) + 16) : (pix | 1);
-    const size_t bytes = (cb * pixp + ntc * cb * (p.Cout <= 16 ? 16 : 32) + ntc + pix + 8) * sizeof(float);
+    const size_t pix = (size_t)g.PH * g.PW, ntc = (size_t)(t1 - t0), cqb = cb / 4, nw = p.Cout <= 16 ? 16 : 32;
+    const size_t bytes = (cqb * (pix | 1) + (ntc * cqb + 1) * nw) * 16 + (ntc + pix + 8) * sizeof(float);
+    if (pix * cqb > 256 * TILE_MT_BIG || ntc * cqb * (nw / 4) > 256 * TILE_MW_BIG) return 0;  // per-thread register staging capacity
+    if (big && (pix * cqb > 256 * TILE_MT_SMALL || ntc * cqb * (nw / 4) > 256 * TILE_MW_SMALL)) *big = true;
     worst = bytes > worst ? bytes : worst;
   }
   return worst;
@@ -281,31 +295,31 @@ size_t conv_tile_lds_bytes(const ConvParams& p, int th, TileGeoms* gout) {
 
 int launch_conv_tile(const ConvParams& p, int th, hipStream_t stream) {
   TileGeoms g;
-  const size_t lds = conv_tile_lds_bytes(p, th, &g);
+  bool big = false;
+  const size_t lds = conv_tile_lds_bytes(p, th, &g, &big);
   if (lds == 0 || lds > 96 * 1024 || (th != 8 && th != 4)) {
     set_error("conv_tile: launch not eligible");
     return UDET_ERR_UNSUPPORTED;
   }
+  typedef void (*Kern)(const ConvParams, const TileGeoms);
+  static const Kern K[2][2][2] = {  // [th == 4][16-wide][big staging]
+      {{conv_tile_kernel<8, 32, TILE_MT_SMALL, TILE_MW_SMALL>, conv_tile_kernel<8, 32, TILE_MT_BIG, TILE_MW_BIG>},
+       {conv_tile_kernel<8, 16, TILE_MT_SMALL, TILE_MW_SMALL>, conv_tile_kernel<8, 16, TILE_MT_BIG, TILE_MW_BIG>}},
+      {{conv_tile_kernel<4, 32, TILE_MT_SMALL, TILE_MW_SMALL>, conv_tile_kernel<4, 32, TILE_MT_BIG, TILE_MW_BIG>},
+       {conv_tile_kernel<4, 16, TILE_MT_SMALL, TILE_MW_SMALL>, conv_tile_kernel<4, 16, TILE_MT_BIG, TILE_MW_BIG>}}};
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tile_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tile_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tile16_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tile16_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    for (int a = 0; a < 2; ++a)
+      for (int b = 0; b < 2; ++b)
+        for (int c = 0; c < 2; ++c)
+          (void)hipFuncSetAttribute(reinterpret_cast<const void*>(K[a][b][c]), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     attr_set = true;
   }
   const int tiles = ((p.OWq + 31) / 32) * ((p.OHq + th - 1) / th) * p.N;
   const int ncls = p.ncls > 1 ? p.ncls : 1;
-  if (p.Cout <= 16) {
-    dim3 grid16(tiles, 1, ncls);
-    if (th == 8) hipLaunchKernelGGL(conv_tile16_kernel<8>, grid16, dim3(256), lds, stream, p, g);
-    else hipLaunchKernelGGL(conv_tile16_kernel<4>, grid16, dim3(256), lds, stream, p, g);
-    UDET_HIP(hipGetLastError());
-    return UDET_OK;
-  }
-  dim3 grid(tiles, (p.Cout + 31) / 32, ncls);
-  if (th == 8) hipLaunchKernelGGL(conv_tile_kernel<8>, grid, dim3(256), lds, stream, p, g);
-  else hipLaunchKernelGGL(conv_tile_kernel<4>, grid, dim3(256), lds, stream, p, g);
+  const bool n16 = p.Cout <= 16;
+  dim3 grid(tiles, n16 ? 1 : (p.Cout + 31) / 32, ncls);
+  hipLaunchKernelGGL(K[th == 4][n16][big], grid, dim3(256), lds, stream, p, g);
   UDET_HIP(hipGetLastError());
   return UDET_OK;
 }
