@@ -72,6 +72,9 @@ CONV_CASES = [
     (4, 6, 10, 529, 128, 3, 1, 1, "leaky", 0.1, False),      # tiny level-6 grid -> split-K
     (1, 48, 96, 50, 2, 5, 1, 1, "none", 0.0, False),         # recover flow1 5x5
     (4, 6, 10, 196, 196, 3, 1, 1, "leaky", 0.1, False),      # Cout=196 (two N tiles)
+    (1, 24, 48, 104, 16, 4, 1, 1, "none", 0.0, False),       # recover deconv1: operand-swapped filter gradient (16 channels)
+    (1, 24, 48, 32, 16, 3, 1, 1, "none", 0.0, False),        # generator conv16 shape, swapped view
+    (1, 24, 48, 64, 8, 3, 1, 1, "none", 0.0, False),         # 8 output channels
 ]
 
 

@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, in
       }
     }
     if (p.swapped) {  // bias = column sums of the centre tap's rows of the (gathered) A stage
-      if (co0 == 0 && t < 4 && p.bias_m >= m0 && p.bias_m < m0 + BM) {
+      if (co0 == 0 && t < p.Cin4 && p.bias_m >= m0 && p.bias_m < m0 + BM) {
 #pragma unroll
         for (int k = 0; k < BKP; ++k) bsum += As[buf][k][p.bias_m - m0 + t];
       }
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, in
       for (int j = 0; j < TN; ++j) dst[(size_t)m * ldn + co0 + wn * WTN + j * 32 + li] = acc[i][j][r];
     }
   if (p.swapped) {
-    if (co0 == 0 && t < 4 && p.bias_m >= m0 && p.bias_m < m0 + BM) p.pbias[(size_t)blockIdx.y * ldn + t] = bsum;
+    if (co0 == 0 && t < p.Cin4 && p.bias_m >= m0 && p.bias_m < m0 + BM) p.pbias[(size_t)blockIdx.y * ldn + t] = bsum;
   } else if (mt == 0 && t < BN) {
     p.pbias[(size_t)blockIdx.y * ldn + co0 + t] = bsum;
   }
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(512, 4) void conv_wgrad_dma_kernel(const WgradParam
       }
     }
     if (p.swapped) {  // bias = column sums of the centre tap's rows of the (gathered) A stage
-      if (co0 == 0 && t < 4 && p.bias_m >= m0 && p.bias_m < m0 + BM) {
+      if (co0 == 0 && t < p.Cin4 && p.bias_m >= m0 && p.bias_m < m0 + BM) {
 #pragma unroll
         for (int k = 0; k < BKP; ++k) bsum += As[buf][k][p.bias_m - m0 + t];
       }
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(512, 4) void conv_wgrad_dma_kernel(const WgradParam
       for (int j = 0; j < TN; ++j) dst[(size_t)m * ldn + co0 + wn * WTN + j * 32 + li] = acc[i][j][r];
     }
   if (p.swapped) {
-    if (co0 == 0 && t < 4 && p.bias_m >= m0 && p.bias_m < m0 + BM) p.pbias[(size_t)blockIdx.y * ldn + t] = bsum;
+    if (co0 == 0 && t < p.Cin4 && p.bias_m >= m0 && p.bias_m < m0 + BM) p.pbias[(size_t)blockIdx.y * ldn + t] = bsum;
   } else if (mt == 0 && t < BN) {
     p.pbias[(size_t)blockIdx.y * ldn + co0 + t] = bsum;
   }
@@ -434,14 +434,24 @@ int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream) {
     int centre = -1;
     for (int t = 0; t < p.ntaps; ++t)
       if (p.taps[t].dy == 0 && p.taps[t].dx == 0) centre = t;
-    const bool swap = p.Cout <= 4 && p.Cin >= 16 && p.isy == 1 && p.isx == 1 && p.up_shift == 0 && p.H == p.OH && p.W == p.OW &&
+    // padded MFMA work of the two views: ceil(rows/128)*128 x the N tile
+    auto tile_cost = [](long rows, int cols) {
+      const int bn_ = cols > 64 ? 128 : (cols > 32 ? 64 : 32);
+      return ((rows + 127) / 128 * 128) * (long)((cols + bn_ - 1) / bn_ * bn_);
+    };
+    const int co4 = (p.Cout + 3) & ~3, ci4 = (p.Cin + 3) & ~3;
+    const bool cheaper = tile_cost((long)p.ntaps * co4, p.Cin) < tile_cost((long)p.ntaps * ci4, p.Cout);
+    // <= 4 channels: always (as before); 5..16 channels (deconv1, conv16): when the swapped view pads less.  The bias rows
+    // (centre tap x output channels) must not straddle an M tile: 128 % co4 == 0.
+    const bool narrow = p.Cout <= 4 ? p.Cin >= 16 : (p.Cout <= 16 && 128 % co4 == 0 && cheaper);
+    const bool swap = narrow && p.isy == 1 && p.isx == 1 && p.up_shift == 0 && p.H == p.OH && p.W == p.OW &&
                       p.ya == nullptr && centre >= 0 && !getenv("UDET_NO_WSWAP");
     if (swap) {
       g.x = p.dy; g.ldx = p.ldy; g.x_coff = p.y_coff; g.Cin = p.Cout;
       g.dy = p.x; g.ldy = p.ldx; g.y_coff = p.x_coff; g.Cout = p.Cin;
       for (int t = 0; t < p.ntaps; ++t) { g.taps[t].dy = -p.taps[t].dy; g.taps[t].dx = -p.taps[t].dx; }
       g.swapped = 1;
-      g.bias_m = centre * 4;
+      g.bias_m = centre * co4;
     }
   }
   const int BM = 128;
