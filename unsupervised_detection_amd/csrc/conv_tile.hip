@@ -73,9 +73,10 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams p, cons
   const int CB = p.Kc < 32 ? p.Kc : 32;           // channels resident per pass (deep layers walk Kc in blocks of 32)
   const int CQB = CB >> 2;
   float4* T4 = smem4;                             // [CQB][PIXP]
-  float4* W4 = smem4 + (size_t)CQB * PIXP;        // [ntc*CQB + 1][NW]   (last used row: the zero quad)
-  int* tapoff = reinterpret_cast<int*>(W4 + ((size_t)ntc * CQB + 1) * NW);  // [ntc]
+  float4* W4 = smem4 + (size_t)CQB * PIXP;        // [ntc*CQB + NG][NW]   (rows past the last quad: zeros)
+  int* tapoff = reinterpret_cast<int*>(W4 + ((size_t)ntc * CQB + NG) * NW);  // [ntc]
   int* pixoff = tapoff + ntc;                     // [PIX]
+  int* qoff = pixoff + PIX;                       // [ntc*CQB + 3*NG]  quad -> float4 offset of its tile row (padding: 0)
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int col = lane & (NW - 1), grp = lane / NW;
@@ -178,7 +179,15 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams p, cons
         d[3] = make_float4(wv[u][0].w, wv[u][1].w, wv[u][2].w, wv[u][3].w);
       }
     }
-    for (int e = t; e < NW; e += 256) W4[(size_t)NQ * NW + e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int e = t; e < NG * NW; e += 256) W4[(size_t)NQ * NW + e] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = t; q < NQ + 3 * NG; q += 256) {
+      int o = 0;
+      if (q < NQ) {
+        const int tap = cq_shift >= 0 ? q >> cq_shift : q / cq, c4 = q - tap * cq;
+        o = c4 * PIXP + tapoff[tap];
+      }
+      qoff[q] = o;
+    }
   };
 
   __syncthreads();  // offset tables written
@@ -192,44 +201,70 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams p, cons
     if (c0 + CB < p.Kc) fetch(c0 + CB, p.Kc - (c0 + CB) < CB ? p.Kc - (c0 + CB) : CB);  // in flight during the MFMA loop
 
     // ---- 3. quads: one b128 per operand feeds four MFMAs ---------------------------------------------------------
-    int q = grp, tap = 0, c4 = grp;
-    while (c4 >= cq) { c4 -= cq; ++tap; }
+    // Branch-free and software-pipelined: quad -> tile offset comes from the qoff table (padding quads point at offset 0 and
+    // multiply by zero weight rows); step j+1's fragments and step j+2's offset are in flight while step j's MFMAs issue.
+    constexpr int NA = NW == 32 ? TM : 2 * TM;  // A fragments (float4) per step
     const int steps = (NQ + NG - 1) / NG;
-    for (int j = 0; j < steps; ++j) {
-      const bool ok = q < NQ;
-      const float4 b = W4[(size_t)(ok ? q : NQ) * NW + col];
-      const float4* ta = T4 + (ok ? (size_t)c4 * PIXP + tapoff[tap] : 0);
-      if constexpr (NW == 32) {
-        float4 a[TM];
+    int q = grp;
+    int off1 = qoff[q + NG];
+    float4 b = W4[(size_t)q * NW + col];
+    float4 a[NA];
+    {
+      const float4* ta = T4 + qoff[q];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = ta[abase[i]];
+      for (int i = 0; i < TM; ++i) {
+        if constexpr (NW == 32) {
+          a[i] = ta[abase[i]];
+        } else {
+          a[2 * i] = ta[abase[i]];
+          a[2 * i + 1] = ta[abase[i] + ahalf];
+        }
+      }
+    }
+    for (int j = 0; j < steps; ++j) {
+      float4 bn = b, an[NA];
+#pragma unroll
+      for (int i = 0; i < NA; ++i) an[i] = a[i];
+      int off2 = 0;
+      if (j + 1 < steps) {  // uniform
+        q += NG;
+        off2 = qoff[q + NG];
+        bn = W4[(size_t)q * NW + col];
+        const float4* ta = T4 + off1;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
+          if constexpr (NW == 32) {
+            an[i] = ta[abase[i]];
+          } else {
+            an[2 * i] = ta[abase[i]];
+            an[2 * i + 1] = ta[abase[i] + ahalf];
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if constexpr (NW == 32) {
           acc[i].v = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b.x, acc[i].v, 0, 0, 0);
           acc[i].v = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b.y, acc[i].v, 0, 0, 0);
           acc[i].v = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b.z, acc[i].v, 0, 0, 0);
           acc[i].v = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b.w, acc[i].v, 0, 0, 0);
-        }
-      } else {
-        float4 a[TM][2];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          a[i][0] = ta[abase[i]];
-          a[i][1] = ta[abase[i] + ahalf];
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
+        } else {
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
-            acc[i].v[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][h].x, b.x, acc[i].v[h], 0, 0, 0);
-            acc[i].v[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][h].y, b.y, acc[i].v[h], 0, 0, 0);
-            acc[i].v[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][h].z, b.z, acc[i].v[h], 0, 0, 0);
-            acc[i].v[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][h].w, b.w, acc[i].v[h], 0, 0, 0);
+            acc[i].v[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2 * i + h].x, b.x, acc[i].v[h], 0, 0, 0);
+            acc[i].v[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2 * i + h].y, b.y, acc[i].v[h], 0, 0, 0);
+            acc[i].v[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2 * i + h].z, b.z, acc[i].v[h], 0, 0, 0);
+            acc[i].v[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2 * i + h].w, b.w, acc[i].v[h], 0, 0, 0);
           }
+        }
       }
-      q += NG;
-      c4 += NG;
-      while (c4 >= cq) { c4 -= cq; ++tap; }
+      // issue order pinned: this step's LDS reads first (they complete under the MFMAs), then the MFMAs
+      __builtin_amdgcn_sched_group_barrier(0x100, NA + 2, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * NA, 0);
+      b = bn;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) a[i] = an[i];
+      off1 = off2;
     }
   }
 
@@ -285,7 +320,8 @@ size_t conv_tile_lds_bytes(const ConvParams& p, int th, TileGeoms* gout, bool* b
     g.PW = 31 * p.isx + (mx_x - mn_x) + 1;
     if (gout) gout->g[c] = g;
     const size_t pix = (size_t)g.PH * g.PW, ntc = (size_t)(t1 - t0), cqb = cb / 4, nw = p.Cout <= 16 ? 16 : 32;
-    const size_t bytes = (cqb * (pix | 1) + (ntc * cqb + 1) * nw) * 16 + (ntc + pix + 8) * sizeof(float);
+    const size_t ng = 64 / nw;
+    const size_t bytes = (cqb * (pix | 1) + (ntc * cqb + ng) * nw) * 16 + (ntc + pix + ntc * cqb + 3 * ng + 8) * sizeof(float);
     if (pix * cqb > 256 * TILE_MT_BIG || ntc * cqb * (nw / 4) > 256 * TILE_MW_BIG) return 0;  // per-thread register staging capacity
     if (big && (pix * cqb > 256 * TILE_MT_SMALL || ntc * cqb * (nw / 4) > 256 * TILE_MW_SMALL)) *big = true;
     worst = bytes > worst ? bytes : worst;
