@@ -190,15 +190,18 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams p, cons
     }
   };
 
-  __syncthreads();  // offset tables written
-  fetch(0, p.Kc < CB ? p.Kc : CB);
-  for (int c0 = 0; c0 < p.Kc; c0 += CB) {
-    const int cw = p.Kc - c0 < CB ? p.Kc - c0 : CB;
+  // One call site each for fetch / commit / the MFMA loop (they are large once unrolled): iteration c0 = -CB only fetches
+  // the first pass; afterwards pass c0 is committed, pass c0 + CB is fetched (in flight during the MFMA loop), pass c0 runs.
+  for (int c0 = -CB; c0 < p.Kc; c0 += CB) {
+    const int cw = c0 < 0 ? CB : (p.Kc - c0 < CB ? p.Kc - c0 : CB);
     const int cq = cw >> 2, NQ = ntc * cq;
-    if (c0) __syncthreads();  // previous pass's fragments read
-    commit(cw);
-    __syncthreads();
-    if (c0 + CB < p.Kc) fetch(c0 + CB, p.Kc - (c0 + CB) < CB ? p.Kc - (c0 + CB) : CB);  // in flight during the MFMA loop
+    __syncthreads();  // offset tables written / previous pass's fragments read
+    if (c0 >= 0) {
+      commit(cw);
+      __syncthreads();
+    }
+    if (c0 + CB < p.Kc) fetch(c0 + CB, p.Kc - (c0 + CB) < CB ? p.Kc - (c0 + CB) : CB);
+    if (c0 < 0) continue;
 
     // ---- 3. quads: one b128 per operand feeds four MFMAs ---------------------------------------------------------
     // Branch-free and software-pipelined: quad -> tile offset comes from the qoff table (padding quads point at offset 0 and
@@ -271,29 +274,39 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams p, cons
   // ---- 4. epilogue --------------------------------------------------------------------------------------------------
   const int nn = n0 + col;
   if (nn >= p.Cout) return;
+  // the common forward case (bias + activation, plain store) takes a short path: the generic epilogue's per-element
+  // branches cost more than the MFMA loop of a thin layer
+  const bool plain = !p.y2 && !p.res && !p.accumulate && !p.uo;
+  const float bias = p.bias ? p.bias[nn] : 0.f;
+  auto rows = [&](auto&& emit) {
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int oy = oy0 + wave * TM + i;
-    if (oy >= p.OHq) continue;
-    if constexpr (NW == 32) {
+    for (int i = 0; i < TM; ++i) {
+      const int oy = oy0 + wave * TM + i;
+      if (oy >= p.OHq) continue;
+      const int row = (n * p.OH + oy * p.osy + ooy) * p.OW + oox;  // output pixel index of ox = 0
+      if constexpr (NW == 32) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * grp;
-        if (ox >= p.OWq) continue;
-        const int off = (n * p.OH + oy * p.osy + ooy) * p.OW + ox * p.osx + oox;
-        tile_epilogue(p, off, nn, acc[i].v[r]);
-      }
-    } else {
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int ox = ox0 + h * 16 + grp * 4 + r;
-          if (ox >= p.OWq) continue;
-          const int off = (n * p.OH + oy * p.osy + ooy) * p.OW + ox * p.osx + oox;
-          tile_epilogue(p, off, nn, acc[i].v[h][r]);
+        for (int r = 0; r < 16; ++r) {
+          const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * grp;
+          if (ox < p.OWq) emit(row, ox, acc[i].v[r]);
         }
+      } else {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int ox = ox0 + h * 16 + grp * 4 + r;
+            if (ox < p.OWq) emit(row, ox, acc[i].v[h][r]);
+          }
+      }
     }
+  };
+  if (plain) {
+    float* ycol = p.y + p.y_coff + nn;
+    const int xstep = p.osx * p.ldy;
+    rows([&](int row, int ox, float v) { ycol[(size_t)row * p.ldy + (size_t)ox * xstep] = act_fwd(v + bias, p.act, p.alpha); });
+  } else {
+    rows([&](int row, int ox, float v) { tile_epilogue(p, row + ox * p.osx, nn, v); });
   }
 }
 
