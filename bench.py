@@ -93,12 +93,20 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 "
                              "--master-port 29500 bench.py --gpus %d ..." % (args.gpus, args.gpus))
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
+    # UDET_BENCH_ONE_GPU=1 (testing aid for a 1-GPU box): every rank uses cuda:0 and the collectives run over gloo, which
+    # exercises the multi-process control flow of this script; the numbers of such a run mean nothing.
+    one_gpu = os.environ.get("UDET_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from unsupervised_detection_amd import data
     from unsupervised_detection_amd.engine import BOTH, Engine, EngineConfig
@@ -121,6 +129,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def stage(msg):  # UDET_BENCH_TRACE=1: progress markers on stderr (debugging a multi-process launch)
+        if os.environ.get("UDET_BENCH_TRACE") == "1":
+            print("[bench rank %d] %s" % (rank, msg), file=sys.stderr, flush=True)
+
     # cross-step pipelining (trainer.train_step): every step enqueues the frozen PWC-Net's flow of the NEXT pair beside
     # its own backward pass.  The pipeline is primed before the timed region (>= 1 warm-up step or an explicit prefetch),
     # so the K timed steps contain exactly K PWC forwards, K generator/recover forwards, K x both backward, K x 2 applies.
@@ -128,9 +140,11 @@ def main():
     if nxt is not None and args.warmup == 0:
         eng.prefetch_flow(img1, img2)
         st._prefetched = (img1, img2)
+    stage("plan built, weights packed, autotuned")
     for _ in range(args.warmup):
         train_step(st, img1, img2, BOTH, next_pair=nxt)
     barrier()
+    stage("warm-up done")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         train_step(st, img1, img2, BOTH, next_pair=nxt)
@@ -143,6 +157,7 @@ def main():
     ms = dt / args.steps * 1e3
     pairs_per_s = args.batch * world * args.steps / dt
     losses = eng.losses()
+    stage("timed region done")
 
     # the reference's own schedule (adversarial_learner.py:383-398 with iter_gen=3 / iter_rec=1): a 4-step cycle
     # = 16 pairs, 4 forwards, 1 recover-loss backward, 3 generator-loss backwards.  Reported beside the headline number.
@@ -174,21 +189,24 @@ def main():
     # per-kernel timing with HIP events on the launch stream: ONE extra, untimed step executed serially (the plan collapses
     # its side streams while profiling, so every launch group's duration is its stand-alone duration)
     prof, layers = None, []
-    if rank == 0:
-        import csv
-        import tempfile
-        keep = os.environ.get("UDET_PROF_DUMP")  # a caller-provided path is kept (per-layer CSV for analysis)
-        dump = keep or os.path.join(tempfile.gettempdir(), "udet_layers_%d.csv" % os.getpid())
-        if os.path.exists(dump):
+    # every rank runs the profiled step (it contains the gradient all-reduces: a rank that skipped it would leave the
+    # others waiting in the collective); only rank 0 keeps the per-layer dump and reports
+    import csv
+    import tempfile
+    keep = os.environ.get("UDET_PROF_DUMP") if rank == 0 else None  # a caller-provided path is kept (per-layer CSV for analysis)
+    dump = keep or os.path.join(tempfile.gettempdir(), "udet_layers_%d.csv" % os.getpid())
+    if os.path.exists(dump):
+        os.remove(dump)
+    os.environ["UDET_PROF_DUMP"] = dump
+    stage("reference schedule done; profiling pass")
+    prof = eng.profile(lambda: train_step(st, img1, img2, BOTH))
+    stage("profiling pass done")
+    os.environ.pop("UDET_PROF_DUMP", None)
+    if os.path.exists(dump):
+        with open(dump) as f:
+            layers = [(int(r[0]), r[1], float(r[2]), float(r[3])) for r in csv.reader(f)]
+        if not keep:
             os.remove(dump)
-        os.environ["UDET_PROF_DUMP"] = dump
-        prof = eng.profile(lambda: train_step(st, img1, img2, BOTH))
-        os.environ.pop("UDET_PROF_DUMP", None)
-        if os.path.exists(dump):
-            with open(dump) as f:
-                layers = [(int(r[0]), r[1], float(r[2]), float(r[3])) for r in csv.reader(f)]
-            if not keep:
-                os.remove(dump)
 
     if rank == 0:
         conv_ms = sum(prof[c]["ms"] for c in ("conv_fwd", "conv_dgrad", "conv_wgrad"))
