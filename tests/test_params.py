@@ -58,3 +58,31 @@ def test_plan_rejects_bad_config_without_gpu():
     gb = _ffi.lib.udet_workspace_bytes(h) / 2 ** 30
     assert 0.5 < gb < 16, gb
     _ffi.lib.udet_plan_destroy(h)
+
+
+def test_tf_checkpoint_names_map_onto_the_parameter_tables():
+    """tests/golden/names.json lists the variables the reference's own code creates (oracle/make_golden.py): every one
+    of them canonicalises to exactly one entry of the library's parameter tables, shapes included."""
+    import json
+    from unsupervised_detection_amd import weights as W
+    with open(os.path.join(ROOT, "tests", "golden", "names.json")) as f:
+        created = json.load(f)["variables_created_by_the_reference"]
+    tables = {}
+    for net in (W.NET_PWC, W.NET_GEN, W.NET_REC):
+        tables.update({n: tuple(s) for n, s, _ in W.param_table(net)})
+    seen = {}
+    for group in created.values():
+        for v in group:
+            c = W.canonical_name(v["tf"] + ":0")
+            if v["tf"].endswith(("moving_mean", "moving_variance")):
+                assert c is None
+                continue
+            assert c == v["canonical"] and tables[c] == tuple(v["shape"]), v
+            seen[c] = True
+    assert set(seen) == set(tables)
+    assert W.canonical_name("MaskNet//conv1/kernel/Adam_1") is None and W.canonical_name("train_op/global_step") is None
+    # a {tf name: array} export loads directly
+    import numpy as np
+    export = {v["tf"]: np.full(v["shape"], 0.5, np.float32) for v in created["generator_net + recover_net"]}
+    flat = W.from_tf_dict(export, W.NET_GEN)
+    assert flat.numel() == W.param_total(W.NET_GEN) and float(flat.min()) == 0.5

@@ -57,14 +57,16 @@ class AdversarialLearner(object):
     def _load_weights(self, config):
         """Checkpoint policy of train() (:339-360): PWC weights are mandatory in the reference; here synthetic
         weights with the reference's initializers stand in when no flat-weight file is given (README.md:59-64
-        checkpoints are external downloads).  Files are torch.save'd dicts {tf_name: tensor}."""
+        checkpoints are external downloads).  Files are {variable name: array} dicts -- torch.save'd, or .npz -- under the
+        TF checkpoint's own names ("MaskNet//conv1/kernel", "MaskNet//batch_normalization_3/gamma", ...; optimizer slots
+        and BN moving statistics are ignored) or the canonical ones of weights.param_table()."""
         import os
         out = {}
         for key, flag, net in (("w_pwc", "flow_ckpt", W.NET_PWC), ("w_rec", "recover_ckpt", W.NET_REC), ("w_gen", "full_model_ckpt", W.NET_GEN)):
             path = getattr(config, flag, "")
             if path and os.path.isfile(path):
-                d = torch.load(path, map_location="cpu")
-                out[key] = W.from_dict(d, net)
+                d = dict(np.load(path)) if path.endswith(".npz") else torch.load(path, map_location="cpu")
+                out[key] = W.from_tf_dict(d, net)
                 print("{} loaded from {}".format(flag, path))
             elif path:
                 raise IOError("Could not find {} file {}. Aborting.".format(flag, path))

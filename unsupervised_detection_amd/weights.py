@@ -104,3 +104,47 @@ def from_dict(d, net: int) -> torch.Tensor:
             raise ValueError(f"{name}: shape {tuple(t.shape)} != {shape}")
         flat[off:off + t.numel()] = t.detach().reshape(-1).to(torch.float32)
     return flat
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# TF variable names.  The reference builds the generator inside `tf.variable_scope("MaskNet/")` (the *name scope* string,
+# adversarial_learner.py:99-105) and the recover net inside "FlownetS/", so checkpoint names carry a double slash
+# ("MaskNet//conv1/kernel", "FlownetS//aconv1/weights"), and tf.layers auto-names the generator's batch-norm layers per
+# enclosing scope ("MaskNet//batch_normalization_3/gamma", "MaskNet//conv13_upsample/batch_normalization/beta").
+# tests/golden/names.json holds the full list as created by the reference's own code.
+# --------------------------------------------------------------------------------------------------------------------
+_GEN_TOP_BN_ORDER = ("conv1", "conv2_downsample", "conv3", "conv4_downsample", "conv5", "conv6", "conv7_atrous", "conv8_atrous",
+                     "conv9_atrous", "conv10_atrous", "conv11", "conv12", "conv14", "conv16", "conv17")
+
+
+def canonical_name(tf_name: str):
+    """TF-1 variable name (optionally with a ':0' suffix) -> the name used by param_table(), or None for variables the
+    path does not read (BN moving statistics -- never updated by the reference, see SURVEY 8c-F --, optimizer slots,
+    global_step)."""
+    n = tf_name.split(":")[0].replace("//", "/")
+    parts = n.split("/")
+    if parts[-1] in ("moving_mean", "moving_variance", "Adam", "Adam_1") or parts[0] not in ("MaskNet", "FlownetS", "pwcnet"):
+        return None
+    if parts[0] == "MaskNet" and len(parts) >= 3 and parts[-2].startswith("batch_normalization"):
+        if len(parts) == 3:  # k-th default-named layer of the top scope = k-th gen_conv outside the upsample scopes
+            suf = parts[1][len("batch_normalization"):]
+            k = int(suf[1:]) if suf else 0
+            if k >= len(_GEN_TOP_BN_ORDER):
+                raise KeyError(tf_name)
+            layer = _GEN_TOP_BN_ORDER[k]
+        else:
+            layer = parts[1]
+        return "MaskNet/%s/bn/%s" % (layer, parts[-1])
+    return n
+
+
+def from_tf_dict(d, net: int) -> torch.Tensor:
+    """Flat buffer from {TF variable name: array} as exported from a reference checkpoint (e.g. with
+    tf.train.load_checkpoint(...).get_tensor on a machine that has TensorFlow); names are canonicalised first.
+    Raises KeyError naming the first variable of `net` that the mapping lacks."""
+    canon = {}
+    for k, v in d.items():
+        c = canonical_name(k)
+        if c is not None:
+            canon[c] = v if isinstance(v, torch.Tensor) else torch.as_tensor(np.asarray(v))
+    return from_dict(canon, net)
