@@ -182,10 +182,11 @@ int udet_autotune(udet_plan* plan, const float* w_gen, const float* w_rec, float
                   void* stream);
 int udet_tuned_shapes(void);
 /* tuning hook used by tools/conv_bench.py and the kernel-family tests: force (bm, bn, split-K) for every convolution launch
- * (bm bit 16: non-specialised kernel, bit 17: LDS-DMA staging, bit 18: tile-resident kernel with bm & 0xffff = tile height);
+ * (bm bit 16: non-specialised kernel, bit 17: LDS-DMA staging, bit 18: tile-resident kernel with bm & 0xffff = tile height,
+ * bit 19: self-staging LDS-DMA kernel);
  * (0,0,-1) restores.  A forced family a launch is not eligible for falls back to the built-in choice. */
 void udet_debug_force_conv(int bm, int bn, int ks);
-/* what the most recent convolution launch actually ran: family (0 plain, 1 wave-specialised, 2 LDS-DMA, 3 tile-resident)
+/* what the most recent convolution launch actually ran: family (0 plain, 1 wave-specialised, 2 LDS-DMA, 3 tile-resident, 6 self-staging LDS-DMA)
  * | tile rows << 8 | split count << 20 */
 int udet_debug_last_conv(void);
 

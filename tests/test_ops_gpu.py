@@ -131,9 +131,12 @@ def test_conv2d_transpose(ops, n, h, w, cin, cout):
 
 
 # every convolution kernel family on the same problems (the autotuner picks among them per shape at run time):
-# bm bit 16 = non-specialised 256-thread kernel, bit 17 = LDS-DMA staging, bit 18 = tile-resident kernel (low bits = tile height)
+# bm bit 16 = non-specialised 256-thread kernel, bit 17 = LDS-DMA staging, bit 18 = tile-resident kernel (low bits = tile height),
+# bit 19 = self-staging LDS-DMA kernel (4 waves, 16-wide stages)
 FAMILIES = {"plain": (128 + (1 << 16), 32, 1), "wave_spec": (128, 32, 1), "lds_dma": (128 + (1 << 17), 32, 1),
-            "lds_dma_split3": (128 + (1 << 17), 32, 3), "tile8": ((1 << 18) + 8, 0, 1), "tile4": ((1 << 18) + 4, 0, 1)}
+            "lds_dma_split3": (128 + (1 << 17), 32, 3), "tile8": ((1 << 18) + 8, 0, 1), "tile4": ((1 << 18) + 4, 0, 1),
+            "self_staging": (128 + (1 << 19), 64, 1), "self_staging_128": (128 + (1 << 19), 128, 1),
+            "self_staging_split2": (64 + (1 << 19), 64, 2)}
 THIN_CASES = [
     # n,h,w,cin,cout,k,s
     (1, 32, 64, 16, 16, 3, 1),    # 16-wide MFMA tile kernel
@@ -158,7 +161,8 @@ def force_conv():
     lib.udet_debug_force_conv(0, 0, -1)
 
 
-WS_OF = {"plain": 0, "wave_spec": 1, "lds_dma": 2, "lds_dma_split3": 2, "tile8": 3, "tile4": 3}
+WS_OF = {"plain": 0, "wave_spec": 1, "lds_dma": 2, "lds_dma_split3": 2, "tile8": 3, "tile4": 3, "self_staging": 6,
+         "self_staging_128": 6, "self_staging_split2": 6}
 
 
 @pytest.mark.parametrize("family", list(FAMILIES))

@@ -586,6 +586,210 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_dma_kernel(const ConvParams
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Self-staging LDS-DMA variant: 256 threads = 4 MFMA waves that also issue the DMA of the next stage themselves (the
+// address arithmetic runs in the shadow of the previous MFMAs), 16-wide K stages.  A 128x128 tile then needs 32 KB of
+// LDS and one wave per SIMD, so three to four workgroups share a CU -- the MFMA pipe of a SIMD is fed by waves of
+// DIFFERENT workgroups that are at different points of their stage (one waits at its barrier or for its fragments while
+// another multiplies).  conv_bench on the 128-channel 3x3 layer: one wave-specialised 128x128 workgroup alone on a CU
+// keeps the pipe 44 % busy, two co-resident ones 57 %.
+// A stage: row-major [BM][16] (64-byte rows, 4 slots of 16 B), slot XOR-swizzled by (row>>1)&3 on the source side; B: [16][BN].
+// ---------------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256, 3) void conv_igemm_dma4_kernel(const ConvParams p) {
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+  constexpr int BK = 16;
+  constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  static_assert(TM * 32 == WTM && TN * 32 == WTN && BM % 64 == 0 && BN % 64 == 0, "tile");
+  constexpr int A_LD = BM / 64;               // 256 threads cover 64 rows x 4 slots per pass
+  constexpr int B_F4_ROW = BN / 4;
+  constexpr int B_LD = BK * B_F4_ROW / 256;
+  static_assert(B_LD * 256 == BK * B_F4_ROW, "BK*BN/4 must be a multiple of 256");
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+
+  __shared__ __attribute__((aligned(16))) float As[2][BM][BK];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
+  __shared__ int rowoff[BM];
+  __shared__ int2 tap_yx[UDET_MAX_TAPS];
+  __shared__ int tap_w[UDET_MAX_TAPS];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int li = lane & 31, lh = lane >> 5;
+
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int OHWq = p.OHq * p.OWq;
+  const int Mtot = p.N * OHWq;
+  const int mtiles = (Mtot + BM - 1) / BM;
+  const int cls = bid / mtiles;
+  const int m0 = (bid - cls * mtiles) * BM;
+  const int n0 = blockIdx.y * BN;
+  const int tap0 = p.cls_tap[cls];
+  const int ntc = p.cls_tap[cls + 1] - tap0;
+  const int ooy = p.ncls > 1 ? (cls >> 1) : p.ooy, oox = p.ncls > 1 ? (cls & 1) : p.oox;
+  const int Hs = p.H >> p.up_shift, Ws = p.W >> p.up_shift;
+
+  for (int i = t; i < ntc; i += 256) {
+    tap_yx[i] = make_int2(p.taps[tap0 + i].dy, p.taps[tap0 + i].dx);
+    tap_w[i] = p.taps[tap0 + i].widx;
+  }
+  for (int r = t; r < BM; r += 256) {
+    const int m = m0 + r;
+    int off = -1;
+    if (m < Mtot) {
+      const int n = (int)fdiv(m, p.fd_ohw), rem = m - n * OHWq;
+      const int qy = (int)fdiv(rem, p.fd_ow), qx = rem - qy * p.OWq;
+      off = p.ksplit > 1 ? cls * Mtot + m : (n * p.OH + qy * p.osy + ooy) * p.OW + qx * p.osx + oox;
+    }
+    rowoff[r] = off;
+  }
+  const int Kc = p.Kc;
+  const int nchunks = (ntc * Kc + BK - 1) / BK;
+  int c_begin = 0, c_end = nchunks;
+  if (p.ksplit > 1) {
+    c_begin = (int)((long)nchunks * blockIdx.z / p.ksplit);
+    c_end = (int)((long)nchunks * (blockIdx.z + 1) / p.ksplit);
+  }
+  __syncthreads();
+
+  // ---- staging state of this thread: A_LD rows x one 16-byte slot, B_LD float4 of the weight stage ---------------
+  const int kq = lane & 3;                                   // LDS slot written by this lane (lane-linear)
+  const int kqs = kq ^ ((wave * 8 + (lane >> 3)) & 3);       // channel group it holds: slot ^ ((row>>1)&3), row = wave*16 + lane>>2
+  int a_base[A_LD], a_iy0[A_LD], a_ix0[A_LD];
+#pragma unroll
+  for (int j = 0; j < A_LD; ++j) {
+    const int m = m0 + j * 64 + wave * 16 + (lane >> 2);
+    if (m < Mtot) {
+      const int n = (int)fdiv(m, p.fd_ohw), rem = m - n * OHWq;
+      const int qy = (int)fdiv(rem, p.fd_ow), qx = rem - qy * p.OWq;
+      a_base[j] = n * Hs * Ws;
+      a_iy0[j] = qy * p.isy;
+      a_ix0[j] = qx * p.isx;
+    } else {
+      a_base[j] = 0;
+      a_iy0[j] = -(1 << 28);
+      a_ix0[j] = 0;
+    }
+  }
+  const KOrder ko = korder(Kc, ntc, p.dbg);
+  KCursor ka = kc_init(ko, c_begin * BK + kqs * 4), kb[B_LD];
+#pragma unroll
+  for (int j = 0; j < B_LD; ++j) kb[j] = kc_init(ko, c_begin * BK + (t + j * 256) / B_F4_ROW);
+  const float* zero = p.zero16;
+  auto issue = [&](int buf) {
+    int dy = 0, dx = 0;
+    const bool a_ok = kc_valid(ko, ka);
+    const int a_c = kc_chan(ko, ka);
+    if (a_ok) {
+      const int2 yx = tap_yx[ka.tap];
+      dy = yx.x;
+      dx = yx.y;
+    }
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) {
+      int iy = a_iy0[j] + dy, ix = a_ix0[j] + dx;
+      const bool ok = a_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      iy >>= p.up_shift;
+      ix >>= p.up_shift;
+      const float* src = ok ? p.x + ((size_t)(a_base[j] + iy * Ws + ix) * p.ldx + p.x_coff + a_c) : zero;
+      __builtin_amdgcn_global_load_lds(src, (lds_ptr)&As[buf][j * 64 + wave * 16][0], 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) {
+      const int c4 = (t + j * 256) % B_F4_ROW;
+      const int n = n0 + c4 * 4;
+      const bool ok = kc_valid(ko, kb[j]) && n < p.ldw;
+      const int wi = ok ? tap_w[kb[j].tap] : 0;
+      const float* src = ok ? p.wp + (((size_t)wi * Kc + kc_chan(ko, kb[j])) * p.ldw + n) : zero;
+      __builtin_amdgcn_global_load_lds(src, (lds_ptr)(&Bs[buf][0][0] + (j * 256 + wave * 64) * 4), 16, 0, 0);
+    }
+    kc_advance(ko, ka, BK);
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) kc_advance(ko, kb[j], BK);
+  };
+  auto meet = [&]() {  // this wave's DMA has landed and its fragment reads are done, then meet the other waves
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+
+  floatx16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int swz = (li >> 1) & 3;  // (row>>1)&3 of every row this lane reads (wave / sub-tile offsets are multiples of 32)
+  auto compute_chunk = [&](int buf) {
+    float4 a[2][TM];
+    float b[2][4][TN];
+    auto frag = [&](int s_, int kk) {
+      const int g = 2 * kk + lh;  // channel group of this lane half
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[s_][i] = *reinterpret_cast<const float4*>(&As[buf][wm * WTM + i * 32 + li][(g ^ swz) * 4]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[s_][e][j] = Bs[buf][g * 4 + e][wn * WTN + j * 32 + li];
+    };
+    frag(0, 0);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      if (kk + 1 < 2) frag((kk + 1) & 1, kk + 1);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const float av = e == 0 ? a[kk & 1][i].x : (e == 1 ? a[kk & 1][i].y : (e == 2 ? a[kk & 1][i].z : a[kk & 1][i].w));
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[kk & 1][e][j], acc[i][j], 0, 0, 0);
+        }
+      }
+      if (kk + 1 < 2) __builtin_amdgcn_sched_group_barrier(0x100, TM + 4 * TN, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);
+    }
+  };
+
+  if (c_begin < c_end) issue(0);
+  meet();
+  {
+    int buf = 0;
+    for (int c = c_begin; c < c_end; ++c) {
+      if (c + 1 < c_end) issue(buf ^ 1);  // lands while this stage is multiplied
+      compute_chunk(buf);
+      meet();
+      buf ^= 1;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int off = rowoff[row];
+      if (off < 0) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WTN + j * 32 + li;
+        float v = acc[i][j][r];
+        if (p.ksplit > 1) {
+          if (n < p.ldp) p.partial[((size_t)blockIdx.z * p.ncls * Mtot + off) * p.ldp + n] = v;
+          continue;
+        }
+        if (n >= p.Cout) continue;
+        conv_epilogue(p, off, n, v);
+      }
+    }
+  }
+}
+
 // second pass of a split-K launch: sum the partial slabs and run the epilogue.  SL lanes share one output element
 // (each sums every SL-th slab, then a fixed-order shuffle tree): small outputs with many splits stay parallel.
 template <int SL>
@@ -616,14 +820,23 @@ static int g_last_cfg = 0;  // kernel family / tile / split count of the most re
 int conv_last_config() { return g_last_cfg; }
 void conv_force_config(int bm, int bn, int ks) {
   g_force_bm = bm & 0xffff; g_force_bn = bn; g_force_ks = ks;
-  g_force_ws = (bm >> 16) & 1 ? 0 : ((bm >> 17) & 1 ? 2 : ((bm >> 18) & 1 ? 3 : -1));  // bit 16: non-specialised, 17: LDS-DMA, 18: tile kernel
+  // bit 16: non-specialised, 17: LDS-DMA (wave-specialised), 18: tile kernel, 19: self-staging LDS-DMA (4 waves, BK 16)
+  g_force_ws = (bm >> 16) & 1 ? 0 : ((bm >> 17) & 1 ? 2 : ((bm >> 18) & 1 ? 3 : ((bm >> 19) & 1 ? 6 : -1)));
 }
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
 static int launch_cfg(const ConvParams& p, int ws, hipStream_t stream) {
   const int Mtot = p.N * p.OHq * p.OWq;
   dim3 grid(p.ncls * ((Mtot + BM - 1) / BM), (p.Cout + BN - 1) / BN, p.ksplit > 1 ? p.ksplit : 1);
-  if (ws == 2) hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WAVES_M, WAVES_N>), grid, dim3(512), 0, stream, p);
+  if (ws == 6) {
+    if constexpr (BM % 64 == 0 && BN % 64 == 0 && BM <= 128) {
+      hipLaunchKernelGGL((conv_igemm_dma4_kernel<BM, BN, 2, 2>), grid, dim3(256), 0, stream, p);
+    } else {
+      set_error("conv: no self-staging kernel for tile %dx%d", BM, BN);
+      return UDET_ERR_UNSUPPORTED;
+    }
+  }
+  else if (ws == 2) hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WAVES_M, WAVES_N>), grid, dim3(512), 0, stream, p);
   else if (ws) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, true>), grid, dim3(512), 0, stream, p);
   else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, false>), grid, dim3(256), 0, stream, p);
   UDET_HIP(hipGetLastError());
@@ -774,11 +987,14 @@ static ConvCfg tune_cfg(ConvParams& p, hipStream_t stream) {
   if (dma_ok(p)) {  // LDS-DMA staging: re-scan the tiles, the balance between staging and MFMA waves differs
     for (auto& c : cand) {
       ConvCfg d = c;
-      d.ws = 2;
-      const float ms = time_cfg(p, d, 3, stream);
-      if (ms < a * 0.98f) {
-        const float ms5 = time_cfg(p, d, 5, stream);
-        if (ms5 < a * 0.98f) { a = ms5; best = d; }
+      for (int ws : {2, 6}) {  // wave-specialised / self-staging (4 waves, 16-wide stages, 3-4 workgroups per CU)
+        if (ws == 6 && !((d.bm == 128 || d.bm == 64) && (d.bn == 64 || d.bn == 128))) continue;
+        d.ws = ws;
+        const float ms = time_cfg(p, d, 3, stream);
+        if (ms < a * 0.98f) {
+          const float ms5 = time_cfg(p, d, 5, stream);
+          if (ms5 < a * 0.98f) { a = ms5; best = d; }
+        }
       }
     }
     b = a;
@@ -842,7 +1058,8 @@ int launch_conv(ConvParams& p, hipStream_t stream) {
   if (g_force_bm) { c.bm = g_force_bm; c.bn = g_force_bn; }
   if (g_force_ks >= 0) c.ks = g_force_ks > max_ksplit(p) ? max_ksplit(p) : g_force_ks;
   if (g_force_ws >= 0) c.ws = g_force_ws;
-  if (c.ws == 2 && !dma_ok(p)) c.ws = 1;
+  if ((c.ws == 2 || c.ws == 6) && !dma_ok(p)) c.ws = 1;
+  if (c.ws == 6 && !((c.bm == 128 || c.bm == 64) && (c.bn == 64 || c.bn == 128))) c.ws = 2;
   if (g_force_ws == 3) { c.ws = 3; c.bm = (g_force_bm == 4) ? 4 : 8; }
   if (c.ws == 3 && !tile_ok(p, c.bm)) { c = heuristic_cfg(p); }
   g_last_cfg = (c.ws & 0xff) | ((c.bm & 0xfff) << 8) | ((c.ks & 0xff) << 20);
