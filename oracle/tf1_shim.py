@@ -44,6 +44,7 @@ class _State:
         self.dtype = torch.float32
         self.rng = torch.Generator().manual_seed(0)
         self.raw_grads = []           # one [(grad, var)] list per optimizer.compute_gradients call
+        self.draws = []               # every random draw, in order: (op, value) -- TF's own generator cannot be reproduced
 
 
 STATE = _State()
@@ -127,6 +128,30 @@ def _get_shape(self):
 
 
 torch.Tensor.get_shape = _get_shape  # the reference calls x.get_shape().as_list() / x.get_shape()[i]
+torch.Tensor.set_shape = lambda self, shape: None
+
+
+class FlipTensor(torch.Tensor):
+    """torch tensor that accepts numpy/TF style reversed slices (x[:, ::-1, :], data/aug_flips.py:3-9)."""
+
+    def __getitem__(self, idx):
+        if isinstance(idx, tuple) and any(isinstance(i, slice) and i.step is not None and i.step < 0 for i in idx):
+            dims, clean = [], []
+            for d, i in enumerate(idx):
+                if isinstance(i, slice) and i.step is not None and i.step < 0:
+                    if i != slice(None, None, -1):
+                        raise NotImplementedError(i)
+                    dims.append(d)
+                    clean.append(slice(None))
+                else:
+                    clean.append(i)
+            return torch.flip(torch.Tensor.__getitem__(self, tuple(clean)), dims)
+        return torch.Tensor.__getitem__(self, idx)
+
+
+def as_tf(x):
+    """numpy array / tensor -> tensor with TF-style indexing."""
+    return torch.as_tensor(np.asarray(x) if not isinstance(x, torch.Tensor) else x).as_subclass(FlipTensor)
 
 
 def _t(x, like=None):
@@ -316,8 +341,40 @@ def tf_slice(x, begin, size, name=None):
 
 
 def random_uniform(shape, minval=0, maxval=None, dtype=None, seed=None, name=None):
-    u = torch.rand([int(s) for s in shape], generator=STATE.rng, dtype=STATE.dtype)
-    return u * (float(maxval) - float(minval)) + float(minval)
+    shp = [int(v) for v in shape]
+    if dtype in (torch.int32, torch.int64):
+        lo, hi = int(minval), int(maxval)
+        v = torch.randint(lo, hi, shp, generator=STATE.rng, dtype=dtype)
+    else:
+        hi = 1.0 if maxval is None else float(maxval)
+        v = torch.rand(shp, generator=STATE.rng, dtype=STATE.dtype) * (hi - float(minval)) + float(minval)
+    if v.numel() <= 16:
+        STATE.draws.append(("random_uniform", v.clone().numpy()))
+    return v
+
+
+def equal(a, b, name=None):
+    return torch.eq(_t(a), _t(b))
+
+
+def random_crop(value, size, seed=None, name=None):
+    """tf.random_crop: a window of `size` at a uniformly drawn offset (offset recorded in STATE.draws)."""
+    size = [int(v) for v in size]
+    off = [int(torch.randint(0, int(d) - sz + 1, [], generator=STATE.rng)) for d, sz in zip(value.shape, size)]
+    STATE.draws.append(("random_crop", np.array(off + size, np.int64)))
+    return value[tuple(slice(o, o + sz) for o, sz in zip(off, size))]
+
+
+def central_crop(image, central_fraction):
+    """tf.image.central_crop (image_ops_impl.py, TF 1.13): start = int32((size - size*fraction) / 2), extent = size - 2*start."""
+    if central_fraction >= 1.0:
+        return image
+    hd, wd = (0, 1) if image.dim() == 3 else (1, 2)
+    h, w = int(image.shape[hd]), int(image.shape[wd])
+    y0, x0 = int((h - h * central_fraction) / 2), int((w - w * central_fraction) / 2)
+    idx = [slice(None)] * image.dim()
+    idx[hd], idx[wd] = slice(y0, h - y0), slice(x0, w - x0)
+    return image[tuple(idx)]
 
 
 def placeholder(dtype, shape=None, name=None):
@@ -473,6 +530,8 @@ class ResizeMethod:
 
 
 def resize_images(images, size, method=ResizeMethod.BILINEAR, align_corners=False, **kw):
+    if images.dim() == 3:  # a single HWC image
+        return resize_images(images.unsqueeze(0), size, method, align_corners).squeeze(0)
     size = [int(size[0]), int(size[1])]
     if [int(images.shape[1]), int(images.shape[2])] == size:
         return images  # tf.image.resize_images returns the input when the size already matches
@@ -566,7 +625,7 @@ def install():
     layers = _mod("tensorflow.layers", conv2d=layers_conv2d, conv2d_transpose=layers_conv2d_transpose,
                   batch_normalization=layers_batch_normalization)
     image = _mod("tensorflow.image", resize_bilinear=resize_bilinear, resize_nearest_neighbor=resize_nearest_neighbor,
-                 resize_images=resize_images, ResizeMethod=ResizeMethod)
+                 resize_images=resize_images, ResizeMethod=ResizeMethod, central_crop=central_crop)
     contrib = _mod("tensorflow.contrib",
                    layers=_mod("tensorflow.contrib.layers", xavier_initializer_conv2d=_initializer, xavier_initializer=_initializer),
                    framework=_mod("tensorflow.contrib.framework", model_variable=model_variable))
@@ -574,14 +633,14 @@ def install():
     train = _mod("tensorflow.train", AdamOptimizer=AdamOptimizer)
     tf = _mod(
         "tensorflow", nn=nn, layers=layers, image=image, contrib=contrib, keras=keras, train=train,
-        float32=float32, float64=float64, half=float16, float16=float16, int32=int32, int64=int64, bool=bool_,
+        float32=float32, float64=float64, half=float16, float16=float16, int32=int32, int64=int64, bool=bool_, uint8=torch.uint8,
         Tensor=torch.Tensor, AUTO_REUSE="auto_reuse", GraphKeys=GraphKeys,
         cast=cast, constant=constant, convert_to_tensor=convert_to_tensor, shape=shape, unstack=unstack, stack=stack,
         concat=concat, expand_dims=expand_dims, reshape=reshape, identity=identity, ones_like=ones_like, zeros_like=zeros_like,
         add=add, divide=divide, square=square, sqrt=sqrt, pow=tf_pow, abs=tf_abs, floor=floor, minimum=minimum, maximum=maximum,
         range=tf_range, meshgrid=meshgrid, gather=gather, clip_by_value=clip_by_value, reduce_sum=reduce_sum,
         reduce_mean=reduce_mean, cond=cond, logical_or=logical_or, logical_and=logical_and, pad=pad, slice=tf_slice,
-        random_uniform=random_uniform, placeholder=placeholder, variable_scope=variable_scope, name_scope=name_scope,
+        random_uniform=random_uniform, random_crop=random_crop, equal=equal, placeholder=placeholder, variable_scope=variable_scope, name_scope=name_scope,
         constant_initializer=_initializer, get_collection=get_collection, Variable=Variable, group=group, assign=assign,
         device=lambda *a, **k: contextlib.nullcontext(),
     )

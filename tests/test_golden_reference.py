@@ -145,6 +145,43 @@ def test_oracle_step_matches_reference_build_train_graph():
             _summaries_close(G.grad_summary(clipped[k].numpy()), g["grad/%s/%s" % (tag, k)], 2e-3, floor)
 
 
+def _flip_flags(cases):
+    """(outer, inner) draws of data/aug_flips.py:35-45 -> (flip_lr, flip_td): outer 0 = keep | rotate 180, outer 1 = lr | td."""
+    outer, inner = int(cases[0]), int(cases[1])
+    if outer == 0:
+        return (0, 0) if inner == 0 else (1, 1)
+    return (1, 0) if inner == 0 else (0, 1)
+
+
+def test_oracle_input_stage_matches_reference_reader():
+    g = gold("input_stage")
+    img = ONP.preprocess_image(g["img_u8"][None])[0]
+    assert np.array_equal(img[::32], g["preprocess_image_rows"])
+    assert abs(float(img.astype(np.float64).sum()) - g["preprocess_image_sum"][0]) < 1e-6 * g["preprocess_image_sum"][1]
+    msk = ONP.preprocess_mask(g["mask_u8"][None])[0]
+    assert np.array_equal(msk[::32], g["preprocess_mask_rows"]) and float(msk.astype(np.float64).sum()) == g["preprocess_mask_sum"][0]
+    small, small2 = g["small"], g["small2"]
+    h, w, _ = small.shape
+    for frac in (0.85, 0.9, 0.95, 1.0):
+        y0, x0, ch, cw = ONP.central_crop_box(h, w, frac)
+        got = ONP.flip_crop_resize(small[None], y0, x0, ch, cw, 0, 0)[0]
+        assert np.array_equal(got, g["central_%g" % frac]), frac
+    for k in range(4):
+        y0, x0, ch, cw = (int(v) for v in g["rand_crop_%d_box" % k])
+        # crop size = int(size * (p + u*(1-p))) in float32 (davis2016_data_utils.py:108-116)
+        pct = np.float32(0.8) + np.float32(g["rand_crop_%d_u" % k][0]) * np.float32(1 - 0.8)
+        assert (ch, cw) == (int(np.float32(h) * pct), int(np.float32(w) * pct))
+        assert np.array_equal(ONP.flip_crop_resize(small[None], y0, x0, ch, cw, 0, 0)[0], g["rand_crop_%d_a" % k])
+        assert np.array_equal(ONP.flip_crop_resize(small2[None], y0, x0, ch, cw, 0, 0)[0], g["rand_crop_%d_b" % k])
+    seen = set()
+    for k in range(8):
+        lr, td = _flip_flags(g["flip_%d_cases" % k])
+        seen.add((lr, td))
+        a = ONP.flip_crop_resize(small[None, :6, :10], 0, 0, 6, 10, lr, td)[0]
+        assert np.array_equal(a, g["flip_%d_a" % k])
+    assert len(seen) >= 3  # the eight recorded draws cover at least three of the four outcomes
+
+
 # ----------------------------------------------------------------------------------------------- GPU: HIP path vs reference
 
 @pytest.fixture(scope="module")
@@ -230,3 +267,29 @@ def test_hip_step_matches_reference_build_train_graph(gpu_env):
         for k, v in d.items():
             _summaries_close(G.grad_summary(v.numpy()), g["rawgrad/%s/%s" % (tag, k)], 2e-3, floor)
             _summaries_close(G.grad_summary(v.clamp(-0.2, 0.2).numpy()), g["grad/%s/%s" % (tag, k)], 2e-3, floor)
+
+
+@pytest.mark.gpu
+def test_hip_input_stage_matches_reference_reader():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from unsupervised_detection_amd import data as D
+    g = gold("input_stage")
+    img = D.preprocess_image(T(g["img_u8"][None].copy()).cuda()).cpu().numpy()[0]
+    assert np.array_equal(img[::32], g["preprocess_image_rows"])  # bit-exact: same float32 op order as the reader
+    msk = D.preprocess_mask(T(g["mask_u8"][None].copy()).cuda()).cpu().numpy()[0]
+    assert np.array_equal(msk[::32], g["preprocess_mask_rows"])
+    small, small2 = T(g["small"][None].copy()).cuda(), T(g["small2"][None].copy()).cuda()
+    for frac in (0.85, 0.9, 0.95, 1.0):
+        assert np.array_equal(D.central_cropping(small, frac).cpu().numpy()[0], g["central_%g" % frac]), frac
+    h, w = g["small"].shape[:2]
+    for k in range(4):
+        y0, x0, ch, cw = (int(v) for v in g["rand_crop_%d_box" % k])
+        prm = np.array([[y0, x0, ch, cw, 0, 0]], np.int32)
+        assert np.array_equal(D.crop_flip_resize(small, h, w, prm).cpu().numpy()[0], g["rand_crop_%d_a" % k])
+        assert np.array_equal(D.crop_flip_resize(small2, h, w, prm).cpu().numpy()[0], g["rand_crop_%d_b" % k])
+    tiny = T(np.ascontiguousarray(g["small"][None, :6, :10])).cuda()
+    for k in range(8):
+        lr, td = _flip_flags(g["flip_%d_cases" % k])
+        prm = np.array([[0, 0, 6, 10, lr, td]], np.int32)
+        assert np.array_equal(D.crop_flip_resize(tiny, 6, 10, prm).cpu().numpy()[0], g["flip_%d_a" % k])
