@@ -217,10 +217,20 @@ __global__ __launch_bounds__(256) void tap_gather_kernel(const ConvParams g, con
       qx = ox >> 1;
     }
     float v = g.bias ? g.bias[co] : 0.f;
-    for (int t = g.cls_tap[cls]; t < g.cls_tap[cls + 1]; ++t) {
-      const int iy = qy + g.taps[t].dy, ix = qx + g.taps[t].dx;
-      if ((unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W)
-        v += z[((size_t)(n * g.H + iy) * g.W + ix) * ldz + g.taps[t].widx * g.Cout + co];
+    // eight taps in flight per trip (a branchy one-load-per-trip loop pays one L2 latency per tap: 25 of them for the
+    // 5x5 head); taps outside the image / past the class contribute +0, added in tap order
+    const int t1 = g.cls_tap[cls + 1];
+    for (int t0 = g.cls_tap[cls]; t0 < t1; t0 += 8) {
+      float a[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int t = t0 + u < t1 ? t0 + u : t1 - 1;
+        const int iy = qy + g.taps[t].dy, ix = qx + g.taps[t].dx;
+        const bool ok = t0 + u < t1 && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+        a[u] = ok ? z[((size_t)(n * g.H + iy) * g.W + ix) * ldz + g.taps[t].widx * g.Cout + co] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += a[u];
     }
     g.y[(size_t)pix * g.ldy + g.y_coff + co] = v;
   }

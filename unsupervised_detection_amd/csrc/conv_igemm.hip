@@ -801,8 +801,21 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const ConvPar
   const int sl = threadIdx.x % SL;
   for (long e = ((long)blockIdx.x * 256 + threadIdx.x) / SL; e < total; e += (long)gridDim.x * (256 / SL)) {
     const int ma = (int)(e / p.Cout), n = (int)(e - (long)ma * p.Cout);
+    // four slabs in flight per trip (the loads are independent; a plain loop waits for each before the next add);
+    // the additions keep the slab order, so the sum is the same number as before
     float v = 0.f;
-    for (int s = sl; s < p.ksplit; s += SL) v += p.partial[((size_t)s * Mall + ma) * p.ldp + n];
+    const float* src = p.partial + (size_t)ma * p.ldp + n;
+    const size_t slab = (size_t)Mall * p.ldp;
+    int s = sl;
+    for (; s + 3 * SL < p.ksplit; s += 4 * SL) {
+      const float a0 = src[(size_t)s * slab], a1 = src[(size_t)(s + SL) * slab];
+      const float a2 = src[(size_t)(s + 2 * SL) * slab], a3 = src[(size_t)(s + 3 * SL) * slab];
+      v += a0;
+      v += a1;
+      v += a2;
+      v += a3;
+    }
+    for (; s < p.ksplit; s += SL) v += src[(size_t)s * slab];
 #pragma unroll
     for (int d = SL / 2; d > 0; d >>= 1) v += __shfl_xor(v, d, SL);
     if (sl != 0) continue;

@@ -345,8 +345,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradParams p, 
     if (is_bias && p.swapped && co >= p.oCout) continue;  // (uniform over the SL lanes of an element)
     const float* src = is_bias ? p.pbias + co : p.partial + (size_t)m * ldn + co;
     const size_t stride = is_bias ? (size_t)ldn : slab;
-    float s = 0.f;
-    for (int k = sl; k < nsplit; k += SL) s += src[k * stride];
+    float s = 0.f;  // eight partials in flight per trip, added in split order
+    int k = sl;
+    for (; k + 7 * SL < nsplit; k += 8 * SL) {
+      float a[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] = src[(size_t)(k + u * SL) * stride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += a[u];
+    }
+    for (; k < nsplit; k += SL) s += src[k * stride];
 #pragma unroll
     for (int d = SL / 2; d > 0; d >>= 1) s += __shfl_xor(s, d, SL);
     if (sl != 0) continue;

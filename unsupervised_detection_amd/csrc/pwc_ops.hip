@@ -1,4 +1,6 @@
 // Bandwidth-bound PWC-Net kernels: dense backward warp and the 81-channel cost volume.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace udet {
@@ -103,27 +105,47 @@ __global__ __launch_bounds__(256) void cost_volume_kernel(const float* __restric
 #pragma unroll
   for (int j = 0; j < CV_ND; ++j) acc[j] = 0.f;
 
+  // Global -> registers -> LDS: all loads of a 32-channel slice are issued back to back (one memory latency per slice, not
+  // one per loop trip), and the next slice is fetched before this slice's arithmetic so that its latency hides behind it.
+  constexpr int HL = CV_HALO * CV_HALO * 8 / 256;  // float4 halo loads per thread (8)
+  constexpr int TL = CV_T * CV_T * 8 / 256;        // float4 c1 loads per thread (2)
+  int hoff[HL], toff[TL];                           // global element offsets (-1: outside the image); N*H*W*C < 2^31
+#pragma unroll
+  for (int u = 0; u < HL; ++u) {
+    const int hp = (t + u * 256) >> 3;
+    const int hy = hp / CV_HALO, hx = hp - hy * CV_HALO;
+    const int yy = y0 + hy - CV_R, xx = x0 + hx - CV_R;
+    hoff[u] = ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) ? ((n * H + yy) * W + xx) * C : -1;
+  }
+#pragma unroll
+  for (int u = 0; u < TL; ++u) {
+    const int tp = (t + u * 256) >> 3;
+    const int yy = y0 + (tp >> 3), xx = x0 + (tp & 7);
+    toff[u] = (yy < H && xx < W) ? ((n * H + yy) * W + xx) * C : -1;
+  }
+  const int c4 = t & 7;  // (t + u*256) & 7
+  float4 hv[HL], tv[TL];
+  auto fetch = [&](int cb) {
+    const bool cok = c4 * 4 < min(32, C - cb);
+#pragma unroll
+    for (int u = 0; u < HL; ++u) {
+      hv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (cok && hoff[u] >= 0) hv[u] = *reinterpret_cast<const float4*>(wr + hoff[u] + cb + c4 * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < TL; ++u) {
+      tv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (cok && toff[u] >= 0) tv[u] = *reinterpret_cast<const float4*>(c1 + toff[u] + cb + c4 * 4);
+    }
+  };
+  fetch(0);
   for (int cb = 0; cb < C; cb += 32) {
-    const int cw = min(32, C - cb);  // multiple of 4
-    // stage the halo of warp: 256 pixels x 8 float4
-    for (int e = t; e < CV_HALO * CV_HALO * 8; e += 256) {
-      const int c4 = e & 7, hp = e >> 3;
-      const int hy = hp / CV_HALO, hx = hp - hy * CV_HALO;
-      const int yy = y0 + hy - CV_R, xx = x0 + hx - CV_R;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (c4 * 4 < cw && (unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
-        v = *reinterpret_cast<const float4*>(wr + (((long)n * H + yy) * W + xx) * C + cb + c4 * 4);
-      *reinterpret_cast<float4*>(&sw[hp * CV_CS + c4 * 4]) = v;
-    }
-    for (int e = t; e < CV_T * CV_T * 8; e += 256) {
-      const int c4 = e & 7, tp = e >> 3;
-      const int yy = y0 + (tp >> 3), xx = x0 + (tp & 7);
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (c4 * 4 < cw && yy < H && xx < W)
-        v = *reinterpret_cast<const float4*>(c1 + (((long)n * H + yy) * W + xx) * C + cb + c4 * 4);
-      *reinterpret_cast<float4*>(&s1[tp * CV_CS + c4 * 4]) = v;
-    }
+#pragma unroll
+    for (int u = 0; u < HL; ++u) *reinterpret_cast<float4*>(&sw[((t + u * 256) >> 3) * CV_CS + c4 * 4]) = hv[u];
+#pragma unroll
+    for (int u = 0; u < TL; ++u) *reinterpret_cast<float4*>(&s1[((t + u * 256) >> 3) * CV_CS + c4 * 4]) = tv[u];
     __syncthreads();
+    if (cb + 32 < C) fetch(cb + 32);
     float4 a[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) a[q] = *reinterpret_cast<const float4*>(&s1[p * CV_CS + q * 4]);
@@ -169,6 +191,10 @@ int launch_cost_volume(const float* c1, const float* wr, float* out, int ldo, in
                        hipStream_t stream) {
   if (C % 4 != 0) {
     set_error("cost_volume: C=%d must be a multiple of 4", C);
+    return UDET_ERR_SHAPE;
+  }
+  if ((long)N * H * W * C >= (1L << 31)) {
+    set_error("cost_volume: tensor too large for 32-bit element offsets");
     return UDET_ERR_SHAPE;
   }
   const int tiles = ((W + CV_T - 1) / CV_T) * ((H + CV_T - 1) / CV_T) * N;
