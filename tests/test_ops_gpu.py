@@ -146,7 +146,19 @@ THIN_CASES = [
     (1, 32, 48, 4, 16, 7, 2),     # stride-2 forward, 7x7 over the ld=4 input
     (1, 32, 64, 16, 32, 5, 2),    # stride 2: backward-data runs four parity classes, 16 output channels
     (1, 32, 64, 32, 64, 3, 2),
+    (1, 30, 50, 16, 16, 3, 1),    # ragged: 50 = 32 + 18 columns, 30 rows; partial tiles on both axes
+    (2, 13, 37, 32, 32, 5, 1),    # odd sizes, 5x5
+    (1, 31, 47, 32, 64, 3, 2),    # odd grid, stride 2: backward-data falls back to one launch per parity class
 ]
+
+
+def _tile_fits(th, cin, cout, k, s):
+    """LDS need of the tile-resident kernel (conv_tile_lds_bytes): halo tile of <= 32 channels + all taps' weights of one
+    32- (16-) column block must fit 96 KB; otherwise a forced tile family falls back to the built-in choice."""
+    cb = min((cin + 7) // 8 * 8, 32)
+    nw = 16 if cout <= 16 else 32
+    pix = ((th - 1) * s + k) * (31 * s + k)
+    return (cb // 4 * (pix | 1) + (k * k * cb // 4 + 64 // nw) * nw) * 16 + (k * k + 2 * pix) * 4 <= 96 * 1024
 
 
 @pytest.fixture
@@ -178,12 +190,13 @@ def test_conv_kernel_families(ops, force_conv, family, case):
     gx, = torch.autograd.grad((lin * dy).sum(), [x])
     force_conv.udet_debug_force_conv(*FAMILIES[family])
     got = ops.conv2d(x.detach().float().cuda(), wt.float().cuda(), b.float().cuda(), s, 1, "leaky", 0.1, False).cpu()
-    if WS_OF[family] != 3 or not (s == 2 and cin >= 16):  # stride-2 halo of >= 16 channels + 25 taps of weights exceed the LDS budget
+    if WS_OF[family] != 3 or _tile_fits(8 if family == "tile8" else 4, cin, cout, k, s):
         assert (force_conv.udet_debug_last_conv() & 0xff) == WS_OF[family]  # the family under test really ran
     assert (got - y.detach().float()).abs().max() < 1e-4 * max(1.0, float(y.abs().max()))
     # backward-data of the linear layer (no act' on load: the form the step uses, dU being materialised by its producer)
     dx = ops.conv2d_backward_data(dy.float().cuda(), lin.detach().float().cuda(), wt.float().cuda(), (h, w), s, 1, "none", 0.0).cpu()
-    if WS_OF[family] != 3 or cin <= 64:  # the tile-resident kernel takes at most 64 output channels (= cin here)
+    # backward-data: K = cout, N = cin (at most 64 columns in the tile-resident kernel), stride-1 walk over the dY grid
+    if WS_OF[family] != 3 or (cin <= 64 and _tile_fits(8 if family == "tile8" else 4, cout, cin, k, 1)):
         assert (force_conv.udet_debug_last_conv() & 0xff) == WS_OF[family]
     assert (dx - gx.float()).abs().max() < 2e-4 * max(1.0, float(gx.abs().max()))
 
