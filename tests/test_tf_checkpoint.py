@@ -1,0 +1,83 @@
+"""CPU: the TensorFlow-free reader / writer of tf.train.Saver V2 checkpoints (unsupervised_detection_amd/tf_checkpoint.py).
+No TensorFlow-written file exists here, so the reader is exercised on files from the writer; CRC-32C is pinned by its
+published check value, and every layer of the format (varints, prefix-compressed keys, restart arrays, block trailers,
+footer, protobuf entries) by round trips over awkward inputs plus corruption tests."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from unsupervised_detection_amd import tf_checkpoint as C
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_crc32c_known_answers():
+    assert C.crc32c(b"123456789") == 0xE3069283          # the CRC-32C check value
+    assert C.crc32c(b"") == 0
+    assert C.crc32c(bytes(32)) == 0x8A9136AA             # RFC 3720 B.4: 32 bytes of zeros
+    assert C.crc32c(bytes([0xFF] * 32)) == 0x62A8AB43    # RFC 3720 B.4: 32 bytes of ones
+    assert C.crc32c(bytes(range(32))) == 0x46DD794E      # RFC 3720 B.4: incrementing bytes
+    big = np.random.RandomState(1).randint(0, 256, size=70001).astype(np.uint8)
+    assert C.crc32c(big) == C._update_scalar(0xFFFFFFFF, big.tolist()) ^ 0xFFFFFFFF  # chunked path == byte-serial path
+    assert C.unmask_crc(C.mask_crc(0xDEADBEEF)) == 0xDEADBEEF
+
+
+def test_round_trip_with_the_references_variable_names(tmp_path):
+    from unsupervised_detection_amd import weights as W
+    with open(os.path.join(ROOT, "tests", "golden", "names.json")) as f:
+        created = json.load(f)["variables_created_by_the_reference"]
+    rs = np.random.RandomState(0)
+    tensors = {}
+    for v in created["generator_net + recover_net"]:
+        tensors[v["tf"]] = rs.standard_normal(v["shape"]).astype(np.float32)
+    tensors["train_op/global_step"] = np.array(175, np.int64)                    # scalar, not a float
+    tensors["MaskNet//conv1/kernel/Adam"] = np.zeros((5, 5, 5, 32), np.float32)  # optimizer slot: ignored on import
+    prefix = str(tmp_path / "model-175")
+    C.write_checkpoint(prefix, tensors, block_entries=7)  # many data blocks -> a real index block
+    header, entries = C.read_index(prefix)
+    assert header["num_shards"] == 1 and set(entries) == set(tensors)
+    back = C.read_checkpoint(prefix)
+    for k, v in tensors.items():
+        assert back[k].dtype == v.dtype and back[k].shape == v.shape and np.array_equal(back[k], v), k
+    flat = W.from_tf_dict(back, W.NET_REC)
+    d = W.as_dict(flat, W.NET_REC)
+    assert np.array_equal(d["FlownetS/aconv1/weights"].numpy(), tensors["FlownetS//aconv1/weights"])
+    gen = W.as_dict(W.from_tf_dict(back, W.NET_GEN), W.NET_GEN)
+    assert np.array_equal(gen["MaskNet/conv3/bn/gamma"].numpy(), tensors["MaskNet//batch_normalization_2/gamma"])
+    # names round-trip: canonical -> TF -> canonical
+    for net in (W.NET_PWC, W.NET_GEN, W.NET_REC):
+        for name, _, _ in W.param_table(net):
+            assert W.canonical_name(C.tf_variable_name(name)) == name
+
+
+def test_corruption_is_detected(tmp_path):
+    prefix = str(tmp_path / "ck")
+    C.write_checkpoint(prefix, {"a/kernel": np.arange(12, dtype=np.float32).reshape(3, 4), "a/bias": np.ones(4, np.float32)})
+    data = bytearray(open(prefix + ".data-00000-of-00001", "rb").read())
+    data[16 + 5] ^= 0x40  # inside a/kernel (keys are stored in byte order: a/bias occupies the first 16 bytes)
+    open(prefix + ".data-00000-of-00001", "wb").write(bytes(data))
+    with pytest.raises(ValueError, match="checksum"):
+        C.read_checkpoint(prefix)
+    assert C.read_checkpoint(prefix, verify=False)["a/bias"].tolist() == [1, 1, 1, 1]
+    idx = bytearray(open(prefix + ".index", "rb").read())
+    idx[3] ^= 0x01
+    open(prefix + ".index", "wb").write(bytes(idx))
+    with pytest.raises(ValueError):
+        C.read_index(prefix)
+    open(prefix + ".index", "wb").write(b"not a table")
+    with pytest.raises(ValueError, match="magic"):
+        C.read_index(prefix)
+
+
+def test_learner_restores_a_saver_prefix(tmp_path):
+    """--recover_ckpt given as a checkpoint prefix (as in the reference's scripts) goes through the TensorBundle reader."""
+    import types
+    from unsupervised_detection_amd import weights as W
+    from unsupervised_detection_amd.learner import AdversarialLearner
+    tensors = {C.tf_variable_name(n): np.full(s, 0.25, np.float32) for n, s, _ in W.param_table(W.NET_REC)}
+    prefix = str(tmp_path / "model-175")
+    C.write_checkpoint(prefix, tensors)
+    out = AdversarialLearner()._load_weights(types.SimpleNamespace(flow_ckpt="", recover_ckpt=prefix, full_model_ckpt=""))
+    assert set(out) == {"w_rec"} and out["w_rec"].numel() == W.param_total(W.NET_REC) and float(out["w_rec"].min()) == 0.25

@@ -12,6 +12,8 @@ _DEFS = [
     ("recover_ckpt", str, ""), ("flow_ckpt", str, ""), ("full_model_ckpt", str, ""), ("checkpoint_dir", str, ""),
     ("summary_freq", int, 30), ("save_freq", int, 5), ("generate_visualization", bool, False), ("test_crop", float, 0.9),
     ("test_temporal_shift", int, 1), ("ckpt_file", str, ""), ("test_partition", str, "val"), ("test_save_dir", str, ""),
+    # not a reference flag: also write checkpoints in tf.train.Saver format under the reference's variable names
+    ("save_tf_checkpoint", bool, False),
 ]
 
 

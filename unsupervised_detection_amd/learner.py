@@ -57,14 +57,19 @@ class AdversarialLearner(object):
     def _load_weights(self, config):
         """Checkpoint policy of train() (:339-360): PWC weights are mandatory in the reference; here synthetic
         weights with the reference's initializers stand in when no flat-weight file is given (README.md:59-64
-        checkpoints are external downloads).  Files are {variable name: array} dicts -- torch.save'd, or .npz -- under the
+        checkpoints are external downloads).  Accepted: a tf.train.Saver V2 checkpoint prefix (`<prefix>.index` +
+        `<prefix>.data-*`, read by tf_checkpoint.py), or {variable name: array} dicts -- torch.save'd, or .npz -- under the
         TF checkpoint's own names ("MaskNet//conv1/kernel", "MaskNet//batch_normalization_3/gamma", ...; optimizer slots
         and BN moving statistics are ignored) or the canonical ones of weights.param_table()."""
         import os
         out = {}
         for key, flag, net in (("w_pwc", "flow_ckpt", W.NET_PWC), ("w_rec", "recover_ckpt", W.NET_REC), ("w_gen", "full_model_ckpt", W.NET_GEN)):
             path = getattr(config, flag, "")
-            if path and os.path.isfile(path):
+            if path and os.path.isfile(path + ".index"):  # a tf.train.Saver checkpoint prefix, e.g. pwcnet.ckpt-595000
+                from .tf_checkpoint import read_checkpoint
+                out[key] = W.from_tf_dict(read_checkpoint(path), net)
+                print("{} restored from TF checkpoint {}".format(flag, path))
+            elif path and os.path.isfile(path):
                 d = dict(np.load(path)) if path.endswith(".npz") else torch.load(path, map_location="cpu")
                 out[key] = W.from_tf_dict(d, net)
                 print("{} loaded from {}".format(flag, path))
@@ -165,6 +170,13 @@ class AdversarialLearner(object):
         d["global_step"] = torch.tensor(self.global_step)
         name = "model.best" if step == "best" else "model-{}".format(step)
         torch.save({k: v.clone() for k, v in d.items()}, os.path.join(checkpoint_dir, name))
+        if getattr(self.config, "save_tf_checkpoint", False):
+            # the same weights as a tf.train.Saver V2 checkpoint under the reference's variable names: its
+            # test_generator.py / train.py --full_model_ckpt can restore them (tf_checkpoint.py)
+            from .tf_checkpoint import tf_variable_name, write_checkpoint
+            tf_vars = {tf_variable_name(k): v.numpy() for k, v in d.items() if k != "global_step"}
+            tf_vars["train_op/global_step"] = np.array(self.global_step, np.int64)
+            write_checkpoint(os.path.join(checkpoint_dir, name + ".tf"), tf_vars)
 
     # ----------------------------------------------------------------- inference ----
     def setup_inference(self, config, aug_test=False):
