@@ -22,7 +22,6 @@ Gradients (``optimizer.compute_gradients``) are torch autograd through the same 
 from __future__ import annotations
 
 import contextlib
-import math
 import sys
 import types
 from collections import OrderedDict

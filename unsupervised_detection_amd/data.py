@@ -13,7 +13,6 @@ JPEG / PNG decoding stays on the host (Pillow); batches are dicts {"img1","img2"
 form AdversarialLearner consumes (config.data_source)."""
 from __future__ import annotations
 
-import ctypes
 import os
 
 import numpy as np

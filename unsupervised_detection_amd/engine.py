@@ -8,7 +8,7 @@ from dataclasses import dataclass
 import torch
 
 from ._ffi import c_f, c_i, c_p, c_sz, check, lib
-from .weights import NET_GEN, NET_REC
+from .weights import NET_GEN, NET_REC  # noqa: F401  (re-exported: the net ids udet_apply takes)
 
 
 class _Cfg(ctypes.Structure):

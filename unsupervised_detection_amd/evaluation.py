@@ -12,7 +12,6 @@ The batch functions take device tensors [B,H,W,1]; one kernel pass produces ever
 the MAE need (exact counts, double accumulation), the few scalar operations that remain run on the host."""
 from __future__ import annotations
 
-import ctypes
 
 import numpy as np
 import torch

@@ -23,7 +23,7 @@ import torch
 
 from . import data as _data
 from . import weights as W
-from .engine import BOTH, GEN, REC, Engine, EngineConfig
+from .engine import GEN, REC, Engine, EngineConfig
 from .trainer import TrainState, train_step
 
 TEST_CROPS = [0.85, 0.9, 0.95, 1.0]  # adversarial_learner.py:531

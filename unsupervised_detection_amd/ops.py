@@ -5,7 +5,6 @@ from __future__ import annotations
 
 import torch
 
-from . import _ffi
 from ._ffi import check, lib
 
 ACT = {"none": 0, "identity": 0, "leaky": 1, "elu": 2}

@@ -10,7 +10,7 @@ from __future__ import annotations
 import torch
 
 from . import weights as W
-from .engine import BOTH, GEN, REC, Engine, EngineConfig
+from .engine import BOTH, GEN, REC, Engine
 
 
 class TrainState:
