@@ -136,7 +136,8 @@ def test_conv2d_transpose(ops, n, h, w, cin, cout):
 FAMILIES = {"plain": (128 + (1 << 16), 32, 1), "wave_spec": (128, 32, 1), "lds_dma": (128 + (1 << 17), 32, 1),
             "lds_dma_split3": (128 + (1 << 17), 32, 3), "tile8": ((1 << 18) + 8, 0, 1), "tile4": ((1 << 18) + 4, 0, 1),
             "self_staging": (128 + (1 << 19), 64, 1), "self_staging_128": (128 + (1 << 19), 128, 1),
-            "self_staging_split2": (64 + (1 << 19), 64, 2)}
+            "self_staging_split2": (64 + (1 << 19), 64, 2), "self_staging_n32": (128 + (1 << 19), 32, 1),
+            "self_staging_256x32": (256 + (1 << 19), 32, 1)}
 THIN_CASES = [
     # n,h,w,cin,cout,k,s
     (1, 32, 64, 16, 16, 3, 1),    # 16-wide MFMA tile kernel
@@ -174,7 +175,7 @@ def force_conv():
 
 
 WS_OF = {"plain": 0, "wave_spec": 1, "lds_dma": 2, "lds_dma_split3": 2, "tile8": 3, "tile4": 3, "self_staging": 6,
-         "self_staging_128": 6, "self_staging_split2": 6}
+         "self_staging_128": 6, "self_staging_split2": 6, "self_staging_n32": 6, "self_staging_256x32": 6}
 
 
 @pytest.mark.parametrize("family", list(FAMILIES))

@@ -601,11 +601,12 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_dma4_kernel(const ConvParam
   constexpr int BK = 16;
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
   constexpr int TM = WTM / 32, TN = WTN / 32;
-  static_assert(TM * 32 == WTM && TN * 32 == WTN && BM % 64 == 0 && BN % 64 == 0, "tile");
+  static_assert(TM * 32 == WTM && TN * 32 == WTN && BM % 64 == 0 && BN % 32 == 0, "tile");
   constexpr int A_LD = BM / 64;               // 256 threads cover 64 rows x 4 slots per pass
   constexpr int B_F4_ROW = BN / 4;
-  constexpr int B_LD = BK * B_F4_ROW / 256;
-  static_assert(B_LD * 256 == BK * B_F4_ROW, "BK*BN/4 must be a multiple of 256");
+  constexpr int B_F4 = BK * B_F4_ROW;         // float4 of one weight stage (128 for BN = 32: half of the threads load)
+  constexpr int B_LD = (B_F4 + 255) / 256;
+  static_assert(B_F4 % 64 == 0, "whole waves issue the weight DMA");
   typedef __attribute__((address_space(3))) void* lds_ptr;
 
   __shared__ __attribute__((aligned(16))) float As[2][BM][BK];
@@ -702,12 +703,14 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_dma4_kernel(const ConvParam
     }
 #pragma unroll
     for (int j = 0; j < B_LD; ++j) {
-      const int c4 = (t + j * 256) % B_F4_ROW;
-      const int n = n0 + c4 * 4;
-      const bool ok = kc_valid(ko, kb[j]) && n < p.ldw;
-      const int wi = ok ? tap_w[kb[j].tap] : 0;
-      const float* src = ok ? p.wp + (((size_t)wi * Kc + kc_chan(ko, kb[j])) * p.ldw + n) : zero;
-      __builtin_amdgcn_global_load_lds(src, (lds_ptr)(&Bs[buf][0][0] + (j * 256 + wave * 64) * 4), 16, 0, 0);
+      if (j * 256 + wave * 64 < B_F4) {  // wave-uniform
+        const int c4 = (t + j * 256) % B_F4_ROW;
+        const int n = n0 + c4 * 4;
+        const bool ok = kc_valid(ko, kb[j]) && n < p.ldw;
+        const int wi = ok ? tap_w[kb[j].tap] : 0;
+        const float* src = ok ? p.wp + (((size_t)wi * Kc + kc_chan(ko, kb[j])) * p.ldw + n) : zero;
+        __builtin_amdgcn_global_load_lds(src, (lds_ptr)(&Bs[buf][0][0] + (j * 256 + wave * 64) * 4), 16, 0, 0);
+      }
     }
     kc_advance(ko, ka, BK);
 #pragma unroll
@@ -844,6 +847,8 @@ static int launch_cfg(const ConvParams& p, int ws, hipStream_t stream) {
   if (ws == 6) {
     if constexpr (BM % 64 == 0 && BN % 64 == 0 && BM <= 128) {
       hipLaunchKernelGGL((conv_igemm_dma4_kernel<BM, BN, 2, 2>), grid, dim3(256), 0, stream, p);
+    } else if constexpr (BN == 32 && BM % 128 == 0) {
+      hipLaunchKernelGGL((conv_igemm_dma4_kernel<BM, BN, 4, 1>), grid, dim3(256), 0, stream, p);
     } else {
       set_error("conv: no self-staging kernel for tile %dx%d", BM, BN);
       return UDET_ERR_UNSUPPORTED;
@@ -892,6 +897,9 @@ int launch_conv_tile(const ConvParams& p, int th, hipStream_t stream);
 static bool tile_ok(const ConvParams& p, int th) {
   const size_t b = conv_tile_lds_bytes(p, th, nullptr, nullptr);
   return b > 0 && b <= 96 * 1024 && p.Kc <= 256 && p.Cout <= 64;
+}
+static bool self_staging_tile(int bm, int bn) {  // tiles conv_igemm_dma4_kernel is instantiated for
+  return ((bm == 128 || bm == 64) && (bn == 64 || bn == 128)) || (bn == 32 && (bm == 128 || bm == 256));
 }
 static bool dma_ok(const ConvParams& p) { return p.xa == nullptr && p.zero16 != nullptr && !(reinterpret_cast<uintptr_t>(p.zero16) & 15); }
 static ConvCfg heuristic_cfg(const ConvParams& p) {
@@ -1001,7 +1009,7 @@ static ConvCfg tune_cfg(ConvParams& p, hipStream_t stream) {
     for (auto& c : cand) {
       ConvCfg d = c;
       for (int ws : {2, 6}) {  // wave-specialised / self-staging (4 waves, 16-wide stages, 3-4 workgroups per CU)
-        if (ws == 6 && !((d.bm == 128 || d.bm == 64) && (d.bn == 64 || d.bn == 128))) continue;
+        if (ws == 6 && !self_staging_tile(d.bm, d.bn)) continue;
         d.ws = ws;
         const float ms = time_cfg(p, d, 3, stream);
         if (ms < a * 0.98f) {
@@ -1072,7 +1080,7 @@ int launch_conv(ConvParams& p, hipStream_t stream) {
   if (g_force_ks >= 0) c.ks = g_force_ks > max_ksplit(p) ? max_ksplit(p) : g_force_ks;
   if (g_force_ws >= 0) c.ws = g_force_ws;
   if ((c.ws == 2 || c.ws == 6) && !dma_ok(p)) c.ws = 1;
-  if (c.ws == 6 && !((c.bm == 128 || c.bm == 64) && (c.bn == 64 || c.bn == 128))) c.ws = 2;
+  if (c.ws == 6 && !self_staging_tile(c.bm, c.bn)) c.ws = 2;
   if (g_force_ws == 3) { c.ws = 3; c.bm = (g_force_bm == 4) ? 4 : 8; }
   if (c.ws == 3 && !tile_ok(p, c.bm)) { c = heuristic_cfg(p); }
   g_last_cfg = (c.ws & 0xff) | ((c.bm & 0xfff) << 8) | ((c.ks & 0xff) << 20);
