@@ -2,6 +2,8 @@
 // (tap lists, sub-grids, TF 'SAME' padding) + the weight packing kernels.
 #include <string.h>
 
+#include <stdint.h>
+
 #include "common.h"
 #include "conv_host.h"
 
@@ -235,9 +237,49 @@ __global__ __launch_bounds__(256) void tap_gather_kernel(const ConvParams g, con
     g.y[(size_t)pix * g.ldy + g.y_coff + co] = v;
   }
 }
+// the 2-channel heads (every flow / up_feat / upflow layer): one thread per pixel, float2 per tap
+__global__ __launch_bounds__(256) void tap_gather2_kernel(const ConvParams g, const float* __restrict__ z, int ldz) {
+  const long total = (long)g.N * g.OH * g.OW;
+  for (long pix = (long)blockIdx.x * 256 + threadIdx.x; pix < total; pix += (long)gridDim.x * 256) {
+    const int ox = (int)(pix % g.OW), oy = (int)((pix / g.OW) % g.OH), n = (int)(pix / ((long)g.OW * g.OH));
+    int cls = 0, qy = oy, qx = ox;
+    if (g.ncls > 1) {
+      cls = (oy & 1) * 2 + (ox & 1);
+      qy = oy >> 1;
+      qx = ox >> 1;
+    }
+    float2 v = g.bias ? make_float2(g.bias[0], g.bias[1]) : make_float2(0.f, 0.f);
+    const int t1 = g.cls_tap[cls + 1];
+    for (int t0 = g.cls_tap[cls]; t0 < t1; t0 += 8) {
+      float2 a[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int t = t0 + u < t1 ? t0 + u : t1 - 1;
+        const int iy = qy + g.taps[t].dy, ix = qx + g.taps[t].dx;
+        const bool ok = t0 + u < t1 && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+        a[u] = ok ? *reinterpret_cast<const float2*>(z + ((size_t)(n * g.H + iy) * g.W + ix) * ldz + g.taps[t].widx * 2)
+                  : make_float2(0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        v.x += a[u].x;
+        v.y += a[u].y;
+      }
+    }
+    *reinterpret_cast<float2*>(g.y + (size_t)pix * g.ldy + g.y_coff) = v;
+  }
+}
 int launch_tap_gather(const ConvParams& g, const float* z, int ldz, hipStream_t stream) {
   ConvParams q = g;
   if (q.ncls != 4) { q.ncls = 1; q.cls_tap[0] = 0; q.cls_tap[1] = q.ntaps; }
+  if (q.Cout == 2 && ldz % 2 == 0 && q.ldy % 2 == 0 && q.y_coff % 2 == 0 && !((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(q.y)) & 7)) {
+    const long pixels = (long)q.N * q.OH * q.OW;
+    int nb2 = (int)((pixels + 255) / 256);
+    if (nb2 > 4096) nb2 = 4096;
+    hipLaunchKernelGGL(tap_gather2_kernel, dim3(nb2), dim3(256), 0, stream, q, z, ldz);
+    UDET_HIP(hipGetLastError());
+    return UDET_OK;
+  }
   const long total = (long)q.N * q.OH * q.OW * q.Cout;
   int nb = (int)((total + 255) / 256);
   if (nb > 4096) nb = 4096;
