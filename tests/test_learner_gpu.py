@@ -59,6 +59,50 @@ def test_inference_dict_contract(gpu, monkeypatch):
     assert out["outs"]["pred_masks"][0.9].shape == (64, 128, 1) and out["outs"]["img_1s"][1.0].shape == (64, 128, 3)
 
 
+class _SrcGt(_Src):
+    """reader-style batches: annotation at the reader's resolution (here 128x192), image size of the graphs 64x128"""
+
+    def __iter__(self):
+        g = torch.Generator().manual_seed(3)
+        for b in super().__iter__():
+            m = (torch.rand(self.batch, self.hw[0] // 8, self.hw[1] // 8, 1, generator=g) > 0.5).float()
+            b["gt_mask"] = m.repeat_interleave(8, 1).repeat_interleave(8, 2).contiguous().cuda()
+            yield b
+
+
+def test_ground_truth_masks_follow_the_graphs(gpu, monkeypatch):
+    """adversarial_learner.py:92-94, :498-500, :568-570: the annotation is resized to img_height x img_width with
+    nearest-neighbour sampling inside the graphs; the augmented graph crops it centrally first (reader, :348)."""
+    from oracle import oracle_np as ONP
+    from unsupervised_detection_amd import learner as Lr
+    monkeypatch.setattr(Lr, "_engine_config", lambda config, batch=None, in_hw=(128, 192): Lr.EngineConfig(
+        batch_size=batch or config.batch_size, in_height=128, in_width=192, img_height=config.img_height, img_width=config.img_width))
+    src = _SrcGt(2, 1)
+    ref_gt = next(iter(src))["gt_mask"].cpu().numpy()
+    lr = Lr.AdversarialLearner()
+    lr.setup_inference(_cfg(data_source=_SrcGt(2, 1)), aug_test=False)
+    out = lr.inference(None)
+    assert out["gt_masks"].shape == (2, 64, 128, 1)
+    assert np.array_equal(out["gt_masks"], ONP.resize_nearest_legacy(ref_gt, 64, 128))
+    # validation IoU of the training graph: generated masks against the resized annotation
+    from unsupervised_detection_amd.evaluation import compute_all_IoU
+    lr.config.batch_size = 2
+    v = lr.validation_iou(_SrcGt(2, 1))
+    lr.engine.forward(next(iter(_SrcGt(2, 1)))["img1"], next(iter(_SrcGt(2, 1)))["img2"], 0)
+    want = ONP.compute_all_IoU(lr.engine.buffer("mask").cpu().numpy(), ONP.resize_nearest_legacy(ref_gt, 64, 128)).sum() / 2
+    assert abs(v - want) < 1e-6
+    # augmented graph: central crop (bilinear resize back, like the reader's central_cropping), then nearest to 64x128
+    lr2 = Lr.AdversarialLearner()
+    lr2.setup_inference(_cfg(data_source=_SrcGt(1, 1)), aug_test=True)
+    outs = lr2.inference(None)["outs"]
+    one = next(iter(_SrcGt(1, 1)))["gt_mask"].cpu().numpy()
+    for crop in lr2.test_crops:
+        y0, x0, ch, cw = ONP.central_crop_box(128, 192, crop)
+        cropped = ONP.flip_crop_resize(one, y0, x0, ch, cw, 0, 0) if crop < 1.0 else one
+        assert outs["gt_masks"][crop].shape == (64, 128, 1)
+        assert np.array_equal(outs["gt_masks"][crop], ONP.resize_nearest_legacy(cropped, 64, 128)[0]), crop
+
+
 def test_train_loop_runs_and_learns_schedule(gpu, monkeypatch, capsys):
     from unsupervised_detection_amd import learner as Lr
     monkeypatch.setattr(Lr, "_engine_config", lambda config, batch=None, in_hw=(128, 192): Lr.EngineConfig(

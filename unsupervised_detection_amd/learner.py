@@ -137,7 +137,7 @@ class AdversarialLearner(object):
             if batch.get("gt_mask") is None:
                 continue
             e.forward(batch["img1"], batch["img2"], 0)
-            total += float(compute_all_IoU(e.buffer("mask").contiguous(), batch["gt_mask"].contiguous()).sum())
+            total += float(compute_all_IoU(e.buffer("mask").contiguous(), self._resize_gt(batch["gt_mask"]).contiguous()).sum())
             steps += 1
         return total / max(steps * self.config.batch_size, 1)
 
@@ -198,6 +198,14 @@ class AdversarialLearner(object):
         """tf.image.central_crop + resize back to 384x640 (data/davis2016_data_utils.py:129-133,328-354)."""
         return _data.central_cropping(img, frac)
 
+    def _resize_gt(self, gt):
+        """The graphs resize the annotation to the working resolution with nearest-neighbour sampling
+        (adversarial_learner.py:92-94 train / validation, :498-500 test, :568-570 augmented test)."""
+        e = self.engine.cfg
+        if gt is None or (gt.shape[1] == e.img_height and gt.shape[2] == e.img_width):
+            return gt
+        return _data.crop_flip_resize(gt.contiguous(), e.img_height, e.img_width, None, True)
+
     def inference(self, sess=None):
         """Outputs a dictionary with the results of the required operations (:606-623).  `sess` is accepted and
         ignored.  Raises StopIteration at the end of the data (the reference raises tf.errors.OutOfRangeError)."""
@@ -211,12 +219,13 @@ class AdversarialLearner(object):
                 e.forward(i1, i2, 0)
                 outs["pred_masks"][crop] = e.buffer("mask")[0].cpu().numpy()
                 outs["img_1s"][crop] = e.buffer("image")[0].cpu().numpy()
-                gt = batch.get("gt_mask")
-                outs["gt_masks"][crop] = None if gt is None else gt[0].cpu().numpy()
+                gt = batch.get("gt_mask")  # seg_1s[crop]: central_cropping of the annotation (bilinear, :348), then nearest
+                outs["gt_masks"][crop] = None if gt is None else \
+                    self._resize_gt(self._central_crop_resize(gt, crop))[0].cpu().numpy()
             return {"outs": outs, "img_fname": batch["fname"][0]}
         e.forward(batch["img1"], batch["img2"], 1)
         B = e.cfg.batch_size
-        gt = batch.get("gt_mask")
+        gt = self._resize_gt(batch.get("gt_mask"))
         return {"gen_masks": e.buffer("mask").cpu().numpy(), "pred_flow": e.buffer("pred")[:B].cpu().numpy(),
                 "input_image": e.buffer("image").cpu().numpy(), "gt_flow": e.buffer("flow").cpu().numpy(),
                 "gt_masks": None if gt is None else gt.cpu().numpy(), "img_fname": np.array(batch["fname"])}
