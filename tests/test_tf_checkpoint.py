@@ -81,3 +81,20 @@ def test_learner_restores_a_saver_prefix(tmp_path):
     C.write_checkpoint(prefix, tensors)
     out = AdversarialLearner()._load_weights(types.SimpleNamespace(flow_ckpt="", recover_ckpt=prefix, full_model_ckpt=""))
     assert set(out) == {"w_rec"} and out["w_rec"].numel() == W.param_total(W.NET_REC) and float(out["w_rec"].min()) == 0.25
+
+
+def test_full_model_checkpoint_restores_every_network_it_holds(tmp_path):
+    """test_generator.py restores ONE checkpoint holding all trainable variables (generator, recover net, PWC-Net)."""
+    import types
+    from unsupervised_detection_amd import weights as W
+    from unsupervised_detection_amd.learner import AdversarialLearner
+    tensors = {}
+    for net, val in ((W.NET_GEN, 0.5), (W.NET_REC, 0.25)):
+        tensors.update({C.tf_variable_name(n): np.full(s, val, np.float32) for n, s, _ in W.param_table(net)})
+    tensors["train_op/global_step"] = np.array(7, np.int64)
+    prefix = str(tmp_path / "model.best")
+    C.write_checkpoint(prefix, tensors)
+    out = AdversarialLearner()._load_weights(types.SimpleNamespace(flow_ckpt="", recover_ckpt="", full_model_ckpt="", ckpt_file=prefix))
+    assert set(out) == {"w_gen", "w_rec"} and float(out["w_gen"].max()) == 0.5 and float(out["w_rec"].max()) == 0.25
+    with pytest.raises(IOError):
+        AdversarialLearner()._load_weights(types.SimpleNamespace(flow_ckpt=str(tmp_path / "missing"), recover_ckpt="", full_model_ckpt=""))

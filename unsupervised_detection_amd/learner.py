@@ -55,26 +55,48 @@ class AdversarialLearner(object):
 
     # ------------------------------------------------------------------ training ----
     def _load_weights(self, config):
-        """Checkpoint policy of train() (:339-360): PWC weights are mandatory in the reference; here synthetic
-        weights with the reference's initializers stand in when no flat-weight file is given (README.md:59-64
-        checkpoints are external downloads).  Accepted: a tf.train.Saver V2 checkpoint prefix (`<prefix>.index` +
-        `<prefix>.data-*`, read by tf_checkpoint.py), or {variable name: array} dicts -- torch.save'd, or .npz -- under the
-        TF checkpoint's own names ("MaskNet//conv1/kernel", "MaskNet//batch_normalization_3/gamma", ...; optimizer slots
-        and BN moving statistics are ignored) or the canonical ones of weights.param_table()."""
+        """Checkpoint policy of train() (:339-360) and of the test scripts (test_generator.py:45-55): PWC weights are
+        mandatory in the reference; here synthetic weights with the reference's initializers stand in when no file is
+        given (README.md:59-64 checkpoints are external downloads).  Accepted: a tf.train.Saver V2 checkpoint prefix
+        (`<prefix>.index` + `<prefix>.data-*`, read by tf_checkpoint.py), or {variable name: array} dicts -- torch.save'd, or
+        .npz -- under the TF checkpoint's own names ("MaskNet//conv1/kernel", "MaskNet//batch_normalization_3/gamma", ...;
+        optimizer slots and BN moving statistics are ignored) or the canonical ones of weights.param_table().
+          flow_ckpt        -> PWC-Net                       (flow_saver, :329)
+          recover_ckpt     -> recover net                   (recover_saver, :327)
+          full_model_ckpt  -> every network it holds        (self.saver = all trainable variables: resume_train, :346-353)
+          ckpt_file        -> every network it holds        (test_generator.py:45-55, test_generator_ensemble.py)"""
         import os
-        out = {}
-        for key, flag, net in (("w_pwc", "flow_ckpt", W.NET_PWC), ("w_rec", "recover_ckpt", W.NET_REC), ("w_gen", "full_model_ckpt", W.NET_GEN)):
-            path = getattr(config, flag, "")
-            if path and os.path.isfile(path + ".index"):  # a tf.train.Saver checkpoint prefix, e.g. pwcnet.ckpt-595000
+
+        def read(path):
+            if os.path.isfile(path + ".index"):  # a Saver prefix, e.g. pwcnet.ckpt-595000
                 from .tf_checkpoint import read_checkpoint
-                out[key] = W.from_tf_dict(read_checkpoint(path), net)
-                print("{} restored from TF checkpoint {}".format(flag, path))
-            elif path and os.path.isfile(path):
-                d = dict(np.load(path)) if path.endswith(".npz") else torch.load(path, map_location="cpu")
+                return read_checkpoint(path), "restored from TF checkpoint"
+            if os.path.isfile(path):
+                return (dict(np.load(path)) if path.endswith(".npz") else torch.load(path, map_location="cpu")), "loaded from"
+            raise IOError("Could not find checkpoint file {}. Aborting.".format(path))
+
+        out = {}
+        for key, flag, net in (("w_pwc", "flow_ckpt", W.NET_PWC), ("w_rec", "recover_ckpt", W.NET_REC)):
+            path = getattr(config, flag, "")
+            if path:
+                d, how = read(path)
                 out[key] = W.from_tf_dict(d, net)
-                print("{} loaded from {}".format(flag, path))
-            elif path:
-                raise IOError("Could not find {} file {}. Aborting.".format(flag, path))
+                print("{} {} {}".format(flag, how, path))
+        for flag in ("full_model_ckpt", "ckpt_file"):
+            path = getattr(config, flag, "")
+            if not path:
+                continue
+            d, how = read(path)
+            found = []
+            for key, net in (("w_pwc", W.NET_PWC), ("w_gen", W.NET_GEN), ("w_rec", W.NET_REC)):
+                try:
+                    out[key] = W.from_tf_dict(d, net)
+                    found.append(key[2:])
+                except KeyError:
+                    pass  # this checkpoint does not hold that network
+            if not found:
+                raise IOError("{} {} holds none of the networks' variables".format(flag, path))
+            print("{} {} {} ({})".format(flag, how, path, ", ".join(found)))
         return out
 
     def train(self, config):
