@@ -61,15 +61,11 @@ def main(argv=None):
         learner.train(flags)
         return 0
     if cmd == "test_generator":
-        if flags.ckpt_file:
-            flags.full_model_ckpt = flags.ckpt_file
-        _sources(flags, "test")
+        _sources(flags, "test")  # --ckpt_file is restored by the learner (every network the checkpoint holds)
         learner.setup_inference(flags, aug_test=False)
         from .evaluation import evaluate_masks
         evaluate_masks(learner)
         return 0
-    if flags.ckpt_file:
-        flags.full_model_ckpt = flags.ckpt_file
     _sources(flags, "ensemble")
     learner.setup_inference(flags, aug_test=True)
     from .evaluation import evaluate_ensemble
