@@ -64,3 +64,17 @@ def grad_summary(g: np.ndarray):
     """What the fixtures keep of a gradient tensor: L2 norm, signed sum, the first 16 entries."""
     f = np.asarray(g, np.float64).ravel()
     return np.concatenate([[np.sqrt((f * f).sum()), f.sum()], np.pad(f[:16], (0, max(0, 16 - f.size)))]).astype(np.float64)
+
+
+# TensorFlow's own unit-test vectors for the resize kernels (tensorflow/python/ops/image_ops_test.py, r1.13,
+# ResizeImagesTest.testResizeUpAlignCornersFalse / testResizeUpAlignCornersTrue): input [1,3,2,1], expected kernel outputs
+TF_RESIZE_FALSE = dict(
+    data=[64, 32, 32, 64, 50, 100], in_hw=(3, 2), out_hw=(6, 4),
+    bilinear=[64.0, 48.0, 32.0, 32.0, 48.0, 48.0, 48.0, 48.0, 32.0, 48.0, 64.0, 64.0, 41.0, 61.5, 82.0, 82.0, 50.0, 75.0, 100.0, 100.0,
+              50.0, 75.0, 100.0, 100.0],
+    nearest=[64.0, 64.0, 32.0, 32.0, 64.0, 64.0, 32.0, 32.0, 32.0, 32.0, 64.0, 64.0, 32.0, 32.0, 64.0, 64.0, 50.0, 50.0, 100.0, 100.0,
+             50.0, 50.0, 100.0, 100.0])
+TF_RESIZE_TRUE = dict(
+    data=[6, 3, 3, 6, 6, 9], in_hw=(3, 2), out_hw=(5, 4),
+    bilinear=[6.0, 5.0, 4.0, 3.0, 4.5, 4.5, 4.5, 4.5, 3.0, 4.0, 5.0, 6.0, 4.5, 5.5, 6.5, 7.5, 6.0, 7.0, 8.0, 9.0],
+    nearest=[6.0, 6.0, 3.0, 3.0, 3.0, 3.0, 6.0, 6.0, 3.0, 3.0, 6.0, 6.0, 6.0, 6.0, 9.0, 9.0, 6.0, 6.0, 9.0, 9.0])

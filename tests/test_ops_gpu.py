@@ -234,3 +234,15 @@ def test_resize_bilinear_legacy(ops, h, w, oh, ow, c):
     (O.resize_bilinear_legacy(xd, oh, ow) * dy.double()).sum().backward()
     dx = ops.resize_bilinear_legacy_backward(dy.cuda(), h, w).cpu()
     assert (dx - xd.grad.float()).abs().max() < 1e-5
+
+
+def test_resize_kernels_reproduce_tensorflows_unit_test_vectors(ops):
+    """image_ops_test.py (TF r1.13) ResizeImagesTest.testResizeUpAlignCornersFalse: the legacy bilinear / nearest kernels."""
+    from oracle.golden_inputs import TF_RESIZE_FALSE as v
+    from unsupervised_detection_amd import data as D
+    x = torch.tensor(v["data"], dtype=torch.float32).reshape(1, *v["in_hw"], 1)
+    oh, ow = v["out_hw"]
+    got = ops.resize_bilinear_legacy(x.cuda(), oh, ow).cpu().reshape(-1).tolist()
+    assert got == v["bilinear"]
+    got = D.crop_flip_resize(x.cuda().contiguous(), oh, ow, None, True).cpu().reshape(-1).tolist()
+    assert got == v["nearest"]

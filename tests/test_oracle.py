@@ -216,3 +216,40 @@ def test_pwc_forward_shapes():
     flow, pyr = O.pwc_forward(pp, i1, i2)
     assert flow.shape == (1, 64, 128, 2) and [tuple(f.shape[1:3]) for f in pyr] == [(1, 2), (2, 4), (4, 8), (8, 16), (16, 32)]
     assert torch.isfinite(flow).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# TensorFlow's own unit-test vectors for the resize kernels (tensorflow/python/ops/image_ops_test.py, r1.13,
+# ResizeImagesTest.testResizeUpAlignCornersFalse / testResizeUpAlignCornersTrue): expected outputs of the C++ kernels the
+# oracle and the TF stand-in restate.  They pin the legacy (non-half-pixel) sampling of tf.image.resize_images and the
+# align_corners=True nearest-neighbour rounding used by the generator's x2 upsampling (convolution_utils.py:4-24,70).
+# ---------------------------------------------------------------------------------------------------------------
+from oracle.golden_inputs import TF_RESIZE_FALSE, TF_RESIZE_TRUE  # noqa: E402
+
+
+def test_resize_kernels_reproduce_tensorflows_unit_test_vectors():
+    import numpy as np
+    import torch
+    from oracle import oracle_np as ONP
+    from oracle import oracle_torch as OT
+    from oracle import tf1_shim as S
+    v = TF_RESIZE_FALSE
+    x = np.asarray(v["data"], np.float32).reshape(1, *v["in_hw"], 1)
+    oh, ow = v["out_hw"]
+    want_b = np.asarray(v["bilinear"], np.float32).reshape(1, oh, ow, 1)
+    want_n = np.asarray(v["nearest"], np.float32).reshape(1, oh, ow, 1)
+    assert np.array_equal(OT.resize_bilinear_legacy(torch.from_numpy(x), oh, ow).numpy(), want_b)
+    assert np.array_equal(ONP.resize_bilinear_legacy(x, oh, ow), want_b)
+    assert np.array_equal(S.resize_bilinear(torch.from_numpy(x), [oh, ow], align_corners=False).numpy(), want_b)
+    assert np.array_equal(OT.resize_nearest_legacy(torch.from_numpy(x), oh, ow).numpy(), want_n)
+    assert np.array_equal(ONP.resize_nearest_legacy(x, oh, ow), want_n)
+    assert np.array_equal(S.resize_nearest_neighbor(torch.from_numpy(x), [oh, ow], align_corners=False).numpy(), want_n)
+    v = TF_RESIZE_TRUE
+    x = np.asarray(v["data"], np.float32).reshape(1, *v["in_hw"], 1)
+    oh, ow = v["out_hw"]
+    want_b = np.asarray(v["bilinear"], np.float32).reshape(1, oh, ow, 1)
+    want_n = np.asarray(v["nearest"], np.float32).reshape(1, oh, ow, 1)
+    assert np.allclose(S.resize_bilinear(torch.from_numpy(x), [oh, ow], align_corners=True).numpy(), want_b, atol=1e-6)
+    assert np.array_equal(OT.resize_nearest_align_corners(torch.from_numpy(x), oh, ow).numpy(), want_n)
+    assert np.array_equal(ONP.resize_nearest_align_corners(x, oh, ow), want_n)
+    assert np.array_equal(S.resize_nearest_neighbor(torch.from_numpy(x), [oh, ow], align_corners=True).numpy(), want_n)
