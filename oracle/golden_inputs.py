@@ -78,3 +78,13 @@ TF_RESIZE_TRUE = dict(
     data=[6, 3, 3, 6, 6, 9], in_hw=(3, 2), out_hw=(5, 4),
     bilinear=[6.0, 5.0, 4.0, 3.0, 4.5, 4.5, 4.5, 4.5, 3.0, 4.0, 5.0, 6.0, 4.5, 5.5, 6.5, 7.5, 6.0, 7.0, 8.0, 9.0],
     nearest=[6.0, 6.0, 3.0, 3.0, 3.0, 3.0, 6.0, 6.0, 3.0, 3.0, 6.0, 6.0, 6.0, 6.0, 9.0, 9.0, 6.0, 6.0, 9.0, 9.0])
+
+
+# tensorflow/python/kernel_tests/conv_ops_test.py (r1.13), Conv2DTest: input and filter hold 1, 2, 3, ... in row-major
+# order (NHWC / HWIO); (input shape, filter shape, stride, expected flattened output) of the 'SAME'-padded cases
+TF_CONV_SAME = [
+    ([1, 2, 3, 3], [2, 2, 3, 3], 2, [2271.0, 2367.0, 2463.0, 1230.0, 1305.0, 1380.0]),   # testConv2D2x2FilterStride2Same
+    ([1, 3, 3, 1], [1, 1, 1, 1], 2, [1.0, 3.0, 7.0, 9.0]),                                # testConv2DKernelSmallerThanStrideSame
+    ([1, 4, 4, 1], [1, 1, 1, 1], 2, [1.0, 3.0, 9.0, 11.0]),
+    ([1, 4, 4, 1], [2, 2, 1, 1], 3, [44.0, 28.0, 41.0, 16.0]),
+]

@@ -246,3 +246,15 @@ def test_resize_kernels_reproduce_tensorflows_unit_test_vectors(ops):
     assert got == v["bilinear"]
     got = D.crop_flip_resize(x.cuda().contiguous(), oh, ow, None, True).cpu().reshape(-1).tolist()
     assert got == v["nearest"]
+
+
+def test_same_padded_convolution_reproduces_tensorflows_unit_test_vectors(ops):
+    """conv_ops_test.py (TF r1.13) Conv2DTest, the stride-2 'SAME' cases, through udet_conv2d."""
+    from oracle.golden_inputs import TF_CONV_SAME
+    for tin, fin, stride, expected in TF_CONV_SAME:
+        if stride > 2:
+            continue  # the path only has stride 1 / 2 layers
+        x = torch.arange(1, int(np.prod(tin)) + 1, dtype=torch.float32).reshape(tin)
+        w = torch.arange(1, int(np.prod(fin)) + 1, dtype=torch.float32).reshape(fin)
+        y = ops.conv2d(x.cuda(), w.cuda(), torch.zeros(fin[3]).cuda(), stride, 1, "none", 0.0, False).cpu()
+        assert y.reshape(-1).tolist() == expected  # small integers: exact in fp32

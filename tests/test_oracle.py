@@ -253,3 +253,20 @@ def test_resize_kernels_reproduce_tensorflows_unit_test_vectors():
     assert np.array_equal(OT.resize_nearest_align_corners(torch.from_numpy(x), oh, ow).numpy(), want_n)
     assert np.array_equal(ONP.resize_nearest_align_corners(x, oh, ow), want_n)
     assert np.array_equal(S.resize_nearest_neighbor(torch.from_numpy(x), [oh, ow], align_corners=True).numpy(), want_n)
+
+
+def test_same_padded_convolution_reproduces_tensorflows_unit_test_vectors():
+    """conv_ops_test.py (TF r1.13): the SAME-padding cases -- stride 2 on a 2x3 grid (pad (0,1)), kernel smaller than the
+    stride, stride 3 -- against both oracle restatements and the TF stand-in."""
+    import numpy as np
+    import torch
+    from oracle import oracle_np as ONP
+    from oracle import oracle_torch as OT
+    from oracle import tf1_shim as S
+    from oracle.golden_inputs import TF_CONV_SAME
+    for tin, fin, stride, expected in TF_CONV_SAME:
+        x = np.arange(1, int(np.prod(tin)) + 1, dtype=np.float32).reshape(tin)
+        w = np.arange(1, int(np.prod(fin)) + 1, dtype=np.float32).reshape(fin)
+        assert OT.conv2d_same(torch.from_numpy(x), torch.from_numpy(w), None, stride).reshape(-1).tolist() == expected
+        assert ONP.conv2d_same(x, w, None, stride).reshape(-1).tolist() == expected
+        assert S.nn_conv2d(torch.from_numpy(x), torch.from_numpy(w), [1, stride, stride, 1], "SAME").reshape(-1).tolist() == expected
