@@ -270,3 +270,21 @@ def test_same_padded_convolution_reproduces_tensorflows_unit_test_vectors():
         assert OT.conv2d_same(torch.from_numpy(x), torch.from_numpy(w), None, stride).reshape(-1).tolist() == expected
         assert ONP.conv2d_same(x, w, None, stride).reshape(-1).tolist() == expected
         assert S.nn_conv2d(torch.from_numpy(x), torch.from_numpy(w), [1, stride, stride, 1], "SAME").reshape(-1).tolist() == expected
+
+
+def test_transposed_convolution_reproduces_tensorflows_unit_test():
+    """conv2d_transpose_test.py (TF r1.13) testConv2DTransposeSame: ones [2,6,4,3] through a 3x3 stride-2 'SAME' transposed
+    convolution with a ones filter [3,3,2,3] -> [2,12,8,2]; every output is 3, +3 where one coordinate is an interior multiple
+    of the stride, +9 where both are.  Pins which border the SAME alignment favours in the TF stand-in's general kernel; the
+    oracle's 4x4 stride-2 special case is held to the stand-in by the PWC-Net fixtures (up_flow / up_feat layers)."""
+    import torch
+    from oracle import tf1_shim as S
+    S.reset(lambda name, shape: torch.ones(shape) if name.endswith("kernel") else torch.zeros(shape))
+    y = S.layers_conv2d_transpose(torch.ones(2, 6, 4, 3), 2, 3, 2, "same", name="t").numpy()
+    assert y.shape == (2, 12, 8, 2)
+    for h in range(12):
+        for w in range(8):
+            h_in = h % 2 == 0 and 0 < h < 11
+            w_in = w % 2 == 0 and 0 < w < 7
+            target = 3.0 + (9.0 if h_in and w_in else (3.0 if h_in or w_in else 0.0))
+            assert (y[:, h, w, :] == target).all(), (h, w)
