@@ -11,9 +11,12 @@ The reference's own Python does run, though: oracle/make_golden.py imports
 /root/reference's models/*.py (incl. AdversarialLearner.build_train_graph) on
 the eager TF-1.13 stand-in oracle/tf1_shim.py and commits the outputs as
 tests/golden/*.npz; tests/test_golden_reference.py holds this oracle (and the
-HIP path) to them.  Not pinned: the TF C++ kernels behind conv2d /
-conv2d_transpose SAME padding, the bilinear / nearest resizes and inference BN,
-which the stand-in restates independently.
+HIP path) to them.  The TF C++ kernels behind the stand-in's primitives are
+restated and checked against TensorFlow's own
+unit-test vectors where the semantics are subtle: legacy / align-corners
+bilinear and nearest resize (image_ops_test.py), SAME-padded strided conv2d
+(conv_ops_test.py), SAME conv2d_transpose (conv2d_transpose_test.py) --
+tests/test_oracle.py.  Inference BN is a closed formula.
 Further pins: (i) known-answer properties derived from the reference code
 (tests/test_oracle_*.py) and (ii) a second, independent explicit-loop numpy
 restatement of every index-math op (oracle/oracle_np.py).
