@@ -97,7 +97,14 @@ __global__ __launch_bounds__(256) void cost_volume_kernel(const float* __restric
   __shared__ __attribute__((aligned(16))) float s1[CV_T * CV_T * CV_CS];
   const int t = threadIdx.x;
   const int tiles_x = (W + CV_T - 1) / CV_T, tiles_y = (H + CV_T - 1) / CV_T;
-  const int bx = blockIdx.x % tiles_x, by = (blockIdx.x / tiles_x) % tiles_y, n = blockIdx.x / (tiles_x * tiles_y);
+  // XCD-aware tile order (workgroups are dealt round-robin to the 8 XCDs, each with its own L2): consecutive tiles -- whose
+  // 16x16 halos overlap -- go to the same XCD, so the overlap is fetched once per XCD instead of once per tile
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int bx = bid % tiles_x, by = (bid / tiles_x) % tiles_y, n = bid / (tiles_x * tiles_y);
   const int y0 = by * CV_T, x0 = bx * CV_T;
   const int p = t & 63, g = t >> 6;
   const int py = p >> 3, px = p & 7;
