@@ -46,6 +46,12 @@ int udet_warp_debug(const float* image, const float* flow, float flow_scale, flo
                     float* alpha_yx, int n, int h, int w, int c, void* stream);
 /* cost_volume(c1, warp, search_range=4) incl. leaky 0.1: models/PWCNet/core_costvol.py:20-40. out [n,h,w,81] */
 int udet_cost_volume(const float* c1, const float* warp, float* out, int n, int h, int w, int c, void* stream);
+/* The fused form the step plan launches once per pyramid level (model_pwcnet.py:616-623): warped = dense_image_warp(c2,
+ * flow*flow_scale) is produced tile by tile in LDS and correlated with c1 at once -- the warped tensor never exists in HBM.
+ * flow == NULL: no warp (level 6 correlates c1 with c2).  corr [n,h,w,81]; warped_dbg: optional [n,h,w,c] dump of the warped
+ * features (test hook).  Bit-identical to udet_warp followed by udet_cost_volume. */
+int udet_warp_cost_volume(const float* c1, const float* c2, const float* flow, float flow_scale, float* corr, float* warped_dbg,
+                          int n, int h, int w, int c, void* stream);
 
 /* tf.image.resize_images(x,[oh,ow]) / tf.image.resize_bilinear, TF-1.13 legacy sampling (align_corners=False, no
  * half-pixel centres): models/adversarial_learner.py:87-90, models/nets.py:108, models/utils/convolution_utils.py:88,
@@ -91,6 +97,34 @@ int udet_conv2d_backward_filter(const float* x, const float* dy, const float* y_
 int udet_conv2d_transpose4x4s2(const float* x, const float* w_hwoi, const float* bias, float* y, int n, int h, int w,
                                int cin, int cout, void* workspace, size_t workspace_bytes, void* stream);
 
+
+/* ---- per-stage entry points of the loss / optimizer tail (parity tests, callers that keep their own graph) ------------
+ * `workspace` (device, 8-byte aligned) >= udet_stage_workspace_bytes(n) holds the deterministic two-stage reduction partials. */
+size_t udet_stage_workspace_bytes(int n);
+/* preprocess_flow_batch(flow): models/utils/flow_utils.py:5-12 -- per sample and channel (f - mean) / sqrt(var), population
+ * variance, no epsilon.  flow, out [n,h,w,2]. */
+int udet_flow_normalize(const float* flow, float* out, int n, int h, int w, void* workspace, size_t workspace_bytes, void* stream);
+/* charbonnier_loss(gt_flows, pred_flows, masks, cbn): models/utils/loss_utils.py:34-51.  out[n] (device) = sum over h,w,c of
+ * ((gt - pred)^2 + 0.001^2)^cbn * mask; masks [n,h,w,mask_channels] with 1 (broadcast) or 2 channels, or NULL (ones). */
+int udet_charbonnier_loss(const float* gt_flows, const float* pred_flows, const float* masks, int mask_channels, int n, int h, int w,
+                          float cbn, float* out, void* workspace, size_t workspace_bytes, void* stream);
+/* losses{} of models/adversarial_learner.py:141-204 from flow [b,h,w,2], mask [b,h,w,1] and the three recover predictions
+ * pred3 [3b,h,w,2] (calls: masked, complement, image-only).  losses8 (device) in the order of :196-204; coef [b][4] (device) =
+ * d generator_loss / d {R_b, D_b, Rc_b, Dc_b}, consumed by udet_losses_backward. */
+int udet_losses_forward(const float* flow, const float* mask, const float* pred3, int b, int h, int w, float cbn, float epsilon,
+                        float* losses8, float* coef, void* workspace, size_t workspace_bytes, void* stream);
+/* tf.gradients of the two losses w.r.t. the predictions (models/utils/loss_utils.py:18 through :141-204):
+ * which = 2: d recover_loss / d pred3 -> dpred [3b,h,w,2];  which = 1: d generator_loss / d pred3[0:2b] -> dpred [2b,h,w,2]
+ * and the direct mask term -> dmask [b,h,w,1] (coef from udet_losses_forward). */
+int udet_losses_backward(const float* flow, const float* mask, const float* pred3, const float* coef, int which, int b, int h, int w,
+                         float cbn, float* dpred, float* dmask, void* stream);
+/* train_op, second half (models/utils/loss_utils.py:22-31): g <- flag2[1] != 0 ? |U(-clip,clip)| (counter-based stream keyed by
+ * (seed, step, index)) : clip(g, +-clip).  flag2: device {avg, flag} from udet_grad_absmean, or NULL (clip only). */
+int udet_clip_or_noise(float* g, size_t n, float clip, const float* flag2, unsigned long long seed, long step, void* stream);
+/* tf.train.AdamOptimizer(lr, beta1).apply_gradients (adversarial_learner.py:216; TF form lr_t = lr*sqrt(1-b2^t)/(1-b1^t)) on a
+ * flat buffer; t = number of applies of the shared optimizer object including this one (>= 1). */
+int udet_adam_step(float* w, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, long t,
+                   void* stream);
 
 /* ---- the step plan ------------------------------------------------------------------------
  * One plan = one (batch, shapes, flags) specialisation of the graph assembled by
@@ -156,6 +190,10 @@ int udet_forward_from_flow(udet_plan* plan, int ncalls, void* workspace, void* s
 /* generator_net(images, flows) alone (models/nets.py:4-42): reads "image","flow", writes "mask" (flow standardisation
  * of models/utils/flow_utils.py:5-12 included). */
 int udet_generator_forward(udet_plan* plan, void* workspace, void* stream);
+/* generator_net's own contract (models/nets.py:4-42): `flows` arrives ALREADY standardised (the call site passes
+ * preprocess_flow_batch(flow), adversarial_learner.py:99-105).  Reads the caller-packed buffer "gen.in" ([.,.,.,8]: image 3,
+ * standardised flow 2, zeros), writes "mask". */
+int udet_generator_layers(udet_plan* plan, void* workspace, void* stream);
 /* recover_net(img1, flow_masked, mask) alone (models/nets.py:45-110) on n*B samples whose inputs the caller packed into
  * "rec.imgin" ([.,.,.,4]: image, 0) and "rec.fin" ([.,.,.,4]: flow_masked(2), 1, 1-mask); writes "pred". */
 int udet_recover_forward(udet_plan* plan, int n, void* workspace, void* stream);
@@ -163,6 +201,12 @@ int udet_recover_forward(udet_plan* plan, int n, void* workspace, void* stream);
  * (models/utils/loss_utils.py:18; adversarial_learner.py:211-234) into the flat gradient buffers. */
 int udet_backward(udet_plan* plan, int which, const float* w_gen, const float* w_rec, float* g_gen, float* g_rec,
                   void* workspace, void* stream);
+/* the two passes alone: train_generator_op / train_recover_op's compute_gradients (adversarial_learner.py:224-234) */
+int udet_generator_backward(udet_plan* plan, const float* w_gen, float* g_gen, void* workspace, void* stream);
+int udet_recover_backward(udet_plan* plan, const float* w_rec, float* g_rec, void* workspace, void* stream);
+/* train_op, first half (loss_utils.py:19-21): out2 (device) = {mean over the variables of mean|g_v|, that < 1e-5 ? 1 : 0};
+ * g is the flat gradient buffer of `net` (1 or 2). */
+int udet_grad_absmean(udet_plan* plan, int net, const float* g, float* out2, void* workspace, void* stream);
 /* the rest of train_op (loss_utils.py:19-32): clip +-0.2 / escape noise (generator only), Adam apply with the
  * shared beta-power accumulators; g is overwritten with the clipped gradient. */
 int udet_apply(udet_plan* plan, int net, float* w, float* g, float* m, float* v, void* workspace, void* stream);
@@ -177,19 +221,13 @@ int udet_train_step(udet_plan* plan, int which, const float* img1, const float* 
  * forward + both backward passes over random data; every distinct convolution problem of the plan times its candidate
  * kernel configurations on `stream` and the fastest is cached process-wide (keyed by problem shape) for all later
  * launches.  Needs packed weights (udet_pack_pwc / udet_pack_trainable); overwrites g_gen / g_rec and re-zeroes the
- * activation regions of the workspace.  Optional: without it the built-in heuristics choose the configurations. */
+ * activation regions of the workspace.  Optional: without it the built-in heuristics choose the configurations.
+ * Every winner's output on the tuning data is compared with the built-in configuration's before it is cached (a
+ * configuration that differs is rejected and reported on stderr); the comparison buffers are the one temporary device
+ * allocation the library makes, freed before udet_autotune returns. */
 int udet_autotune(udet_plan* plan, const float* w_gen, const float* w_rec, float* g_gen, float* g_rec, void* workspace,
                   void* stream);
 int udet_tuned_shapes(void);
-/* tuning hook used by tools/conv_bench.py and the kernel-family tests: force (bm, bn, split-K) for every convolution launch
- * (bm bit 16: non-specialised kernel, bit 17: LDS-DMA staging, bit 18: tile-resident kernel with bm & 0xffff = tile height,
- * bit 19: self-staging LDS-DMA kernel);
- * (0,0,-1) restores.  A forced family a launch is not eligible for falls back to the built-in choice. */
-void udet_debug_force_conv(int bm, int bn, int ks);
-/* what the most recent convolution launch actually ran: family (0 plain, 1 wave-specialised, 2 LDS-DMA, 3 tile-resident, 6 self-staging LDS-DMA)
- * | tile rows << 8 | split count << 20 */
-int udet_debug_last_conv(void);
-
 /* Measurement aid (bench.py): between begin/end every convolution / warp / cost-volume launch group is
  * bracketed by HIP events on the launch stream.  out[cat*4 + {0,1,2,3}] = {groups, total ms, algorithmic
  * FLOPs, algorithmic bytes} for cat 0 conv fwd, 1 conv dgrad, 2 conv wgrad, 3 warp, 4 cost volume. */

@@ -1,0 +1,21 @@
+/* Test-only hooks of libudet.so (NOT part of the drop-in surface in udet.h): used by tools/conv_bench.py and the
+ * kernel-family tests to pin one convolution kernel family / tile / split-K mode and to ask which one ran. */
+#ifndef UDET_DEBUG_H
+#define UDET_DEBUG_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* force (bm, bn, split-K) for every convolution launch (bm bit 16: non-specialised kernel, bit 17: LDS-DMA staging,
+ * bit 18: tile-resident kernel with bm & 0xffff = tile height, bit 19: self-staging LDS-DMA kernel, bit 20: split-K summed by a
+ * second launch, bit 21: split-K summed by the last-arriving workgroup); (0,0,-1) restores.  A forced family a launch is not
+ * eligible for falls back to the built-in choice.  Process-global state: never call it from product code. */
+void udet_debug_force_conv(int bm, int bn, int ks);
+/* what the most recent convolution launch actually ran: family (0 plain, 1 wave-specialised, 2 LDS-DMA, 3 tile-resident,
+ * 6 self-staging LDS-DMA) | tile rows << 8 | split count << 20 | folded split-K << 28 */
+int udet_debug_last_conv(void);
+/* autotuner winners rejected because their output differed from the reference configuration's (0 on a healthy build) */
+int udet_tune_rejected(void);
+#ifdef __cplusplus
+}
+#endif
+#endif

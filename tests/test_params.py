@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_exports_every_declared_symbol():
     from unsupervised_detection_amd import _ffi
-    hdr = open(os.path.join(ROOT, "include", "udet.h")).read()
+    hdr = open(os.path.join(ROOT, "include", "udet.h")).read() + open(os.path.join(ROOT, "include", "udet_debug.h")).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     names = set(re.findall(r"\b(udet_[a-z0-9_]+)\s*\(", hdr))
     assert len(names) >= 25

@@ -49,6 +49,21 @@ _sig("udet_conv2d_backward_filter", c_i, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i,
 _sig("udet_conv2d_transpose4x4s2", c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_sz, c_p)
 
 
+_sig("udet_warp_cost_volume", c_i, c_p, c_p, c_p, c_f, c_p, c_p, c_i, c_i, c_i, c_i, c_p)
+_sig("udet_stage_workspace_bytes", c_sz, c_i)
+_sig("udet_flow_normalize", c_i, c_p, c_p, c_i, c_i, c_i, c_p, c_sz, c_p)
+_sig("udet_charbonnier_loss", c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_sz, c_p)
+_sig("udet_losses_forward", c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_f, c_f, c_p, c_p, c_p, c_sz, c_p)
+_sig("udet_losses_backward", c_i, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p, c_p)
+_sig("udet_clip_or_noise", c_i, c_p, c_sz, c_f, c_p, ctypes.c_ulonglong, ctypes.c_long, c_p)
+_sig("udet_adam_step", c_i, c_p, c_p, c_p, c_p, c_sz, c_f, c_f, c_f, c_f, ctypes.c_long, c_p)
+_sig("udet_generator_layers", c_i, c_p, c_p, c_p)
+_sig("udet_generator_backward", c_i, c_p, c_p, c_p, c_p, c_p)
+_sig("udet_recover_backward", c_i, c_p, c_p, c_p, c_p, c_p)
+_sig("udet_grad_absmean", c_i, c_p, c_i, c_p, c_p, c_p, c_p)
+_sig("udet_tune_rejected", c_i)
+
+
 class UdetError(RuntimeError):
     pass
 

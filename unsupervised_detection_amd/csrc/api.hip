@@ -1,8 +1,10 @@
 // extern "C" surface of libudet.so (see include/udet.h).
+#include <math.h>
 #include <stdarg.h>
 #include <string.h>
 
 #include "../../include/udet.h"
+#include "../../include/udet_debug.h"
 #include "common.h"
 #include "conv_host.h"
 #include "elementwise.h"
@@ -88,7 +90,7 @@ size_t udet_conv2d_workspace_bytes(int n, int h, int w, int cin, int cout, int k
   b += 2 * gran(pix_out * round_up(cout, 8));                    // channel-padded dy / y_saved
   b += gran(SPLITK_FLOATS);                                      // split-K partials
   b += gran(64 * wgrad_partial_floats_needed(kh * kw, cin, cout));
-  return b + 8192;
+  return b + 8192 + gran(64 + UDET_MAX_TICKETS);
 }
 
 int udet_conv2d(const float* x, const float* w_hwio, const float* bias, float* y, int n, int h, int w, int cin, int cout,
@@ -113,9 +115,9 @@ int udet_conv2d(const float* x, const float* w_hwio, const float* bias, float* y
     ldx = kc;
   }
   float* part = ar.take(SPLITK_FLOATS);
-  float* zero = ar.take(64);
+  float* zero = ar.take(64 + UDET_MAX_TICKETS);  // 16-byte zero block + split-K tickets
   if (!wp || !part || !zero) { set_error("conv2d: workspace too small"); return UDET_ERR_ARG; }
-  UDET_HIP(hipMemsetAsync(zero, 0, 64 * sizeof(float), stream));
+  UDET_HIP(hipMemsetAsync(zero, 0, (64 + UDET_MAX_TICKETS) * sizeof(float), stream));
   UDET_TRY(launch_pack_weights(w_hwio, wp, kh * kw, cin, cout, kc, ldw, kc, 0, 0, nullptr, stream));
   ConvParams p;
   memset(&p, 0, sizeof(p));
@@ -127,6 +129,7 @@ int udet_conv2d(const float* x, const float* w_hwio, const float* bias, float* y
   p.act = act; p.alpha = alpha;
   p.partial = part; p.partial_cap = SPLITK_FLOATS;
   p.zero16 = zero;
+  p.tickets = reinterpret_cast<int*>(zero + 64);
   return launch_conv(p, stream);
 }
 
@@ -147,9 +150,9 @@ int udet_conv2d_transpose4x4s2(const float* x, const float* w_hwoi, const float*
     ldx = kc;
   }
   float* part = ar.take(SPLITK_FLOATS);
-  float* zero = ar.take(64);
+  float* zero = ar.take(64 + UDET_MAX_TICKETS);  // 16-byte zero block + split-K tickets
   if (!wp || !part || !zero) { set_error("conv2d_transpose: workspace too small"); return UDET_ERR_ARG; }
-  UDET_HIP(hipMemsetAsync(zero, 0, 64 * sizeof(float), stream));
+  UDET_HIP(hipMemsetAsync(zero, 0, (64 + UDET_MAX_TICKETS) * sizeof(float), stream));
   // w is [t][cout][cin]; B operand wants [t][k=cin][n=cout]  -> mode 1 with (R=cout, C=cin)
   UDET_TRY(launch_pack_weights(w_hwoi, wp, 16, cout, cin, kc, ldw, kc, 0, 1, nullptr, stream));
   for (int cls = 0; cls < conv_dgrad_classes(2, 2 * h, 2 * w); ++cls) {
@@ -160,6 +163,7 @@ int udet_conv2d_transpose4x4s2(const float* x, const float* w_hwoi, const float*
     p.y = y; p.ldy = cout; p.Cout = cout;
     p.partial = part; p.partial_cap = SPLITK_FLOATS;
     p.zero16 = zero;
+    p.tickets = reinterpret_cast<int*>(zero + 64);
     UDET_TRY(launch_conv(p, stream));
   }
   return UDET_OK;
@@ -194,9 +198,9 @@ int udet_conv2d_backward_data(const float* dy, const float* y_saved, const float
     ldy = kc;
   }
   float* part = ar.take(SPLITK_FLOATS);
-  float* zero = ar.take(64);
+  float* zero = ar.take(64 + UDET_MAX_TICKETS);  // 16-byte zero block + split-K tickets
   if (!wp || !part || !zero) { set_error("conv2d_backward_data: workspace too small"); return UDET_ERR_ARG; }
-  UDET_HIP(hipMemsetAsync(zero, 0, 64 * sizeof(float), stream));
+  UDET_HIP(hipMemsetAsync(zero, 0, (64 + UDET_MAX_TICKETS) * sizeof(float), stream));
   UDET_TRY(launch_pack_weights(w_hwio, wp, kh * kw, cin, cout, kc, ldw, kc, 0, 1, nullptr, stream));
   for (int cls = 0; cls < conv_dgrad_classes(stride, h, w); ++cls) {
     ConvParams p;
@@ -207,6 +211,7 @@ int udet_conv2d_backward_data(const float* dy, const float* y_saved, const float
     p.y = dx; p.ldy = cin; p.Cout = cin;
     p.partial = part; p.partial_cap = SPLITK_FLOATS;
     p.zero16 = zero;
+    p.tickets = reinterpret_cast<int*>(zero + 64);
     UDET_TRY(launch_conv(p, stream));
   }
   return UDET_OK;
@@ -269,6 +274,66 @@ int udet_conv2d_backward_filter(const float* x, const float* dy, const float* y_
   p.dw = dw_hwio; p.db = dbias; p.partial = part; p.partial_floats = takef;
   p.zero16 = zero;
   return launch_wgrad_T(p, kh * kw, stream);
+}
+
+/* ---- per-stage entry points of the loss / optimizer tail (SURVEY 8b minimum export list) ---------------------------- */
+int udet_flow_normalize(const float* flow, float* out, int n, int h, int w, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!flow || !out || n < 1 || h < 1 || w < 1) { set_error("flow_normalize: bad argument"); return UDET_ERR_ARG; }
+  if (!workspace || workspace_bytes < flow_stats_doubles(n) * sizeof(double) || (reinterpret_cast<uintptr_t>(workspace) & 7)) {
+    set_error("flow_normalize: workspace needs %zu bytes, 8-byte aligned", flow_stats_doubles(n) * sizeof(double));
+    return UDET_ERR_ARG;
+  }
+  return launch_flow_normalize(flow, (double*)workspace, out, n, (long)h * w, (hipStream_t)stream);
+}
+size_t udet_stage_workspace_bytes(int n) {
+  const size_t a = flow_stats_doubles(n) * sizeof(double), b = (loss_part_floats(n) + 5 * (size_t)n + 64) * sizeof(float);
+  return (a > b ? a : b) + 256;
+}
+int udet_charbonnier_loss(const float* gt_flows, const float* pred_flows, const float* masks, int mask_channels, int n, int h, int w,
+                          float cbn, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!gt_flows || !pred_flows || !out || n < 1 || h < 1 || w < 1 || (masks && mask_channels != 1 && mask_channels != 2)) {
+    set_error("charbonnier_loss: bad argument (masks: null, 1 or 2 channels)");
+    return UDET_ERR_ARG;
+  }
+  if (!workspace || workspace_bytes < udet_stage_workspace_bytes(n)) { set_error("charbonnier_loss: workspace too small"); return UDET_ERR_ARG; }
+  return launch_charbonnier(gt_flows, pred_flows, masks, masks ? mask_channels : 1, n, (long)h * w, cbn, (float*)workspace, out, (hipStream_t)stream);
+}
+int udet_losses_forward(const float* flow, const float* mask, const float* pred3, int b, int h, int w, float cbn, float epsilon,
+                        float* losses8, float* coef, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!flow || !mask || !pred3 || !losses8 || !coef || b < 1 || h < 1 || w < 1) { set_error("losses_forward: bad argument"); return UDET_ERR_ARG; }
+  if (!workspace || workspace_bytes < udet_stage_workspace_bytes(b)) { set_error("losses_forward: workspace too small"); return UDET_ERR_ARG; }
+  float* part = (float*)workspace;
+  float* sums = part + loss_part_floats(b);
+  return launch_losses(flow, mask, pred3, (long)h * w, b, cbn, epsilon, (float)w * (float)h * (float)b, part, losses8, coef, sums,
+                       (hipStream_t)stream);
+}
+int udet_losses_backward(const float* flow, const float* mask, const float* pred3, const float* coef, int which, int b, int h, int w,
+                         float cbn, float* dpred, float* dmask, void* stream) {
+  if (!flow || !mask || !pred3 || !dpred || b < 1 || h < 1 || w < 1) { set_error("losses_backward: bad argument"); return UDET_ERR_ARG; }
+  const long HW = (long)h * w;
+  if (which == 2) return launch_rec_loss_bwd(flow, mask, pred3, dpred, (long)b * HW, cbn, 1.0f / ((float)w * (float)h * (float)b), (hipStream_t)stream);
+  if (which == 1) {
+    if (!coef || !dmask) { set_error("losses_backward: the generator loss needs coef (udet_losses_forward) and dmask"); return UDET_ERR_ARG; }
+    return launch_gen_loss_bwd(flow, mask, pred3, coef, dpred, dmask, HW, b, cbn, (hipStream_t)stream);
+  }
+  set_error("losses_backward: which must be 1 (generator loss) or 2 (recover loss)");
+  return UDET_ERR_ARG;
+}
+int udet_clip_or_noise(float* g, size_t n, float clip, const float* flag2, unsigned long long seed, long step, void* stream) {
+  if (!g) { set_error("clip_or_noise: null gradient"); return UDET_ERR_ARG; }
+  return launch_adam(nullptr, g, nullptr, nullptr, (long)n, 0.f, 0.f, 0.f, 0.f, clip, flag2, seed, (uint64_t)step, (hipStream_t)stream, 1);
+}
+int udet_adam_step(float* w, const float* g, float* m, float* v, size_t n, float lr, float beta1, float beta2, float eps, long t,
+                   void* stream) {
+  if (!w || !g || !m || !v || t < 1) { set_error("adam_step: bad argument (t counts applies from 1)"); return UDET_ERR_ARG; }
+  const double lr_t = (double)lr * sqrt(1.0 - pow((double)beta2, (double)t)) / (1.0 - pow((double)beta1, (double)t));
+  return launch_adam(w, const_cast<float*>(g), m, v, (long)n, (float)lr_t, beta1, beta2, eps, 0.f, nullptr, 0, 0, (hipStream_t)stream, 2);
+}
+/* fused warp -> cost volume of one pyramid level (what the step plan launches); corr [n,h,w,81]; warped_dbg optional [n,h,w,c] */
+int udet_warp_cost_volume(const float* c1, const float* c2, const float* flow, float flow_scale, float* corr, float* warped_dbg, int n,
+                          int h, int w, int c, void* stream) {
+  if (!c1 || !c2 || !corr) { set_error("warp_cost_volume: null argument"); return UDET_ERR_ARG; }
+  return launch_warp_cost_volume(c1, c2, flow, 2, 0, flow_scale, corr, 81, 0, -1, warped_dbg, n, h, w, c, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -69,6 +69,11 @@ int udet_generator_forward(udet_plan* h, void* ws, void* stream) {
   UDET_TRY(plan_generator_forward(h->p, (float*)ws, (hipStream_t)stream));
   return plan_recover_forward(h->p, 0, (float*)ws, (hipStream_t)stream);  // ncalls=0: only the mask is produced
 }
+int udet_generator_layers(udet_plan* h, void* ws, void* stream) {
+  h->p->ev_next = 0;
+  UDET_TRY(plan_generator_layers(h->p, (float*)ws, (hipStream_t)stream));
+  return plan_recover_forward(h->p, 0, (float*)ws, (hipStream_t)stream);  // ncalls=0: only the mask is produced
+}
 int udet_recover_forward(udet_plan* h, int n, void* ws, void* stream) {
   if (n < 1 || n > 3) { set_error("recover_forward: n must be 1..3 (multiples of the plan batch)"); return UDET_ERR_ARG; }
   return plan_recover_forward(h->p, n, (float*)ws, (hipStream_t)stream, true);
@@ -167,5 +172,25 @@ int udet_profile_end(udet_plan* h, double* out, int ncat, void* stream) {
   P->prof.clear();
   return UDET_OK;
 }
+
+/* the two train ops' gradient passes alone (adversarial_learner.py:224-234) */
+int udet_generator_backward(udet_plan* h, const float* w_gen, float* g_gen, void* ws, void* stream) {
+  if (!w_gen || !g_gen) { set_error("generator_backward: null argument"); return UDET_ERR_ARG; }
+  return plan_backward(h->p, 1, w_gen, nullptr, g_gen, nullptr, (float*)ws, (hipStream_t)stream);
+}
+int udet_recover_backward(udet_plan* h, const float* w_rec, float* g_rec, void* ws, void* stream) {
+  if (!w_rec || !g_rec) { set_error("recover_backward: null argument"); return UDET_ERR_ARG; }
+  return plan_backward(h->p, 2, nullptr, w_rec, nullptr, g_rec, (float*)ws, (hipStream_t)stream);
+}
+/* loss_utils.py:19-21: out2 = {mean over the variables of mean|g_v|, (that < 1e-5) ? 1 : 0} */
+int udet_grad_absmean(udet_plan* h, int net, const float* g, float* out2, void* ws_, void* stream) {
+  if ((net != NET_GEN && net != NET_REC) || !g || !out2) { set_error("grad_absmean: net must be 1 or 2, g / out2 non-null"); return UDET_ERR_ARG; }
+  Plan* P = h->p;
+  float* ws = (float*)ws_;
+  const NetParams& np = net_params(net);
+  const long* tab = reinterpret_cast<const long*>(ws + P->seg_off[net]);
+  return launch_grad_absmean(g, tab, tab + np.p.size(), (int)np.p.size(), ws + P->small_off + 2048, 1e-5f, out2, (hipStream_t)stream);
+}
+int udet_tune_rejected(void) { return conv_tune_rejected(); }
 
 }  // extern "C"

@@ -99,7 +99,6 @@ struct ConvParams {
   int cls_tap[5];
   FastDiv fd_ohw, fd_ow;  // filled by launch_conv
   const float* zero16;    // >= 16 bytes of zeros in device memory (source of halo / tail lanes of the LDS-DMA kernel); may be null
-  int dbg;                // ablation switches for tuning runs (env UDET_DBG; results are wrong when set)
   // epilogue
   int act;
   float alpha;
@@ -121,7 +120,12 @@ struct ConvParams {
   float* partial;  // [ksplit][Mtot][ldp]
   size_t partial_cap;  // capacity of `partial` in floats
   int ldp;
+  // fold != 0: the workgroup that draws an output tile's last ticket sums the slabs and runs the epilogue (no second launch).
+  // tickets: >= UDET_MAX_TICKETS zero-initialised ints private to the launch stream (self-resetting); null disables folding.
+  int fold;
+  int* tickets;
 };
+#define UDET_MAX_TICKETS 4096
 
 int launch_conv(ConvParams& p, hipStream_t stream);
 // y[n, oy, ox, y_coff+co] = bias[co] + sum_{taps t of the pixel's parity class} Z[n, qy+dy_t, qx+dx_t, widx_t*Cout+co]

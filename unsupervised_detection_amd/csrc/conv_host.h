@@ -9,6 +9,11 @@ int conv_last_config();
 void conv_set_tuning(int on);   // autotuner: while on, unseen problem shapes are timed and the best configuration cached
 int conv_tuned_shapes();
 void conv_clear_tuning();
+int conv_tune_rejected();      // winners whose output differed from the reference configuration's (never cached)
+void conv_tune_note_reject();
+// tuning-time scratch (two device buffers of `floats` each, alive while tuning is on) and the max-abs comparison the tuners use
+float* tune_scratch(size_t floats, int which);
+bool tune_compare(const float* a, const float* b, size_t n, hipStream_t stream, float* diff_out, float* scale_out);
 void wgrad_set_tuning(int on);
 int wgrad_tuned_shapes();  // debugging / tuning hook: bm == 0 and ks < 0 restore the heuristics
 bool conv_setup_dgrad(ConvParams& p, int cls, int N, int H, int W, int kh, int kw, int s, int d);
@@ -25,5 +30,8 @@ int launch_warp(const float* img, const float* flow, int ldf, int f_coff, float 
                 int W, int C, int* dbg_idx, float* dbg_alpha, hipStream_t stream);
 int launch_cost_volume(const float* c1, const float* wr, float* out, int ldo, int o_coff, int N, int H, int W, int C,
                        hipStream_t stream);
+// fused warp -> cost volume -> slab (flow == null: no warp, level 6; c1_coff < 0: no c1 segment; warped_dbg: optional [N,H,W,C])
+int launch_warp_cost_volume(const float* c1, const float* c2, const float* flow, int ldf, int f_coff, float flow_scale, float* out,
+                            int ldo, int corr_coff, int c1_coff, float* warped_dbg, int N, int H, int W, int C, hipStream_t stream);
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 }  // namespace udet

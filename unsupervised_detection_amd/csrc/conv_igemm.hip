@@ -39,15 +39,10 @@ struct KCursor {
 struct KOrder {
   int Kc, CB, nblk, wl, ntc;
 };
-__device__ __forceinline__ KOrder korder(int Kc, int ntc, int dbg = 0) {
+__device__ __forceinline__ KOrder korder(int Kc, int ntc) {
   KOrder o;
   o.Kc = Kc; o.ntc = ntc;
-  int cb = 32;
-  if (dbg & 16) cb = Kc;
-  if (dbg & 32) cb = 64;
-  if (dbg & 64) cb = 128;
-  if (dbg & 128) cb = 256;
-  o.CB = Kc < cb ? Kc : cb;
+  o.CB = Kc < 32 ? Kc : 32;
   o.nblk = (Kc + o.CB - 1) / o.CB;
   o.wl = Kc - (o.nblk - 1) * o.CB;
   return o;
@@ -103,6 +98,79 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, int off, int 
     p.uo[(size_t)off * p.ldu + p.u_coff + n] = v * act_dfo(p.ua[(size_t)off * p.ldua + p.ua_coff + n], p.uact, p.ualpha);
 }
 
+// Result of one workgroup: plain launches run the epilogue; split-K launches store the partial tile into slab blockIdx.z
+// (row index = parity class * Mtot + pixel).
+template <int TM, int TN, int WTM, int WTN>
+__device__ __forceinline__ void igemm_store(const ConvParams& p, floatx16 (&acc)[TM][TN], const int* rowoff, int wm, int wn, int li,
+                                            int lh, int n0, int prow0, int Mtot) {
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int off = rowoff[row];
+      if (off < 0) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * WTN + j * 32 + li;
+        const float v = acc[i][j][r];
+        if (p.ksplit > 1) {
+          if (n < p.ldp) p.partial[((size_t)blockIdx.z * p.ncls * Mtot + prow0 + row) * p.ldp + n] = v;
+          continue;
+        }
+        if (n >= p.Cout) continue;
+        conv_epilogue(p, off, n, v);
+      }
+    }
+  }
+}
+
+// Split-K without a second launch: after storing its partial tile every workgroup of an output tile draws a ticket; the one
+// that draws the last sums the slabs IN SPLIT ORDER (the result does not depend on which workgroup arrives last) and runs the
+// epilogue, then resets the ticket for the next launch on this stream.  Called by the NT threads [0, NT) of the workgroup
+// that are still alive (the staging waves of the wave-specialised kernels have exited: s_barrier counts surviving waves only).
+template <int BM, int BN, int NT>
+__device__ __forceinline__ void splitk_fold(const ConvParams& p, const int* rowoff, int* s_last, int t, int n0, int prow0, int Mtot,
+                                            int tile_id) {
+  __threadfence();  // release: this thread's partial stores are visible device-wide before the ticket is drawn
+  __syncthreads();
+  if (t == 0) *s_last = atomicAdd(p.tickets + tile_id, 1) == p.ksplit - 1;
+  __syncthreads();
+  if (!*s_last) return;
+  __threadfence();  // acquire: the other workgroups' slabs (written through other XCDs' L2) are read from memory
+  constexpr int C4 = BN / 4, ROWS = NT / C4;
+  const int c4 = t % C4, n = n0 + c4 * 4;
+  const size_t slab = (size_t)p.ncls * Mtot * p.ldp;
+  if (n < p.ldp) {
+    for (int row = t / C4; row < BM; row += ROWS) {
+      const int off = rowoff[row];
+      if (off < 0) continue;
+      const float* src = p.partial + (size_t)(prow0 + row) * p.ldp + n;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      int s = 0;
+      for (; s + 3 < p.ksplit; s += 4) {  // four slabs in flight, added in split order
+        const float4 a0 = *reinterpret_cast<const float4*>(src + (size_t)s * slab);
+        const float4 a1 = *reinterpret_cast<const float4*>(src + (size_t)(s + 1) * slab);
+        const float4 a2 = *reinterpret_cast<const float4*>(src + (size_t)(s + 2) * slab);
+        const float4 a3 = *reinterpret_cast<const float4*>(src + (size_t)(s + 3) * slab);
+        v.x += a0.x; v.y += a0.y; v.z += a0.z; v.w += a0.w;
+        v.x += a1.x; v.y += a1.y; v.z += a1.z; v.w += a1.w;
+        v.x += a2.x; v.y += a2.y; v.z += a2.z; v.w += a2.w;
+        v.x += a3.x; v.y += a3.y; v.z += a3.z; v.w += a3.w;
+      }
+      for (; s < p.ksplit; ++s) {
+        const float4 a0 = *reinterpret_cast<const float4*>(src + (size_t)s * slab);
+        v.x += a0.x; v.y += a0.y; v.z += a0.z; v.w += a0.w;
+      }
+      if (n < p.Cout) conv_epilogue(p, off, n, v.x);
+      if (n + 1 < p.Cout) conv_epilogue(p, off, n + 1, v.y);
+      if (n + 2 < p.Cout) conv_epilogue(p, off, n + 2, v.z);
+      if (n + 3 < p.Cout) conv_epilogue(p, off, n + 3, v.w);
+    }
+  }
+  if (t == 0) p.tickets[tile_id] = 0;
+}
+
 // WS (wave specialisation): 512-thread workgroups; waves 0-3 only read fragments from LDS and issue MFMAs, waves
 // 4-7 only stage (global -> registers -> LDS) one stage ahead.  The matrix pipe of a SIMD is then fed by waves that
 // never wait on HBM/L2 or on address arithmetic; one raw s_barrier per stage hands the buffers over.
@@ -127,6 +195,7 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 2) void conv_igemm_kernel(
   __shared__ int rowoff[BM];
   __shared__ int2 tap_yx[UDET_MAX_TAPS];
   __shared__ int tap_w[UDET_MAX_TAPS];
+  __shared__ int s_last;
 
   const int tid = threadIdx.x;
   const int role = __builtin_amdgcn_readfirstlane(tid >> 8);  // WS: 0 = MFMA waves, 1 = staging waves
@@ -163,7 +232,7 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 2) void conv_igemm_kernel(
     if (m < Mtot) {
       const int n = (int)fdiv(m, p.fd_ohw), rem = m - n * OHWq;
       const int qy = (int)fdiv(rem, p.fd_ow), qx = rem - qy * p.OWq;
-      off = p.ksplit > 1 ? cls * Mtot + m : (n * p.OH + qy * p.osy + ooy) * p.OW + qx * p.osx + oox;
+      off = (n * p.OH + qy * p.osy + ooy) * p.OW + qx * p.osx + oox;
     }
     rowoff[r] = off;
   }
@@ -202,7 +271,7 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 2) void conv_igemm_kernel(
     c_end = (int)((long)nchunks * (blockIdx.z + 1) / p.ksplit);
   }
   // flat-K cursors of this thread's A float4 and of its B rows; advanced by BK per stage
-  const KOrder ko = korder(Kc, ntc, p.dbg);
+  const KOrder ko = korder(Kc, ntc);
   KCursor ka = kc_init(ko, c_begin * BK + a_kq * 4), kb[B_LD];
 #pragma unroll
   for (int j = 0; j < B_LD; ++j) kb[j] = kc_init(ko, c_begin * BK + (t + j * 256) / B_F4_ROW);
@@ -223,7 +292,7 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 2) void conv_igemm_kernel(
       int iy = a_iy0[j] + dy, ix = a_ix0[j] + dx;
       const bool ok = a_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ok && !(p.dbg & 1)) {
+      if (ok) {
         iy >>= p.up_shift;
         ix >>= p.up_shift;
         const size_t off = (size_t)(a_base[j] + iy * Ws + ix) * p.ldx + p.x_coff + a_c;
@@ -243,7 +312,7 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 2) void conv_igemm_kernel(
       const int c4 = (t + j * 256) % B_F4_ROW;
       const int n = n0 + c4 * 4;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (kc_valid(ko, kb[j]) && n < p.ldw && !(p.dbg & 1))
+      if (kc_valid(ko, kb[j]) && n < p.ldw)
         v = *reinterpret_cast<const float4*>(p.wp + ((size_t)tap_w[kb[j].tap] * Kc + kc_chan(ko, kb[j])) * p.ldw + n);
       rb[j] = v;
     }
@@ -253,7 +322,6 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 2) void conv_igemm_kernel(
     for (int j = 0; j < B_LD; ++j) kc_advance(ko, kb[j], BK);
   };
   auto store_chunk = [&](int buf) {
-    if (p.dbg & 2) return;
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
       const int r = t / KQ + j * A_ROWS;
@@ -298,7 +366,6 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 2) void conv_igemm_kernel(
   if constexpr (WS) {
     // raw barriers: only LDS traffic is drained (lgkmcnt), global loads stay in flight across the hand-over
     auto handover = [&]() {
-      if (p.dbg & 8) return;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     };
@@ -345,26 +412,8 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 2) void conv_igemm_kernel(
   }
 
   // ---- epilogue -------------------------------------------------------------
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const int off = rowoff[row];
-      if (off < 0) continue;
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * WTN + j * 32 + li;
-        float v = acc[i][j][r];
-        if (p.ksplit > 1) {
-          if (n < p.ldp) p.partial[((size_t)blockIdx.z * p.ncls * Mtot + off) * p.ldp + n] = v;
-          continue;
-        }
-        if (n >= p.Cout) continue;
-        conv_epilogue(p, off, n, v);
-      }
-    }
-  }
+  igemm_store<TM, TN, WTM, WTN>(p, acc, rowoff, wm, wn, li, lh, n0, cls * Mtot + m0, Mtot);
+  if (p.ksplit > 1 && p.fold) splitk_fold<BM, BN, 256>(p, rowoff, &s_last, t, n0, cls * Mtot + m0, Mtot, blockIdx.y * gridDim.x + bid);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -394,6 +443,7 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_dma_kernel(const ConvParams
   __shared__ int rowoff[BM];
   __shared__ int2 tap_yx[UDET_MAX_TAPS];
   __shared__ int tap_w[UDET_MAX_TAPS];
+  __shared__ int s_last;
 
   const int tid = threadIdx.x;
   const int role = __builtin_amdgcn_readfirstlane(tid >> 8);  // 0 = MFMA waves, 1 = staging waves
@@ -428,7 +478,7 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_dma_kernel(const ConvParams
     if (m < Mtot) {
       const int n = (int)fdiv(m, p.fd_ohw), rem = m - n * OHWq;
       const int qy = (int)fdiv(rem, p.fd_ow), qx = rem - qy * p.OWq;
-      off = p.ksplit > 1 ? cls * Mtot + m : (n * p.OH + qy * p.osy + ooy) * p.OW + qx * p.osx + oox;
+      off = (n * p.OH + qy * p.osy + ooy) * p.OW + qx * p.osx + oox;
     }
     rowoff[r] = off;
   }
@@ -461,7 +511,7 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_dma_kernel(const ConvParams
         a_ix0[j] = 0;
       }
     }
-    const KOrder ko = korder(Kc, ntc, p.dbg);
+    const KOrder ko = korder(Kc, ntc);
     KCursor ka = kc_init(ko, c_begin * BK + kqs * 4), kb[B_LD];
 #pragma unroll
     for (int j = 0; j < B_LD; ++j) kb[j] = kc_init(ko, c_begin * BK + (t + j * 256) / B_F4_ROW);
@@ -564,26 +614,8 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_dma_kernel(const ConvParams
       buf ^= 1;
     }
   }
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const int off = rowoff[row];
-      if (off < 0) continue;
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * WTN + j * 32 + li;
-        float v = acc[i][j][r];
-        if (p.ksplit > 1) {
-          if (n < p.ldp) p.partial[((size_t)blockIdx.z * p.ncls * Mtot + off) * p.ldp + n] = v;
-          continue;
-        }
-        if (n >= p.Cout) continue;
-        conv_epilogue(p, off, n, v);
-      }
-    }
-  }
+  igemm_store<TM, TN, WTM, WTN>(p, acc, rowoff, wm, wn, li, lh, n0, cls * Mtot + m0, Mtot);
+  if (p.ksplit > 1 && p.fold) splitk_fold<BM, BN, 256>(p, rowoff, &s_last, t, n0, cls * Mtot + m0, Mtot, blockIdx.y * gridDim.x + bid);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -614,6 +646,7 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_dma4_kernel(const ConvParam
   __shared__ int rowoff[BM];
   __shared__ int2 tap_yx[UDET_MAX_TAPS];
   __shared__ int tap_w[UDET_MAX_TAPS];
+  __shared__ int s_last;
 
   const int t = threadIdx.x;
   const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -646,7 +679,7 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_dma4_kernel(const ConvParam
     if (m < Mtot) {
       const int n = (int)fdiv(m, p.fd_ohw), rem = m - n * OHWq;
       const int qy = (int)fdiv(rem, p.fd_ow), qx = rem - qy * p.OWq;
-      off = p.ksplit > 1 ? cls * Mtot + m : (n * p.OH + qy * p.osy + ooy) * p.OW + qx * p.osx + oox;
+      off = (n * p.OH + qy * p.osy + ooy) * p.OW + qx * p.osx + oox;
     }
     rowoff[r] = off;
   }
@@ -678,7 +711,7 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_dma4_kernel(const ConvParam
       a_ix0[j] = 0;
     }
   }
-  const KOrder ko = korder(Kc, ntc, p.dbg);
+  const KOrder ko = korder(Kc, ntc);
   KCursor ka = kc_init(ko, c_begin * BK + kqs * 4), kb[B_LD];
 #pragma unroll
   for (int j = 0; j < B_LD; ++j) kb[j] = kc_init(ko, c_begin * BK + (t + j * 256) / B_F4_ROW);
@@ -771,26 +804,8 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_dma4_kernel(const ConvParam
       buf ^= 1;
     }
   }
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const int off = rowoff[row];
-      if (off < 0) continue;
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * WTN + j * 32 + li;
-        float v = acc[i][j][r];
-        if (p.ksplit > 1) {
-          if (n < p.ldp) p.partial[((size_t)blockIdx.z * p.ncls * Mtot + off) * p.ldp + n] = v;
-          continue;
-        }
-        if (n >= p.Cout) continue;
-        conv_epilogue(p, off, n, v);
-      }
-    }
-  }
+  igemm_store<TM, TN, WTM, WTN>(p, acc, rowoff, wm, wn, li, lh, n0, cls * Mtot + m0, Mtot);
+  if (p.ksplit > 1 && p.fold) splitk_fold<BM, BN, 256>(p, rowoff, &s_last, t, n0, cls * Mtot + m0, Mtot, blockIdx.y * gridDim.x + bid);
 }
 
 // second pass of a split-K launch: sum the partial slabs and run the epilogue.  SL lanes share one output element
@@ -831,12 +846,14 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const ConvPar
   }
 }
 
-static int g_force_bm = 0, g_force_bn = 0, g_force_ks = -1, g_force_ws = -1;
+static int g_force_bm = 0, g_force_bn = 0, g_force_ks = -1, g_force_ws = -1, g_force_fold = -1;
 static int g_last_cfg = 0;  // kernel family / tile / split count of the most recent launch_conv (debug query)
 int conv_last_config() { return g_last_cfg; }
 void conv_force_config(int bm, int bn, int ks) {
   g_force_bm = bm & 0xffff; g_force_bn = bn; g_force_ks = ks;
-  // bit 16: non-specialised, 17: LDS-DMA (wave-specialised), 18: tile kernel, 19: self-staging LDS-DMA (4 waves, BK 16)
+  // bit 16: non-specialised, 17: LDS-DMA (wave-specialised), 18: tile kernel, 19: self-staging LDS-DMA (4 waves, BK 16);
+  // bit 20: split-K through the second launch, bit 21: split-K folded into the last-arriving workgroup
+  g_force_fold = (bm >> 20) & 1 ? 0 : ((bm >> 21) & 1 ? 1 : -1);
   g_force_ws = (bm >> 16) & 1 ? 0 : ((bm >> 17) & 1 ? 2 : ((bm >> 18) & 1 ? 3 : ((bm >> 19) & 1 ? 6 : -1)));
 }
 
@@ -858,7 +875,7 @@ static int launch_cfg(const ConvParams& p, int ws, hipStream_t stream) {
   else if (ws) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, true>), grid, dim3(512), 0, stream, p);
   else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, false>), grid, dim3(256), 0, stream, p);
   UDET_HIP(hipGetLastError());
-  if (p.ksplit > 1) {
+  if (p.ksplit > 1 && !p.fold) {
     const long total = (long)p.ncls * Mtot * p.Cout;
     // lanes per element: keep >= ~64k threads busy while the split count allows it
     const int sl = (p.ksplit >= 16 && total * 16 <= 262144) ? 16 : ((p.ksplit >= 4 && total * 4 <= 262144) ? 4 : 1);
@@ -873,7 +890,7 @@ static int launch_cfg(const ConvParams& p, int ws, hipStream_t stream) {
 }
 
 // ---- tile / split-K selection ---------------------------------------------------------------
-struct ConvCfg { int bm, bn, ks, ws; };
+struct ConvCfg { int bm, bn, ks, ws, fold; };  // fold: split-K summed by the last-arriving workgroup (no second launch)
 static long cfg_tiles(const ConvParams& p, int bm, int bn) {
   const int Mtot = p.N * p.OHq * p.OWq;
   return (long)p.ncls * ((Mtot + bm - 1) / bm) * ((p.Cout + bn - 1) / bn);
@@ -905,7 +922,7 @@ static bool dma_ok(const ConvParams& p) { return p.xa == nullptr && p.zero16 != 
 static ConvCfg heuristic_cfg(const ConvParams& p) {
   // N tile from the channel count; M tile shrunk while the launch would leave CUs without a workgroup
   ConvCfg c;
-  c.ws = 1;
+  c.ws = 1; c.fold = 0;
   if (p.Cout <= 32) { c.bn = 32; c.bm = 256; if (cfg_tiles(p, 256, 32) < 384) c.bm = 128; }
   else if (p.Cout <= 64) { c.bn = 64; c.bm = 128; if (cfg_tiles(p, 128, 64) < 384) c.bm = 64; }
   else if (p.Cout <= 96) { c.bn = 96; c.bm = 128; }
@@ -917,15 +934,21 @@ static ConvCfg heuristic_cfg(const ConvParams& p) {
     const int cap = max_ksplit(p), half = cap / 2 > 0 ? cap / 2 : 1;  // keep >= 4 stages per split
     c.ks = ks > half ? half : ks;
   }
+  c.fold = c.ks <= 16;  // the last-arriving workgroup sums the slabs alone: beyond ~16 slabs the chip-wide second pass is faster
   return c;
 }
 static int run_cfg(ConvParams& p, const ConvCfg& c, hipStream_t stream) {
   if (c.ws == 3) {  // tile-resident direct convolution (conv_tile.hip); bm carries the tile height
     p.ksplit = 1;
+    p.fold = 0;
     return launch_conv_tile(p, c.bm, stream);
   }
   p.ksplit = c.ks > 1 ? c.ks : 1;
-  if (p.ksplit > 1) p.ldp = (p.Cout + 3) & ~3;
+  p.fold = 0;
+  if (p.ksplit > 1) {
+    p.ldp = (p.Cout + 3) & ~3;
+    p.fold = c.fold && p.tickets && cfg_tiles(p, c.bm, c.bn) <= UDET_MAX_TICKETS;
+  }
   if (c.bm == 256 && c.bn == 32) return launch_cfg<256, 32, 32, 4, 1>(p, c.ws, stream);
   if (c.bm == 128 && c.bn == 32) return launch_cfg<128, 32, 32, 4, 1>(p, c.ws, stream);
   if (c.bm == 128 && c.bn == 64) return launch_cfg<128, 64, 32, 2, 2>(p, c.ws, stream);
@@ -941,9 +964,64 @@ static int run_cfg(ConvParams& p, const ConvCfg& c, hipStream_t stream) {
 static std::unordered_map<uint64_t, ConvCfg> g_cache;
 static std::mutex g_cache_mu;
 static int g_tuning = 0;
-void conv_set_tuning(int on) { g_tuning = on; }
+static void tune_scratch_free();
+void conv_set_tuning(int on) { g_tuning = on; if (!on) tune_scratch_free(); }
 int conv_tuned_shapes() { std::lock_guard<std::mutex> l(g_cache_mu); return (int)g_cache.size(); }
 void conv_clear_tuning() { std::lock_guard<std::mutex> l(g_cache_mu); g_cache.clear(); }
+
+// ---- candidate verification -------------------------------------------------------------------------------------------
+// The tuner selects on time; a configuration that is fast because it computes something else must never be cached.  Before
+// a winner is stored its output on the tuning data is compared (max-abs, relative to the largest reference element) with the
+// output of the reference configuration (built-in heuristic, register-staged wave-specialised kernel).  The two result
+// buffers are temporary device allocations that live only while tuning is on (the one place where the library allocates).
+static float* g_vbuf[3] = {nullptr, nullptr, nullptr};  // two result buffers + {max|a-b|, max|a|}
+static size_t g_vcap = 0;
+static int g_rejected = 0;
+int conv_tune_rejected() { return g_rejected; }
+void conv_tune_note_reject() { ++g_rejected; }
+float* tune_scratch(size_t floats, int which) {
+  if (floats > g_vcap) {
+    for (int i = 0; i < 2; ++i) { if (g_vbuf[i]) (void)hipFree(g_vbuf[i]); g_vbuf[i] = nullptr; }
+    g_vcap = floats + floats / 4;
+    for (int i = 0; i < 2; ++i)
+      if (hipMalloc(reinterpret_cast<void**>(&g_vbuf[i]), g_vcap * sizeof(float)) != hipSuccess) { g_vbuf[i] = nullptr; g_vcap = 0; return nullptr; }
+  }
+  if (!g_vbuf[2] && hipMalloc(reinterpret_cast<void**>(&g_vbuf[2]), 2 * sizeof(float)) != hipSuccess) return nullptr;
+  return g_vbuf[which];
+}
+static void tune_scratch_free() {
+  for (int i = 0; i < 3; ++i) { if (g_vbuf[i]) (void)hipFree(g_vbuf[i]); g_vbuf[i] = nullptr; }
+  g_vcap = 0;
+}
+__global__ __launch_bounds__(256) void tune_maxdiff_kernel(const float* __restrict__ a, const float* __restrict__ b, long n, float* __restrict__ out) {
+  float d = 0.f, m = 0.f;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+    const float x = a[e], y = b[e];
+    float df = fabsf(x - y);
+    if (!(df == df)) df = 3.0e38f;  // NaN in either result
+    d = fmaxf(d, df);
+    m = fmaxf(m, fabsf(x));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { d = fmaxf(d, __shfl_xor(d, o)); m = fmaxf(m, __shfl_xor(m, o)); }
+  if ((threadIdx.x & 63) == 0) {  // non-negative floats order like their bit patterns
+    atomicMax(reinterpret_cast<int*>(out), __float_as_int(d));
+    atomicMax(reinterpret_cast<int*>(out) + 1, __float_as_int(m));
+  }
+}
+// max|a-b| <= 2e-4 * max|a| + 1e-6 ?  (a = reference; split-K orders differ by ~1e-6 relative)
+bool tune_compare(const float* a, const float* b, size_t n, hipStream_t stream, float* diff_out, float* scale_out) {
+  float* res = g_vbuf[2];
+  if (!res) return false;
+  if (hipMemsetAsync(res, 0, 2 * sizeof(float), stream) != hipSuccess) return false;
+  long nbl = ((long)n + 255) / 256;
+  hipLaunchKernelGGL(tune_maxdiff_kernel, dim3((int)(nbl > 2048 ? 2048 : nbl)), dim3(256), 0, stream, a, b, (long)n, res);
+  float h[2] = {3.0e38f, 0.f};
+  if (hipMemcpyAsync(h, res, sizeof(h), hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) return false;
+  if (diff_out) *diff_out = h[0];
+  if (scale_out) *scale_out = h[1];
+  return h[0] <= 2e-4f * h[1] + 1e-6f;
+}
 
 static uint64_t conv_key(const ConvParams& p) {
   const int f[] = {p.N, p.H, p.W, p.up_shift, p.Kc, p.Cout, p.ntaps, p.ncls, p.OHq, p.OWq, p.isy, p.osy, p.xa ? 1 : 0,
@@ -990,7 +1068,7 @@ static ConvCfg tune_cfg(ConvParams& p, hipStream_t stream) {
     for (int ks : kss) {
       if (ks > 1 && (tiles >= 512 || tiles * ks > 4096)) continue;
       if (tiles * ks < 96 && ks * 2 <= kcap) continue;  // hopelessly under-filled
-      cand.push_back({bm, bn, ks, 1});
+      cand.push_back({bm, bn, ks, 1, ks <= 16});
     }
   }
   cand.push_back(h);
@@ -1022,16 +1100,49 @@ static ConvCfg tune_cfg(ConvParams& p, hipStream_t stream) {
   }
   for (int th : {8, 4}) {  // thin layers: tile-resident direct convolution
     if (!tile_ok(p, th)) continue;
-    const ConvCfg d = {th, 32, 1, 3};
+    const ConvCfg d = {th, 32, 1, 3, 0};
     const float ms = time_cfg(p, d, 3, stream);
     if (ms < a * 0.97f) {
       const float ms5 = time_cfg(p, d, 5, stream);
       if (ms5 < a * 0.97f) { a = b = ms5; best = d; }
     }
   }
+  if (best.ks > 1 && best.ws != 3) {  // the other way of summing the slabs: last-arriving workgroup <-> second launch
+    ConvCfg d = best;
+    d.fold = !best.fold;
+    const float ms = time_cfg(p, d, 5, stream);
+    if (ms < (a < b ? a : b) * 0.98f) { a = b = ms; best = d; }
+  }
+  // verification against the reference configuration on the tuning data (see above)
+  if (best.bm != h.bm || best.bn != h.bn || best.ks != h.ks || best.ws != h.ws || best.fold != h.fold) {
+    const int ld = (p.Cout + 3) & ~3;
+    const size_t n = (size_t)p.N * p.OH * p.OW * ld;
+    float* r0 = tune_scratch(n, 0);
+    float* r1 = tune_scratch(n, 1);
+    bool ok = false;
+    float diff = 0.f, scale = 0.f;
+    if (r0 && r1) {
+      ConvParams q = p;
+      q.ldy = ld; q.y_coff = 0; q.accumulate = 0; q.y2 = nullptr; q.uo = nullptr;
+      (void)hipMemsetAsync(r0, 0, n * sizeof(float), stream);
+      (void)hipMemsetAsync(r1, 0, n * sizeof(float), stream);
+      q.y = r0;
+      int rc = run_cfg(q, h, stream);
+      q.y = r1;
+      if (rc == UDET_OK) rc = run_cfg(q, best, stream);
+      ok = rc == UDET_OK && tune_compare(r0, r1, n, stream, &diff, &scale);
+    }
+    if (!ok) {
+      fprintf(stderr, "[udet tune] REJECTED N=%d %dx%d Kc=%d taps=%d cls=%d Cout=%d: %dx%d ks=%d ws=%d fold=%d differs from the reference "
+              "configuration (max|diff| %.3e, scale %.3e); keeping the heuristic\n", p.N, p.OHq, p.OWq, p.Kc, p.ntaps, p.ncls, p.Cout,
+              best.bm, best.bn, best.ks, best.ws, best.fold, diff, scale);
+      conv_tune_note_reject();
+      best = h;
+    }
+  }
   if (getenv("UDET_TUNE_LOG"))
-    fprintf(stderr, "[udet tune] N=%d %dx%d Kc=%d taps=%d cls=%d Cout=%d -> %dx%d ks=%d ws=%d  %.1f us (heuristic %dx%d ks=%d)\n", p.N,
-            p.OHq, p.OWq, p.Kc, p.ntaps, p.ncls, p.Cout, best.bm, best.bn, best.ks, best.ws, (a < b ? a : b) * 1e3f, h.bm, h.bn, h.ks);
+    fprintf(stderr, "[udet tune] N=%d %dx%d Kc=%d taps=%d cls=%d Cout=%d -> %dx%d ks=%d ws=%d fold=%d  %.1f us (heuristic %dx%d ks=%d)\n", p.N,
+            p.OHq, p.OWq, p.Kc, p.ntaps, p.ncls, p.Cout, best.bm, best.bn, best.ks, best.ws, best.fold, (a < b ? a : b) * 1e3f, h.bm, h.bn, h.ks);
   return best;
 }
 
@@ -1055,10 +1166,6 @@ int launch_conv(ConvParams& p, hipStream_t stream) {
   }
   p.fd_ohw = make_fastdiv((unsigned)(p.OHq * p.OWq));
   p.fd_ow = make_fastdiv((unsigned)p.OWq);
-  {
-    static const int dbg = getenv("UDET_DBG") ? atoi(getenv("UDET_DBG")) : 0;
-    p.dbg = dbg;
-  }
   ConvCfg c;
   bool have = false;
   const uint64_t key = conv_key(p);
@@ -1079,11 +1186,12 @@ int launch_conv(ConvParams& p, hipStream_t stream) {
   if (g_force_bm) { c.bm = g_force_bm; c.bn = g_force_bn; }
   if (g_force_ks >= 0) c.ks = g_force_ks > max_ksplit(p) ? max_ksplit(p) : g_force_ks;
   if (g_force_ws >= 0) c.ws = g_force_ws;
+  if (g_force_fold >= 0) c.fold = g_force_fold;
   if ((c.ws == 2 || c.ws == 6) && !dma_ok(p)) c.ws = 1;
   if (c.ws == 6 && !self_staging_tile(c.bm, c.bn)) c.ws = 2;
   if (g_force_ws == 3) { c.ws = 3; c.bm = (g_force_bm == 4) ? 4 : 8; }
   if (c.ws == 3 && !tile_ok(p, c.bm)) { c = heuristic_cfg(p); }
-  g_last_cfg = (c.ws & 0xff) | ((c.bm & 0xfff) << 8) | ((c.ks & 0xff) << 20);
+  g_last_cfg = (c.ws & 0xff) | ((c.bm & 0xfff) << 8) | ((c.ks & 0xff) << 20) | ((c.ks > 1 && c.fold && c.ws != 3 && p.tickets ? 1 : 0) << 28);
   return run_cfg(p, c, stream);
 }
 

@@ -546,6 +546,26 @@ int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream) {
           if (ms < best_ms) { best_ms = ms; best = cfg; }
         }
       nsplit = best;
+      // the winner's filter / bias gradient must equal the heuristic configuration's (see conv_igemm.hip: candidate verification)
+      if (best != h) {
+        float* r0 = tune_scratch(wsz + (size_t)p.Cout, 0);
+        bool ok = false;
+        float diff = 0.f, scale = 0.f;
+        if (r0) {
+          run(h);
+          (void)hipMemcpyAsync(r0, p.dw, wsz * sizeof(float), hipMemcpyDeviceToDevice, stream);
+          if (p.db) (void)hipMemcpyAsync(r0 + wsz, p.db, (size_t)p.Cout * sizeof(float), hipMemcpyDeviceToDevice, stream);
+          run(best);
+          ok = tune_compare(r0, p.dw, wsz, stream, &diff, &scale);
+          if (ok && p.db) ok = tune_compare(r0 + wsz, p.db, (size_t)p.Cout, stream, &diff, &scale);
+        }
+        if (!ok) {
+          fprintf(stderr, "[udet tune] REJECTED wgrad N=%d %dx%d Cin=%d Cout=%d taps=%d: nsplit=%d dma=%d differs from the heuristic "
+                  "configuration (max|diff| %.3e, scale %.3e)\n", p.N, p.OH, p.OW, p.Cin, p.Cout, p.ntaps, best & 0xfffff, best >> 20, diff, scale);
+          conv_tune_note_reject();
+          nsplit = h;
+        }
+      }
       if (getenv("UDET_TUNE_LOG"))
         fprintf(stderr, "[udet tune] wgrad N=%d %dx%d Cin=%d Cout=%d taps=%d -> nsplit=%d dma=%d (heuristic %d) %.1f us\n", p.N, p.OH,
                 p.OW, p.Cin, p.Cout, p.ntaps, nsplit & 0xfffff, nsplit >> 20, h, best_ms / 3 * 1e3f);

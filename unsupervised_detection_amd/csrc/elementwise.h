@@ -26,7 +26,10 @@ int launch_mask_bwd(const float* dmask, const float* dfin, const float* f, const
 int launch_grad_absmean(const float* g, const long* seg_off, const long* seg_len, int nvars, float* vmean, float thresh,
                         float* out, hipStream_t s);
 int launch_adam(float* w, float* g, float* m, float* v, long n, float lr_t, float b1, float b2, float eps, float clip,
-                const float* flag, uint64_t seed, uint64_t step, hipStream_t s);
+                const float* flag, uint64_t seed, uint64_t step, hipStream_t s, int mode = 0);
+int launch_flow_normalize(const float* f, double* part, float* out, int B, long HW, hipStream_t s);
+int launch_charbonnier(const float* gt, const float* pred, const float* mask, int mc, int B, long HW, float cbn, float* part,
+                       float* out, hipStream_t s);
 int launch_crop_flip_resize(const void* src, int src_u8, int nearest, int N, int H, int W, int C, const int* prm, float* dst, int OH,
                             int OW, float div, float add, hipStream_t s);
 int launch_mask_stats(const float* pred, const float* gt, int N, int H, int W, float threshold, float gt_threshold, double* out,

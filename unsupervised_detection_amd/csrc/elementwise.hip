@@ -432,6 +432,35 @@ int launch_gen_input(const float* img, const float* f, double* part, float* gin,
   return UDET_OK;
 }
 size_t flow_stats_doubles(int B) { return (size_t)B * FS_BLOCKS * 4; }
+// the standardised flow alone (the generator-input packer above fuses the same arithmetic): out[B,H,W,2]
+__global__ __launch_bounds__(256) void flow_normalize_kernel(const float* __restrict__ f, const double* __restrict__ part,
+                                                             float* __restrict__ out, long HW) {
+  __shared__ float st[4];
+  const int n = blockIdx.y;
+  if (threadIdx.x < 2) {
+    double s = 0, q = 0;
+    for (int b = 0; b < FS_BLOCKS; ++b) {
+      s += part[((long)n * FS_BLOCKS + b) * 4 + threadIdx.x];
+      q += part[((long)n * FS_BLOCKS + b) * 4 + 2 + threadIdx.x];
+    }
+    const double mean = s / (double)HW, var = q / (double)HW - mean * mean;
+    st[threadIdx.x] = (float)mean;
+    st[2 + threadIdx.x] = sqrtf((float)var);
+  }
+  __syncthreads();
+  const float m0 = st[0], m1 = st[1], d0 = st[2], d1 = st[3];
+  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < HW; p += (long)gridDim.x * 256) {
+    const long q = (long)n * HW + p;
+    const float2 v = *reinterpret_cast<const float2*>(f + q * 2);
+    *reinterpret_cast<float2*>(out + q * 2) = make_float2((v.x - m0) / d0, (v.y - m1) / d1);
+  }
+}
+int launch_flow_normalize(const float* f, double* part, float* out, int B, long HW, hipStream_t s) {
+  hipLaunchKernelGGL(flow_stats_kernel, dim3(FS_BLOCKS, B), dim3(256), 0, s, f, HW, part);
+  hipLaunchKernelGGL(flow_normalize_kernel, dim3(grid_for(HW, 256), B), dim3(256), 0, s, f, part, out, HW);
+  UDET_HIP(hipGetLastError());
+  return UDET_OK;
+}
 
 // ---------------------------------------------------------------------------
 // mask + recover inputs (models/nets.py:38-41,50-52; adversarial_learner.py:107-131)
@@ -555,6 +584,39 @@ int launch_losses(const float* f, const float* mask, const float* pred, long HW,
   return UDET_OK;
 }
 size_t loss_part_floats(int B) { return (size_t)B * LS_BLOCKS * 5; }
+
+// charbonnier_loss(gt_flows, pred_flows, masks, cbn) alone (loss_utils.py:34-51): out[b] = sum_{h,w,c} phi(gt - pred) * mask,
+// mask [B,H,W,mc] with mc = 1 (broadcast over the two flow channels), 2, or null (ones).  Deterministic two-stage sum.
+__global__ __launch_bounds__(256) void charbonnier_sum_kernel(const float* __restrict__ gt, const float* __restrict__ pred,
+                                                              const float* __restrict__ mask, int mc, long HW, float cbn,
+                                                              float* __restrict__ part /*[B][LS_BLOCKS]*/) {
+  __shared__ float sm[4];
+  const int n = blockIdx.y;
+  float acc = 0.f;
+  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < HW; p += (long)gridDim.x * 256) {
+    const long q = (long)n * HW + p;
+    const float2 a = *reinterpret_cast<const float2*>(gt + q * 2);
+    const float2 b = *reinterpret_cast<const float2*>(pred + q * 2);
+    const float m0 = mask ? mask[q * mc] : 1.f, m1 = mask ? mask[q * mc + (mc - 1)] : 1.f;
+    acc += charb(a.x - b.x, cbn) * m0 + charb(a.y - b.y, cbn) * m1;
+  }
+  acc = block_sum(acc, sm);
+  if (threadIdx.x == 0) part[(long)n * LS_BLOCKS + blockIdx.x] = acc;
+}
+__global__ void charbonnier_finish_kernel(const float* __restrict__ part, int B, float* __restrict__ out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float v = 0.f;
+  for (int k = 0; k < LS_BLOCKS; ++k) v += part[(long)b * LS_BLOCKS + k];
+  out[b] = v;
+}
+int launch_charbonnier(const float* gt, const float* pred, const float* mask, int mc, int B, long HW, float cbn, float* part,
+                       float* out, hipStream_t s) {
+  hipLaunchKernelGGL(charbonnier_sum_kernel, dim3(LS_BLOCKS, B), dim3(256), 0, s, gt, pred, mask, mc, HW, cbn, part);
+  hipLaunchKernelGGL(charbonnier_finish_kernel, dim3((B + 63) / 64), dim3(64), 0, s, part, B, out);
+  UDET_HIP(hipGetLastError());
+  return UDET_OK;
+}
 
 // d(recover_loss)/d pred for the 3 calls  (recover_loss = (sum R + sum Rc + sum P)/num_pixels)
 __global__ __launch_bounds__(256) void rec_loss_bwd_kernel(const float* __restrict__ f, const float* __restrict__ mask,
@@ -692,13 +754,18 @@ __device__ __host__ __forceinline__ float udet_uniform01(uint64_t seed, uint64_t
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long n, float lr_t, float b1, float b2, float eps,
                                                    float clip, const float* __restrict__ flag, uint64_t seed,
-                                                   uint64_t step) {
+                                                   uint64_t step, int mode) {
+  // mode 0: clip / noise + Adam (the step's fused form); 1: clip / noise only (train_op's clipped_grad_and_vars);
+  // 2: Adam only on the gradient as it is (optimizer.apply_gradients)
   const bool noise = flag && flag[1] != 0.f;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     float gi = g[i];
-    if (noise) gi = fabsf((udet_uniform01(seed, step, (uint64_t)i) * 2.f - 1.f) * clip);
-    else gi = fminf(fmaxf(gi, -clip), clip);
-    g[i] = gi;  // clipped_grad_and_vars (loss_utils.py:31) -- what the reference logs as gradient histograms
+    if (mode != 2) {
+      if (noise) gi = fabsf((udet_uniform01(seed, step, (uint64_t)i) * 2.f - 1.f) * clip);
+      else gi = fminf(fmaxf(gi, -clip), clip);
+      g[i] = gi;  // clipped_grad_and_vars (loss_utils.py:31) -- what the reference logs as gradient histograms
+      if (mode == 1) continue;
+    }
     const float mi = m[i] + (gi - m[i]) * (1.f - b1);
     const float vi = v[i] + (gi * gi - v[i]) * (1.f - b2);
     m[i] = mi;
@@ -755,9 +822,9 @@ int launch_mask_stats(const float* pred, const float* gt, int N, int H, int W, f
   return UDET_OK;
 }
 int launch_adam(float* w, float* g, float* m, float* v, long n, float lr_t, float b1, float b2, float eps, float clip,
-                const float* flag, uint64_t seed, uint64_t step, hipStream_t s) {
+                const float* flag, uint64_t seed, uint64_t step, hipStream_t s, int mode) {
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, s, w, g, m, v, n, lr_t, b1, b2, eps, clip, flag, seed,
-                     step);
+                     step, mode);
   UDET_HIP(hipGetLastError());
   return UDET_OK;
 }

@@ -89,6 +89,7 @@ struct Plan {
   size_t wgrad_off[NLANE] = {}, wgrad_floats = 0;       // wgrad partials (lanes that run filter gradients)
   ~Plan();
   size_t small_off = 0;          // losses, coefficients, flags, reduction partials
+  size_t ticket_off = 0;         // NLANE x UDET_MAX_TICKETS ints: split-K arrival counters (zero between launches)
   size_t seg_off[3] = {0, 0, 0}; // per-variable (offset,len) tables on device (as long)
   size_t jobs_off[3] = {0, 0, 0}; // PackJob tables on device
   int njobs[3] = {0, 0, 0};
@@ -117,6 +118,7 @@ int plan_forward(Plan* P, const float* img1, const float* img2, int ncalls, floa
 int plan_prefetch(Plan* P, const float* img1, const float* img2, float* ws, hipStream_t s);
 int plan_prefetch_consume(Plan* P, float* ws, hipStream_t s);
 int plan_generator_forward(Plan* P, float* ws, hipStream_t s);
+int plan_generator_layers(Plan* P, float* ws, hipStream_t s);
 int plan_recover_forward(Plan* P, int ncalls, float* ws, hipStream_t s, bool inputs_prepacked = false, bool skip_enc_a = false);
 int plan_losses(Plan* P, float* ws, hipStream_t s);
 // which: 1 generator loss -> MaskNet, 2 recover loss -> FlownetS, 3 both (the two passes run concurrently)

@@ -478,6 +478,8 @@ Plan* plan_build(const Config& cfg) {
   }
   P->small_off = off;
   off = align64(off + 65536);
+  P->ticket_off = off;  // split-K tickets, one table per lane (outside the region udet_autotune fills with probe data)
+  off = align64(off + (size_t)Plan::NLANE * UDET_MAX_TICKETS);
   for (int net = 1; net <= 2; ++net) {
     P->seg_off[net] = off;
     off = align64(off + 4 * net_params(net).p.size() + 64);  // two long tables (offset, len) = 4 floats per entry

@@ -90,6 +90,7 @@ static void fill_common(Plan* P, ConvParams& p, float* ws, int slot) {
   p.partial = ws + P->scratch_off[slot];
   p.partial_cap = P->scratch_floats;
   p.zero16 = ws + P->small_off + 60000;  // never written after udet_plan_init's memset
+  p.tickets = reinterpret_cast<int*>(ws + P->ticket_off) + (size_t)slot * UDET_MAX_TICKETS;
 }
 
 static int run_fwd(Plan* P, const Layer& L, int N, float* ws, const Lane& ln, size_t x_extra = 0, size_t y_extra = 0) {
@@ -331,18 +332,13 @@ static int pwc_forward_on(Plan* P, const float* img1, const float* img2, float* 
     const Buf& slab = P->buf(P->bid(S("pwc.slab%d", l)));
     const float* c1 = ws + cb.off;
     const float* c2 = ws + cb.off + (size_t)B * h * w * C;
-    const float* second = c2;
-    if (l != 6) {
-      // warp(c2, up_flow * 20/2^l)  (model_pwcnet.py:616-617)
-      float* wr = ws + P->buf(P->bid(S("pwc.warp%d", l))).off;
-      prof_begin(P, PROF_WARP, 0, (double)B * h * w * (2.0 * C + 2.0) * 4.0, s);  // read c2 + flow, write warped
-      UDET_TRY(launch_warp(c2, ws + slab.off, slab.ld, 532 + C, 20.0f / (float)(1 << l), wr, B, h, w, C, nullptr, nullptr, s));
-      prof_end(P, s);
-      second = wr;
-      UDET_TRY(launch_copy_channels(c1, C, 0, ws + slab.off, slab.ld, 532, (long)B * h * w, C, 1.f, 0.f, s));
-    }
-    prof_begin(P, PROF_CORR, 2.0 * B * h * w * 81.0 * C, (double)B * h * w * (2.0 * C + 81.0) * 4.0, s);  // read c1 + warped, write 81 ch
-    UDET_TRY(launch_cost_volume(c1, second, ws + slab.off, slab.ld, 448, B, h, w, C, s));
+    // warp(c2, up_flow * 20/2^l) -> cost volume -> slab segments [corr 81 | c1] in one launch (model_pwcnet.py:616-623);
+    // level 6 correlates c1 with c2 itself and has no c1 / up_flow / up_feat segments
+    const bool warped = l != 6;
+    const double px = (double)B * h * w;
+    prof_begin(P, PROF_CORR, 2.0 * px * 81.0 * C, px * ((warped ? 3.0 * C + 2.0 : 2.0 * C) + 81.0) * 4.0, s, S("warp_costvol%d", l).c_str());
+    UDET_TRY(launch_warp_cost_volume(c1, c2, warped ? ws + slab.off : nullptr, slab.ld, 532 + C, 20.0f / (float)(1 << l), ws + slab.off,
+                                     slab.ld, 448, warped ? 532 : -1, nullptr, B, h, w, C, s));
     prof_end(P, s);
     for (int i = 0; i < 5; ++i) UDET_TRY(run_fwd(P, *find_layer(P->pwc, S("pwcnet/predict_flow/conv%d_%d", l, i)), B, ws, L0));
     // upfeat (the slab) is complete: the flow head and the learned upsampling of upfeat only read it, so they run on
@@ -406,6 +402,12 @@ int plan_generator_forward(Plan* P, float* ws, hipStream_t s) {
   UDET_TRY(launch_gen_input(ws + P->buf(P->bid("image")).off, ws + P->buf(P->bid("flow")).off, part,
                             ws + P->buf(P->bid("gen.in")).off, c.batch, HW, s));
   for (const auto& L : P->gen) UDET_TRY(run_fwd(P, L, c.batch, ws, L0));
+  return UDET_OK;
+}
+// the 17 layers alone, from a caller-packed "gen.in" ([image 3 | standardised flow 2 | 0 0 0]): nets.generator_net's own contract
+int plan_generator_layers(Plan* P, float* ws, hipStream_t s) {
+  const Lane L0 = lane_of(P, s, 0);
+  for (const auto& L : P->gen) UDET_TRY(run_fwd(P, L, P->cfg.batch, ws, L0));
   return UDET_OK;
 }
 

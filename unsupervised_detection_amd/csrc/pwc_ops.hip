@@ -210,4 +210,213 @@ int launch_cost_volume(const float* c1, const float* wr, float* out, int ldo, in
   return UDET_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Fused warp -> cost volume (+ the c1 segment of the level slab): model_pwcnet.py:616-623 in ONE launch per pyramid level.
+//   warped = dense_image_warp(c2, flow * scale)            (core_warp.py:153-202; skipped when flow == null: level 6)
+//   out[.., corr_coff + d] = leaky0.1(mean_c c1 * warped@d)  (core_costvol.py:20-40)
+//   out[.., c1_coff + c]   = c1                              (the tf.concat([corr, c1, up_flow, up_feat]) of :622)
+// One workgroup per TxT pixel tile.  Thread hp computes the grid-index math of halo pixel hp once (floor indices and alphas,
+// the same explicitly rounded operations as warp_kernel -> bit-identical); per 32-channel slice the (T+8)^2 halo of the
+// WARPED features is produced straight into LDS from four corner gathers of c2 (the warped tensor never exists in HBM), the
+// c1 tile goes to LDS and to the slab, and thread (pixel, g) accumulates displacements g, g+NG, ... exactly like
+// cost_volume_kernel (same FMA order: results are bit-identical to udet_warp followed by udet_cost_volume).
+// xcds < 8: only workgroups whose hardware slot falls on the first `xcds` XCDs work (the others exit): the small pyramid
+// levels then stay inside one or two L2s instead of every XCD fetching the whole level for a handful of tiles.
+// ---------------------------------------------------------------------------
+template <int T>
+__global__ __launch_bounds__(256) void warp_cost_volume_kernel(const float* __restrict__ c1, const float* __restrict__ c2,
+                                                               const float* __restrict__ flow, int ldf, int f_coff, float flow_scale,
+                                                               float* __restrict__ out, int ldo, int corr_coff, int c1_coff,
+                                                               float* __restrict__ warped_dbg, int N, int H, int W, int C, int xcds) {
+  constexpr int HALO = T + 2 * CV_R, NHP = HALO * HALO, NP = T * T, NG = 256 / NP, ND = (81 + NG - 1) / NG;
+  constexpr int HL = (NHP * 8 + 255) / 256;  // float4 halo items per thread and slice
+  constexpr int TL = (NP * 8 + 255) / 256;   // float4 c1 items per thread and slice
+  __shared__ __attribute__((aligned(16))) float sw[(NHP * CV_CS > NP * 81 ? NHP * CV_CS : NP * 81)];
+  __shared__ __attribute__((aligned(16))) float s1[NP * CV_CS];
+  __shared__ int h_off[NHP];       // element offset of the top-left corner in c2 (-1: halo pixel outside the image)
+  __shared__ float2 h_a[NHP];      // (alpha_y, alpha_x)
+  const int t = threadIdx.x;
+  const int tiles_x = (W + T - 1) / T, tiles_y = (H + T - 1) / T;
+  int bid = blockIdx.x;
+  {
+    const int slot = bid & 7;
+    if (slot >= xcds) return;
+    const int nwg = (gridDim.x >> 3) * xcds, idx = bid >> 3;  // gridDim.x is a multiple of 8
+    const int q = nwg / xcds;                                  // workgroups per active XCD (nwg is a multiple of xcds)
+    bid = slot * q + idx;                                      // consecutive tiles (overlapping halos) on the same XCD
+    if (bid >= tiles_x * tiles_y * N) return;
+  }
+  const int bx = bid % tiles_x, by = (bid / tiles_x) % tiles_y, n = bid / (tiles_x * tiles_y);
+  const int y0 = by * T, x0 = bx * T;
+  const int p = t % NP, g = t / NP;
+  const int py = p / T, px = p % T;
+
+  // ---- grid-index math of this thread's halo pixel (core_warp.py:99-115), bit-identical to warp_kernel ----
+  if (t < NHP) {
+    const int hy = t / HALO, hx = t - hy * HALO;
+    const int yy = y0 + hy - CV_R, xx = x0 + hx - CV_R;
+    int off = -1;
+    float ay = 0.f, ax = 0.f;
+    if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W) {
+      if (flow) {
+        const float* f = flow + (((long)n * H + yy) * W + xx) * ldf + f_coff;
+        const float fy = f[0] * flow_scale, fx = f[1] * flow_scale;
+        const float qy = (float)yy - fy, qx = (float)xx - fx;
+        const float flo_y = fminf(fmaxf(0.f, floorf(qy)), (float)(H - 2));
+        const float flo_x = fminf(fmaxf(0.f, floorf(qx)), (float)(W - 2));
+        ay = fminf(fmaxf(0.f, (qy - flo_y)), 1.f);
+        ax = fminf(fmaxf(0.f, (qx - flo_x)), 1.f);
+        off = ((n * H + (int)flo_y) * W + (int)flo_x) * C;
+      } else {
+        off = ((n * H + yy) * W + xx) * C;
+      }
+    }
+    h_off[t] = off;
+    h_a[t] = make_float2(ay, ax);
+  }
+  int toff[TL];  // c1 tile pixel offsets (-1 outside)
+#pragma unroll
+  for (int u = 0; u < TL; ++u) {
+    const int e = t + u * 256, tp = e >> 3;
+    const int yy = y0 + tp / T, xx = x0 + tp % T;
+    toff[u] = (tp < NP && yy < H && xx < W) ? ((n * H + yy) * W + xx) : -1;
+  }
+  float acc[ND];
+#pragma unroll
+  for (int j = 0; j < ND; ++j) acc[j] = 0.f;
+  const int c4 = t & 7;
+  const long rowC = (long)W * C;
+  __syncthreads();
+
+  for (int cb = 0; cb < C; cb += 32) {
+    const bool cok = c4 * 4 < min(32, C - cb);
+    // c1 tile: LDS + the slab's c1 segment
+#pragma unroll
+    for (int u = 0; u < TL; ++u) {
+      const int e = t + u * 256;
+      if (e < NP * 8) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (cok && toff[u] >= 0) {
+          v = *reinterpret_cast<const float4*>(c1 + (long)toff[u] * C + cb + c4 * 4);
+          if (c1_coff >= 0) *reinterpret_cast<float4*>(out + (long)toff[u] * ldo + c1_coff + cb + c4 * 4) = v;
+        }
+        *reinterpret_cast<float4*>(&s1[(e >> 3) * CV_CS + c4 * 4]) = v;
+      }
+    }
+    // warped halo: four corner gathers per (halo pixel, channel quad), in batches of 4 items (16 loads in flight)
+#pragma unroll
+    for (int ub = 0; ub < HL; ub += 4) {
+      float4 tl[4], tr[4], bl[4], br[4];
+      int hp[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int e = t + (ub + k) * 256;
+        hp[k] = e >> 3;
+        tl[k] = tr[k] = bl[k] = br[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (ub + k < HL && hp[k] < NHP) {
+          const int o = h_off[hp[k]];
+          if (cok && o >= 0) {
+            const float* base = c2 + o + cb + c4 * 4;
+            tl[k] = *reinterpret_cast<const float4*>(base);
+            if (flow) {
+              tr[k] = *reinterpret_cast<const float4*>(base + C);
+              bl[k] = *reinterpret_cast<const float4*>(base + rowC);
+              br[k] = *reinterpret_cast<const float4*>(base + rowC + C);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (ub + k < HL && hp[k] < NHP) {
+          float4 o = tl[k];
+          if (flow) {
+            const float2 a = h_a[hp[k]];
+            o.x = lerp_rn(a.x, lerp_rn(a.y, tl[k].x, tr[k].x), lerp_rn(a.y, bl[k].x, br[k].x));
+            o.y = lerp_rn(a.x, lerp_rn(a.y, tl[k].y, tr[k].y), lerp_rn(a.y, bl[k].y, br[k].y));
+            o.z = lerp_rn(a.x, lerp_rn(a.y, tl[k].z, tr[k].z), lerp_rn(a.y, bl[k].z, br[k].z));
+            o.w = lerp_rn(a.x, lerp_rn(a.y, tl[k].w, tr[k].w), lerp_rn(a.y, bl[k].w, br[k].w));
+          }
+          *reinterpret_cast<float4*>(&sw[hp[k] * CV_CS + c4 * 4]) = o;
+          if (warped_dbg && cok) {  // test hook: the tile's own (centre) pixels of the warped tensor
+            const int hy = hp[k] / HALO, hx = hp[k] - hy * HALO;
+            const int yy = y0 + hy - CV_R, xx = x0 + hx - CV_R;
+            if (hy >= CV_R && hy < CV_R + T && hx >= CV_R && hx < CV_R + T && yy < H && xx < W)
+              *reinterpret_cast<float4*>(warped_dbg + (((long)n * H + yy) * W + xx) * C + cb + c4 * 4) = o;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    float4 a[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a[q] = *reinterpret_cast<const float4*>(&s1[p * CV_CS + q * 4]);
+#pragma unroll
+    for (int j = 0; j < ND; ++j) {
+      const int d = g + NG * j;
+      if (d < 81) {
+        const int dy = d / 9, dx = d - dy * 9;
+        const float* wp = &sw[((py + dy) * HALO + px + dx) * CV_CS];
+        float s = acc[j];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float4 b = *reinterpret_cast<const float4*>(wp + q * 4);
+          s = fmaf(a[q].x, b.x, s);
+          s = fmaf(a[q].y, b.y, s);
+          s = fmaf(a[q].z, b.z, s);
+          s = fmaf(a[q].w, b.w, s);
+        }
+        acc[j] = s;
+      }
+    }
+    __syncthreads();
+  }
+  float* so = sw;
+#pragma unroll
+  for (int j = 0; j < ND; ++j) {
+    const int d = g + NG * j;
+    if (d < 81) {
+      const float v = acc[j] / (float)C;
+      so[p * 81 + d] = v > 0.f ? v : 0.1f * v;
+    }
+  }
+  __syncthreads();
+  for (int e = t; e < NP * 81; e += 256) {
+    const int tp = e / 81, d = e - tp * 81;
+    const int yy = y0 + tp / T, xx = x0 + tp % T;
+    if (yy < H && xx < W) out[(((long)n * H + yy) * W + xx) * ldo + corr_coff + d] = so[e];
+  }
+}
+
+int launch_warp_cost_volume(const float* c1, const float* c2, const float* flow, int ldf, int f_coff, float flow_scale, float* out,
+                            int ldo, int corr_coff, int c1_coff, float* warped_dbg, int N, int H, int W, int C, hipStream_t stream) {
+  if (C % 4 != 0 || (flow && (H < 2 || W < 2))) {
+    set_error("warp_cost_volume: C=%d must be a multiple of 4 and H,W >= 2 (got %dx%d)", C, H, W);
+    return UDET_ERR_SHAPE;
+  }
+  if ((long)N * H * W * (C > ldo ? C : ldo) >= (1L << 31)) {
+    set_error("warp_cost_volume: tensor too large for 32-bit element offsets");
+    return UDET_ERR_SHAPE;
+  }
+  if (c1_coff >= 0 && ((c1_coff | ldo) & 3)) {
+    set_error("warp_cost_volume: c1 segment offset %d / row stride %d must be multiples of 4", c1_coff, ldo);
+    return UDET_ERR_ALIGN;
+  }
+  // small levels: 4x4 tiles (4x the workgroups) on as few XCDs as still give every tile its own CU
+  const long pixels = (long)N * H * W;
+  const int T = pixels <= 4096 ? 4 : 8;
+  const int tiles = ((W + T - 1) / T) * ((H + T - 1) / T) * N;
+  const int xcds = tiles <= 32 ? 1 : (tiles <= 64 ? 2 : (tiles <= 128 ? 4 : 8));
+  const int per = (tiles + xcds - 1) / xcds;
+  const dim3 grid(per * 8);
+  if (T == 4)
+    hipLaunchKernelGGL(warp_cost_volume_kernel<4>, grid, dim3(256), 0, stream, c1, c2, flow, ldf, f_coff, flow_scale, out, ldo, corr_coff,
+                       c1_coff, warped_dbg, N, H, W, C, xcds);
+  else
+    hipLaunchKernelGGL(warp_cost_volume_kernel<8>, grid, dim3(256), 0, stream, c1, c2, flow, ldf, f_coff, flow_scale, out, ldo, corr_coff,
+                       c1_coff, warped_dbg, N, H, W, C, xcds);
+  UDET_HIP(hipGetLastError());
+  return UDET_OK;
+}
+
 }  // namespace udet

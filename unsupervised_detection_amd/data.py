@@ -107,36 +107,32 @@ def augment_pair(image_1: torch.Tensor, image_2: torch.Tensor, train_crop: float
 
 
 class DirectoryIterator(object):
-    """ImageSets/480p/{train,val,trainval}.txt -> per-sequence lists of image / annotation files (:6-65)."""
+    """The DAVIS-2016 split files (`ImageSets/480p/{train,val,trainval}.txt`, one "<image> <annotation>" pair of
+    root-relative paths per line) grouped into sequences.  Attributes follow the reference reader's contract
+    (data/davis2016_data_utils.py:6-65): image_filenames / annotation_filenames are per-sequence lists of absolute paths,
+    samples the number of frames, num_experiments the number of sequences."""
+
+    SPLITS = ("train", "val", "trainval")
 
     def __init__(self, directory, part="train"):
+        from itertools import groupby
         self.directory = directory
-        name_division = {"train": "ImageSets/480p/train.txt", "val": "ImageSets/480p/val.txt", "trainval": "ImageSets/480p/trainval.txt"}
-        part_file = os.path.join(directory, name_division.get(part))
-        if not os.path.isfile(part_file):
+        split = os.path.join(directory, "ImageSets", "480p", "%s.txt" % part) if part in self.SPLITS else ""
+        if not os.path.isfile(split):
             raise IOError("Partition file not found")
-        with open(part_file) as f:
-            components = [ln.split() for ln in f if ln.strip()]
-        self.samples = 0
+        with open(split) as f:
+            rows = [ln.split()[:2] for ln in f if ln.strip()]
+        absolute = lambda rel: os.path.join(directory, rel.lstrip("/"))
+        sequence_of = lambda row: row[0].strip("/").split("/")[2]  # JPEGImages/480p/<sequence>/<frame>.jpg
         self.image_filenames, self.annotation_filenames = [], []
-        current, cur_f, cur_a = "", None, None
-        for string in components:
-            folder_name = string[0].split("/")[3]
-            if folder_name != current:
-                current = folder_name
-                if cur_f is not None:
-                    self.image_filenames.append(cur_f)
-                    self.annotation_filenames.append(cur_a)
-                cur_f, cur_a = [], []
-            cur_f.append(os.path.join(directory, string[0][1:]))
-            cur_a.append(os.path.join(directory, string[1][1:]))
-            self.samples += 1
-        if cur_f is not None:
-            self.image_filenames.append(cur_f)
-            self.annotation_filenames.append(cur_a)
+        for _, frames in groupby(rows, key=sequence_of):  # consecutive lines of one sequence, in file order
+            frames = list(frames)
+            self.image_filenames.append([absolute(img) for img, _ in frames])
+            self.annotation_filenames.append([absolute(ann) for _, ann in frames])
+        self.samples = len(rows)
+        self.num_experiments = len(self.image_filenames)
         if self.samples == 0:
             raise IOError("Did not find any file in the dataset folder")
-        self.num_experiments = len(self.image_filenames)
         print("Found {} images belonging to {} experiments.".format(self.samples, self.num_experiments))
 
 

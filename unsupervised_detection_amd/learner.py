@@ -290,14 +290,7 @@ class HotPath:
         return e.buffer("pred")[:B].clone()
 
 
-def preprocess_flow_batch(flow):
-    """models/utils/flow_utils.py:5-12 (torch ops; the fused device version lives in the generator input packer)."""
-    mean = flow.mean(dim=(1, 2), keepdim=True)
-    var = ((flow - mean) ** 2).mean(dim=(1, 2), keepdim=True)
-    return (flow - mean) / torch.sqrt(var)
-
-
-def charbonnier_loss(gt_flows, pred_flows, masks, cbn=0.5):
-    """models/utils/loss_utils.py:34-51 (torch ops on device; the training path uses the fused HIP reductions)."""
-    lp = torch.pow((gt_flows - pred_flows) ** 2 + 0.001 ** 2, cbn) * masks
-    return lp.sum(dim=(1, 2, 3))
+# module-level names of the reference's function surface (models/nets.py:4,45; model_pwcnet.py:22; loss_utils.py:12,34;
+# flow_utils.py:5), all drivers over libudet.so -- see functional.py
+from .functional import (AdamOptimizer, AdversarialGraph, ModelPWCNet, charbonnier_loss, generator_net,  # noqa: E402,F401
+                         preprocess_flow_batch, recover_net, train_op)
