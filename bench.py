@@ -6,7 +6,11 @@
 
 One step = PWC-Net flow + mask-generator fwd + 3x recover fwd + generator-loss backward + recover-loss backward +
 both clipped-Adam updates on 4 DAVIS-480p-shaped synthetic frame pairs per GPU (BASELINE.json configs[1]/[2]).
-Inputs are resident in HBM (reader preprocessing done before the timed region).  Prints ONE JSON line."""
+Inputs are resident in HBM (reader preprocessing done before the timed region).  Prints ONE JSON line.
+
+The GPU leg and the CPU-oracle leg (`cpu_baseline`, rank 0 at N=1) run the SAME seeded weights on the SAME frame pairs;
+their first (untimed) step is compared -- `parity_check` in the JSON line -- and the process exits non-zero when the HIP path
+is more than 1e-3 (north_star tolerance) away from the oracle."""
 import argparse
 import json
 import os
@@ -19,30 +23,29 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ALG_GFLOP_PER_PAIR = 217.945  # 871.78 GFLOP per 4-pair step (fwd 551.06 + gen bwd 210.35 + rec bwd 110.36)
+ENSEMBLE_GFLOP_PER_FRAME = 1983.5  # 16 x (PWC-Net + generator forward at batch 1)
 PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md chip table
 PEAK_HBM_GBS = 8000.0
+PARITY_TOL = 1e-3
 
 
-def cpu_baseline(batch: int, reps: int, threads: int = 0):
-    """The oracle (PyTorch-CPU restatement, oracle/oracle_torch.py) timed on the host cores: a bounded sample of
-    the same workload -- `reps` full adversarial steps (fwd + both backward + clipped Adam) at batch `batch`."""
+def cpu_baseline(weights, i1, i2, gpu_first, reps: int, threads: int = 0):
+    """The oracle (PyTorch-CPU restatement, oracle/oracle_torch.py) on the host cores, on the weights / frame pairs of the
+    GPU leg.  Step 0 is untimed and is the parity check: oracle PWC flow vs the HIP flow, then generator / recover / losses on
+    the HIP flow vs the HIP results (`gpu_first`).  Steps 1..reps are timed full adversarial steps (fwd + both backward +
+    clipped Adam) -- a bounded sample of the workload."""
     from oracle import oracle_torch as O
-    from unsupervised_detection_amd import data
-    import numpy as np
+    batch = i1.shape[0]
     # measured on the MI355X host (256 logical CPUs), B=1: 16 threads 2.36 pairs/s, 32 -> 1.47, 64 -> 0.59: use 16
     cores = threads or min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
-    pp = O.init_params(O.pwc_param_specs(), 8964)
-    pg = O.init_params(O.generator_param_specs(), 8965)
-    pr = O.init_params(O.recover_param_specs(), 8966)
-    f1, f2 = data.synthetic_davis_pairs(batch, 8964, 384, 640)  # generated directly at the reader's output size
-    i1 = torch.from_numpy(f1.astype(np.float32) / 255.0 - 0.5)
-    i2 = torch.from_numpy(f2.astype(np.float32) / 255.0 - 0.5)
+    pp, pg, pr = ({k: v.clone() for k, v in d.items()} for d in weights)
 
     class C(O.Flags):
         batch_size = batch
     opt = O.TFAdam()
     times = []
+    parity = None
     for r in range(reps + 1):
         for d in (pg, pr):
             for k in d:
@@ -50,7 +53,22 @@ def cpu_baseline(batch: int, reps: int, threads: int = 0):
         t0 = time.time()
         with torch.no_grad():
             image, flow, _ = O.prepare_inputs(pp, i1, i2, C)
-        out = O.forward_from_flow(pg, pr, image, flow, C)
+        if r == 0:
+            gflow = gpu_first["flow"]
+            rel = lambda a, b: float((a - b).abs().max()) / max(1e-6, float(b.abs().max()))
+            parity = {"flow_rel_err": rel(gflow, flow), "image_max_abs_err": float((gpu_first["image"] - image).abs().max())}
+            out = O.forward_from_flow(pg, pr, image, gflow, C)  # the HIP flow: PWC rounding must not leak into what follows
+            parity["mask_max_abs_err"] = float((gpu_first["mask"] - out["mask"]).abs().max())
+            ref_pred = torch.cat([out["pred"], out["pred_c"], out["pred_img"]], 0)
+            parity["pred_rel_err"] = rel(gpu_first["pred"], ref_pred.detach())
+            parity["max_rel_loss_err"] = max(abs(gpu_first["losses"][k] - float(out[k])) / max(1.0, abs(float(out[k])))
+                                             for k in gpu_first["losses"])
+            parity["losses_oracle"] = {k: round(float(out[k]), 6) for k in ("generator", "recover")}
+            parity["losses_hip"] = {k: round(gpu_first["losses"][k], 6) for k in ("generator", "recover")}
+            parity["tolerance"] = PARITY_TOL
+            parity["ok"] = all(parity[k] <= PARITY_TOL for k in ("flow_rel_err", "mask_max_abs_err", "pred_rel_err", "max_rel_loss_err"))
+        else:
+            out = O.forward_from_flow(pg, pr, image, flow, C)
         gg = O.grads_of(out["generator"], pg)
         gr = O.grads_of(out["recover"], pr)
         with torch.no_grad():
@@ -65,10 +83,41 @@ def cpu_baseline(batch: int, reps: int, threads: int = 0):
             times.append(time.time() - t0)
     times.sort()
     med = times[len(times) // 2]
-    return {"value": batch / med, "unit": "frame-pairs/s", "cores": cores, "kind": "port",
+    base = {"value": round(batch / med, 4), "unit": "frame-pairs/s", "cores": cores, "host_cpu_count": os.cpu_count(), "kind": "port",
             "sample": f"{reps} full adversarial steps (PWC fwd + gen fwd + 3x recover fwd + both backward + clipped Adam) at "
-                      f"batch {batch}, 384x640 -> 192x384, median; PyTorch-CPU oracle with {cores} threads "
-                      "(TF-1.13 itself is not installable here)"}
+                      f"batch {batch}, 384x640 -> 192x384, median; PyTorch-CPU oracle with {cores} threads of the host's "
+                      f"{os.cpu_count()} logical CPUs (more threads are slower; TF-1.13 itself is not installable here); same weights "
+                      "and frame pairs as the GPU leg"}
+    return base, parity
+
+
+def ensemble_workload(eng, frames_u8, shifts, reps):
+    """BASELINE.json configs[3] (test_generator_ensemble.py:47-114, adversarial_learner.py:525-592): per frame, the four
+    central crops x `shifts` temporal partners, PWC-Net + generator forward each.  The four crops are the batch of one plan.
+    Timed: crop / resize kernels + forward of every (frame, shift); returns frames/s."""
+    from unsupervised_detection_amd import data
+    crops = (0.85, 0.9, 0.95, 1.0)
+    n = frames_u8.shape[0]
+    imgs = data.preprocess_image(frames_u8)  # reader preprocessing (before the timed region, as in the headline)
+
+    def one_frame(t):
+        for s in shifts:
+            a, b = imgs[t:t + 1], imgs[(t + s) % n:(t + s) % n + 1]
+            i1 = torch.cat([data.central_cropping(a, c) for c in crops], 0)
+            i2 = torch.cat([data.central_cropping(b, c) for c in crops], 0)
+            eng.forward(i1, i2, 0)
+    one_frame(0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for r in range(reps):
+        one_frame(r % n)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"workload": "BASELINE.json configs[3]: 4 central crops x %d temporal shifts, PWC flow + generator forward, 384x640 -> 192x384, "
+                        "crops batched as one plan (B=4)" % len(shifts),
+            "frames": reps, "frames_per_s": round(reps / dt, 3), "ms_per_frame": round(dt / reps * 1e3, 3),
+            "alg_gflop_per_frame": ENSEMBLE_GFLOP_PER_FRAME * len(shifts) / 4.0,
+            "tflops_algorithmic": round(ENSEMBLE_GFLOP_PER_FRAME * len(shifts) / 4.0 * reps / dt / 1e3, 2)}
 
 
 def main():
@@ -77,13 +126,21 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=4, help="frame pairs per GPU (BASELINE.json: 4)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU-oracle leg (and with it the parity check)")
     ap.add_argument("--no-pipeline", action="store_true", help="no cross-step prefetch of the PWC flow (every step serial in itself)")
     ap.add_argument("--no-autotune", action="store_true", help="use the built-in tile heuristics instead of the one-off autotune pass")
+    ap.add_argument("--tune-cache", default="", help="file of tuned configurations: loaded when it exists (no tuning pass), written otherwise")
+    ap.add_argument("--trace-only", action="store_true", help="warm-up + timed steps and nothing else (for rocprofv3 kernel traces: "
+                    "with --tune-cache of an earlier run the trace holds steps only)")
     ap.add_argument("--cpu-reps", type=int, default=5)
     ap.add_argument("--cycles", type=int, default=3, help="reference-schedule cycles (1 recover step + 3 generator steps each) timed "
                     "after the headline region; 0 skips that extra measurement")
+    ap.add_argument("--ensemble-frames", type=int, default=12, help="frames of the configs[3] ensemble workload timed after the headline "
+                    "region (extra field `ensemble`); 0 skips it")
+    ap.add_argument("--pmc-json", default="", help="PMC counters of this build collected with tools/pmc_report.py; fills roofline.traffic")
     args = ap.parse_args()
+    if args.trace_only:
+        args.no_cpu_baseline, args.cycles, args.ensemble_frames = True, 0, 0
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -109,11 +166,21 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from unsupervised_detection_amd import data
+    from unsupervised_detection_amd import weights as W
+    from unsupervised_detection_amd._ffi import lib
     from unsupervised_detection_amd.engine import BOTH, Engine, EngineConfig
-    from unsupervised_detection_amd.trainer import TrainState, train_step
+    from unsupervised_detection_amd.trainer import TrainState, allreduce_mean_, train_step
 
     eng = Engine(EngineConfig(batch_size=args.batch), device=f"cuda:{local_rank}")
-    st = TrainState(eng, seed=8964, autotune=not args.no_autotune)  # identical weights on every rank; kernels autotuned once
+    loaded = 0
+    if args.tune_cache and os.path.exists(args.tune_cache):
+        loaded = int(lib.udet_tune_load(args.tune_cache.encode()))
+    st = TrainState(eng, seed=8964, autotune=not (args.no_autotune or loaded > 0))  # identical weights on every rank; kernels autotuned once
+    if args.tune_cache and not loaded and not args.no_autotune and rank == 0:
+        lib.udet_tune_save(args.tune_cache.encode())
+    w0 = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:  # the oracle leg starts from the same weights
+        w0 = tuple(W.as_dict(t.cpu().clone(), n) for t, n in ((st.w_pwc, W.NET_PWC), (st.w_gen, W.NET_GEN), (st.w_rec, W.NET_REC)))
     f1, f2 = data.synthetic_davis_pairs(args.batch, 8964 + rank)  # distinct data per rank (weak scaling)
     img1 = data.preprocess_image(torch.from_numpy(f1).cuda())
     img2 = data.preprocess_image(torch.from_numpy(f2).cuda())
@@ -132,6 +199,14 @@ def main():
     def stage(msg):  # UDET_BENCH_TRACE=1: progress markers on stderr (debugging a multi-process launch)
         if os.environ.get("UDET_BENCH_TRACE") == "1":
             print("[bench rank %d] %s" % (rank, msg), file=sys.stderr, flush=True)
+
+    # the step-0 forward of the HIP path on the initial weights: what the oracle leg is compared with (untimed)
+    gpu_first = None
+    if w0 is not None:
+        eng.forward(img1, img2, 3)
+        torch.cuda.synchronize()
+        gpu_first = {k: eng.buffer(k).cpu().clone() for k in ("image", "flow", "mask", "pred")}
+        gpu_first["losses"] = eng.losses()
 
     # cross-step pipelining (trainer.train_step): every step enqueues the frozen PWC-Net's flow of the NEXT pair beside
     # its own backward pass.  The pipeline is primed before the timed region (>= 1 warm-up step or an explicit prefetch),
@@ -159,6 +234,18 @@ def main():
     losses = eng.losses()
     stage("timed region done")
 
+    # the gradient exchange alone (the only collective of the step), timed after the headline region
+    allreduce_ms = None
+    if world > 1:
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            allreduce_mean_(st.g_all)
+        barrier()
+        ar = torch.tensor([(time.perf_counter() - t0) / 10 * 1e3], device="cuda", dtype=torch.float64)
+        dist.all_reduce(ar, op=dist.ReduceOp.MAX)
+        allreduce_ms = round(float(ar.item()), 4)
+
     # the reference's own schedule (adversarial_learner.py:383-398 with iter_gen=3 / iter_rec=1): a 4-step cycle
     # = 16 pairs, 4 forwards, 1 recover-loss backward, 3 generator-loss backwards.  Reported beside the headline number.
     ref_cycle = None
@@ -182,17 +269,31 @@ def main():
                      "frame_pairs_per_s": round(args.batch * world * 4 * args.cycles / dc, 3),
                      "alg_gflop_per_pair": 184.1}
 
-    # per-kernel-category timing with HIP events on the launch stream (one extra, untimed step)
-    if getattr(st, "_prefetched", None) is not None:  # drain the pipeline: the profiled step below is self-contained
+    if getattr(st, "_prefetched", None) is not None:  # drain the pipeline: what follows is self-contained
         eng.forward_prefetched(3)
         st._prefetched = None
+    if args.trace_only:
+        if rank == 0:
+            print(json.dumps({"metric": "frame-pairs/sec per adversarial step, DAVIS 480p batch4, 1/2/4/8 GPU", "value": round(pairs_per_s, 3),
+                              "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+                              "trace_only": True, "tuned_configurations_loaded": loaded}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return 0
+
+    ensemble = None
+    if args.ensemble_frames > 0 and args.batch == 4 and rank == 0:
+        fe, _ = data.synthetic_davis_pairs(8, 77)
+        ensemble = ensemble_workload(eng, torch.from_numpy(fe).cuda(), (1, 2, 3, 4), args.ensemble_frames)
+
     # per-kernel timing with HIP events on the launch stream: ONE extra, untimed step executed serially (the plan collapses
-    # its side streams while profiling, so every launch group's duration is its stand-alone duration)
-    prof, layers = None, []
+    # its side streams while profiling, so every launch group's duration is its stand-alone duration).
     # every rank runs the profiled step (it contains the gradient all-reduces: a rank that skipped it would leave the
     # others waiting in the collective); only rank 0 keeps the per-layer dump and reports
     import csv
     import tempfile
+    layers = []
     keep = os.environ.get("UDET_PROF_DUMP") if rank == 0 else None  # a caller-provided path is kept (per-layer CSV for analysis)
     dump = keep or os.path.join(tempfile.gettempdir(), "udet_layers_%d.csv" % os.getpid())
     if os.path.exists(dump):
@@ -208,52 +309,52 @@ def main():
         if not keep:
             os.remove(dump)
 
+    rc = 0
     if rank == 0:
         conv_ms = sum(prof[c]["ms"] for c in ("conv_fwd", "conv_dgrad", "conv_wgrad"))
         conv_groups = sum(prof[c]["groups"] for c in ("conv_fwd", "conv_dgrad", "conv_wgrad"))
         alg_flops = ALG_GFLOP_PER_PAIR * 1e9 * args.batch
-        achieved = alg_flops / (conv_ms * 1e-3) / 1e12
-        # the largest single launch of the step (dense estimator / context convolutions of PWC level 2)
+        # FLOPs of the launches actually executed: below the algorithmic figure because the image encoder of the three recover
+        # calls is evaluated once (identical input), not three times -- the kernel-efficiency numerator
+        exe_flops = sum(l[3] for l in layers if l[0] < 3) * 1e9 or alg_flops
+        achieved = exe_flops / (conv_ms * 1e-3) / 1e12
         top = max((l for l in layers if l[0] < 3), key=lambda l: l[3], default=None)
         pmc = {}
-        pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_dc_conv21.json")
-        if os.path.exists(pmc_path):
-            with open(pmc_path) as f:
+        if args.pmc_json and os.path.exists(args.pmc_json):
+            with open(args.pmc_json) as f:
                 pmc = json.load(f)
         top_launch = None
         if top is not None:
             top_tf = top[3] / top[2] if top[2] > 0 else 0.0  # GFLOP / ms = TFLOP/s
             top_launch = {"layer": top[1], "alg_gflop": round(top[3], 3), "ms": round(top[2], 4), "achieved": round(top_tf, 2),
-                          "frac": round(top_tf / PEAK_FP32_MFMA_TFLOPS, 4),
-                          "alg_bytes": pmc.get("algorithmic_bytes_total"), "traffic_bytes": pmc.get("traffic_bytes_per_launch"),
-                          "traffic_source": "profiles/r01_pmc_dc_conv21.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
-                          if pmc else None}
+                          "frac": round(top_tf / PEAK_FP32_MFMA_TFLOPS, 4)}
         roofline = {"bound": "mfma",
                     "kernel": "conv_igemm_dma_kernel / conv_igemm_kernel / conv_tile_kernel / conv_wgrad_kernel (v_mfma_f32_32x32x2_f32, "
-                              "16x16x4 for <=16 output channels): every "
-                              "convolution launch of one step, timed stand-alone (serial pass)",
+                              "16x16x4 for <=16 output channels): every convolution launch of one step, timed stand-alone with HIP "
+                              "events on the launch stream (serial pass)",
                     "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
-                    "traffic": pmc.get("traffic_bytes_per_launch"),
-                    "traffic_scope": "HBM bytes of the largest launch (top_launch), PMC-derived; algorithmic bytes of that launch: "
-                                     "%s" % pmc.get("algorithmic_bytes_total") if pmc else None,
-                    "launch_groups_per_step": int(conv_groups), "avg_group_ms": round(conv_ms / conv_groups, 4),
-                    "alg_gflop_per_step": round(alg_flops / 1e9, 2), "conv_ms_per_step_serial": round(conv_ms, 3),
-                    # the launches' own FLOP count: below the algorithmic figure because the image encoder of the three
-                    # recover calls is evaluated once (identical input), not three times
-                    "executed_gflop_per_step": round(sum(l[3] for l in layers if l[0] < 3), 2),
-                    "top_launch": top_launch}
+                    "numerator": "executed GFLOP of the launches (recover encoder A once, not three times)",
+                    "executed_gflop_per_step": round(exe_flops / 1e9, 2), "alg_gflop_per_step": round(alg_flops / 1e9, 2),
+                    "achieved_algorithmic": round(alg_flops / (conv_ms * 1e-3) / 1e12, 2),
+                    # HBM bytes per launch from PMC counters are collected offline (tools/pmc_report.py, separate rocprofv3 --pmc
+                    # passes, summaries under profiles/); filled here only from a --pmc-json of this build, else null
+                    "traffic": pmc.get("traffic_bytes_per_launch"), "traffic_source": args.pmc_json or None,
+                    "launch_groups_per_step": int(conv_groups), "avg_group_ms": round(conv_ms / max(conv_groups, 1), 4),
+                    "conv_ms_per_step_serial": round(conv_ms, 3), "top_launch": top_launch}
         hbm = {}
-        for c in ("warp", "cost_volume"):
-            p = prof[c]
-            gbs = p["bytes"] / (p["ms"] * 1e-3) / 1e9 if p["ms"] > 0 else 0.0
-            hbm[c] = {"alg_MB_per_step": round(p["bytes"] / 1e6, 2), "ms_per_step": round(p["ms"], 4), "launches": int(p["groups"]),
-                      "achieved_GBs": round(gbs, 1), "frac_of_8TBs": round(gbs / PEAK_HBM_GBS, 4)}
-            # the pyramid levels differ 64x in size and the small ones are bound by launch latency: report the largest too
-            big = max((l for l in layers if l[0] == (3 if c == "warp" else 4)), key=lambda l: l[4], default=None)
+        p = prof["cost_volume"]
+        if p["ms"] > 0:
+            gbs = p["bytes"] / (p["ms"] * 1e-3) / 1e9
+            hbm["warp_cost_volume"] = {"kernel": "warp_cost_volume_kernel (dense_image_warp + cost_volume + c1 slab segment in one launch per "
+                                                 "pyramid level)",
+                                       "alg_MB_per_step": round(p["bytes"] / 1e6, 2), "ms_per_step": round(p["ms"], 4), "launches": int(p["groups"]),
+                                       "achieved_GBs": round(gbs, 1), "frac_of_8TBs": round(gbs / PEAK_HBM_GBS, 4)}
+            big = max((l for l in layers if l[0] == 4), key=lambda l: l[4], default=None)
             if big is not None and big[2] > 0:
-                hbm[c]["largest_launch"] = {"alg_MB": round(big[4], 2), "ms": round(big[2], 4),
-                                            "achieved_GBs": round(big[4] / big[2], 1), "frac_of_8TBs": round(big[4] / big[2] / PEAK_HBM_GBS, 4)}
+                hbm["warp_cost_volume"]["largest_launch"] = {"level": big[1], "alg_MB": round(big[4], 2), "ms": round(big[2], 4),
+                                                             "achieved_GBs": round(big[4] / big[2], 1),
+                                                             "frac_of_8TBs": round(big[4] / big[2] / PEAK_HBM_GBS, 4)}
         out = {
             "metric": "frame-pairs/sec per adversarial step, DAVIS 480p batch4, 1/2/4/8 GPU",
             "value": round(pairs_per_s, 3), "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -265,22 +366,30 @@ def main():
                        "alg_gflop_per_pair": ALG_GFLOP_PER_PAIR},
             "step_tflops_algorithmic": round(alg_flops * world / (ms * 1e-3) / 1e12, 2),
             "roofline": roofline, "hbm_kernels": hbm,
-            "profile_ms_per_step_serial": {k: round(v["ms"], 3) for k, v in prof.items()},
-            "execution": {"autotuned_shapes": getattr(st, "tuned_shapes", 0), "pipelined": nxt is not None,
+            "profile_ms_per_step_serial": {k: round(v["ms"], 3) for k, v in prof.items() if v["groups"] > 0},
+            "execution": {"autotuned_shapes": getattr(st, "tuned_shapes", 0) or loaded, "tuned_configurations_loaded": loaded,
+                          "tune_rejected": int(lib.udet_tune_rejected()), "pipelined": nxt is not None,
                           "note": "step = forward(prefetched PWC flow) + PWC flow of the next pair beside both backward passes "
                                   "+ 2 applies; every timed step contains all of that work exactly once"},
+            "allreduce_ms": allreduce_ms,
             "reference_schedule": ref_cycle,
+            "ensemble": ensemble,
             "losses": {k: round(v, 5) for k, v in losses.items()},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.batch, args.cpu_reps)
+        if w0 is not None:
+            out["cpu_baseline"], out["parity_check"] = cpu_baseline(w0, img1.cpu(), img2.cpu(), gpu_first, args.cpu_reps)
+            if not out["parity_check"]["ok"]:
+                rc = 1
         else:
-            out["cpu_baseline"] = None
+            out["cpu_baseline"], out["parity_check"] = None, None
         print(json.dumps(out), flush=True)
+        if rc:
+            print("bench.py: PARITY CHECK FAILED: %s" % json.dumps(out["parity_check"]), file=sys.stderr, flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return rc
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

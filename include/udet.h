@@ -201,6 +201,10 @@ int udet_recover_forward(udet_plan* plan, int n, void* workspace, void* stream);
  * (models/utils/loss_utils.py:18; adversarial_learner.py:211-234) into the flat gradient buffers. */
 int udet_backward(udet_plan* plan, int which, const float* w_gen, const float* w_rec, float* g_gen, float* g_rec,
                   void* workspace, void* stream);
+/* Data-parallel overlap: makes `stream` (a communication stream) wait until the flat gradient buffer of `net` written by the
+ * last udet_backward is final -- with which=3 the recover gradients are final while the longer generator-loss pass still
+ * runs, so their all-reduce overlaps it. */
+int udet_stream_wait_grads(udet_plan* plan, int net, void* stream);
 /* the two passes alone: train_generator_op / train_recover_op's compute_gradients (adversarial_learner.py:224-234) */
 int udet_generator_backward(udet_plan* plan, const float* w_gen, float* g_gen, void* workspace, void* stream);
 int udet_recover_backward(udet_plan* plan, const float* w_rec, float* g_rec, void* workspace, void* stream);
@@ -228,6 +232,11 @@ int udet_train_step(udet_plan* plan, int which, const float* img1, const float* 
 int udet_autotune(udet_plan* plan, const float* w_gen, const float* w_rec, float* g_gen, float* g_rec, void* workspace,
                   void* stream);
 int udet_tuned_shapes(void);
+/* The tuned configurations as a text file (keys are hashes of the problem shapes): a later process loads them instead of
+ * tuning again, e.g. a rocprofv3 trace that should contain timed steps only.  udet_tune_load returns the number of entries
+ * read (>= 0) or an error code; entries are trusted (they were verified when they were tuned). */
+int udet_tune_save(const char* path);
+int udet_tune_load(const char* path);
 /* Measurement aid (bench.py): between begin/end every convolution / warp / cost-volume launch group is
  * bracketed by HIP events on the launch stream.  out[cat*4 + {0,1,2,3}] = {groups, total ms, algorithmic
  * FLOPs, algorithmic bytes} for cat 0 conv fwd, 1 conv dgrad, 2 conv wgrad, 3 warp, 4 cost volume. */

@@ -27,3 +27,4 @@ def test_two_ranks_complete_and_report_once():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and out["config"]["global_batch"] == 8
     assert out["value"] > 0 and out["roofline"]["frac"] > 0 and out["reference_schedule"]["cycles"] == 1
+    assert out["allreduce_ms"] is not None and out["allreduce_ms"] > 0 and out["parity_check"] is None

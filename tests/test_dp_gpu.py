@@ -1,0 +1,28 @@
+"""GPU: the data-parallel contract of the real engine on a one-GPU box (tools/dp_check.py): two ranks share cuda:0, gradients
+are averaged over gloo, and after the schedule BOTH, REC, GEN, BOTH (a) the replicas' weights and Adam slots are bit-identical
+and (b) they equal a single process training on the concatenated global batch within 1e-6 -- once with the default epsilon and
+once with every generator step forced onto the escape-noise branch (loss_utils.py:19-26)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("epsilon,noise_steps", [(75.0, 0), (1e15, 3)])
+def test_replicas_stay_identical_and_match_the_global_batch(epsilon, noise_steps):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29544", os.path.join(ROOT, "tools", "dp_check.py"), "--epsilon", repr(epsilon)]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-2500:])
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["ok"] and out["replicas_bit_identical"] and out["world"] == 2
+    assert out["generator_steps_on_the_noise_branch"] == noise_steps

@@ -56,6 +56,32 @@ def test_cost_volume(ops, n, h, w, c):
     assert (out - ref).abs().max() < 1e-5
 
 
+
+@pytest.mark.parametrize("n,h,w,c,scale", [(4, 12, 20, 128, 0.625), (4, 24, 40, 96, 1.25), (2, 48, 80, 64, 2.5),
+                                           (1, 96, 160, 32, 5.0), (2, 13, 21, 36, 1.0), (1, 5, 7, 4, 1.0)])
+def test_fused_warp_cost_volume_is_bit_identical_to_the_two_kernels(ops, n, h, w, c, scale):
+    """model_pwcnet.py:616-623 in one launch: the warped tensor (kept in LDS) and the correlation must equal udet_warp ->
+    udet_cost_volume bit for bit (same rounded grid-index math, same FMA order), and the oracle within 1e-5."""
+    c1, c2 = rnd(n, h, w, c, seed=31), rnd(n, h, w, c, seed=32)
+    flow = rnd(n, h, w, 2, seed=33, scale=2.0)
+    corr, warped = ops.warp_cost_volume(c1.cuda(), c2.cuda(), flow.cuda(), scale, return_warped=True)
+    w_ref = ops.dense_image_warp(c2.cuda(), flow.cuda(), scale)
+    assert torch.equal(warped, w_ref)
+    assert torch.equal(warped.cpu(), O.dense_image_warp(c2, flow * np.float32(scale)))
+    assert torch.equal(corr, ops.cost_volume(c1.cuda(), w_ref))
+    ref = O.cost_volume(c1, O.dense_image_warp(c2, flow * np.float32(scale)))
+    assert (corr.cpu() - ref).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize("n,h,w,c", [(4, 6, 10, 196), (1, 9, 11, 8)])
+def test_fused_cost_volume_without_warp(ops, n, h, w, c):
+    """level 6: cost_volume(c1, c2) (model_pwcnet.py:619-620) through the fused kernel with flow = None"""
+    c1, c2 = rnd(n, h, w, c, seed=34), rnd(n, h, w, c, seed=35)
+    corr = ops.warp_cost_volume(c1.cuda(), c2.cuda(), None)
+    assert torch.equal(corr, ops.cost_volume(c1.cuda(), c2.cuda()))
+    assert (corr.cpu() - O.cost_volume(c1, c2)).abs().max() < 1e-5
+
+
 CONV_CASES = [
     # n,h,w,cin,cout,k,s,d,act,alpha,up
     (2, 24, 40, 64, 128, 3, 1, 1, "leaky", 0.1, False),
@@ -137,7 +163,11 @@ FAMILIES = {"plain": (128 + (1 << 16), 32, 1), "wave_spec": (128, 32, 1), "lds_d
             "lds_dma_split3": (128 + (1 << 17), 32, 3), "tile8": ((1 << 18) + 8, 0, 1), "tile4": ((1 << 18) + 4, 0, 1),
             "self_staging": (128 + (1 << 19), 64, 1), "self_staging_128": (128 + (1 << 19), 128, 1),
             "self_staging_split2": (64 + (1 << 19), 64, 2), "self_staging_n32": (128 + (1 << 19), 32, 1),
-            "self_staging_256x32": (256 + (1 << 19), 32, 1)}
+            "self_staging_256x32": (256 + (1 << 19), 32, 1),
+            # split-K both ways: bit 21 = slabs summed by the last-arriving workgroup (ticket counter), bit 20 = second launch
+            "wave_spec_split4_fold": (128 + (1 << 21), 32, 4), "wave_spec_split4_2pass": (128 + (1 << 20), 32, 4),
+            "plain_split2_fold": (128 + (1 << 16) + (1 << 21), 32, 2), "lds_dma_split3_2pass": (128 + (1 << 17) + (1 << 20), 32, 3),
+            "lds_dma_split5_fold_64": (64 + (1 << 17) + (1 << 21), 64, 5), "self_staging_split2_2pass": (64 + (1 << 19) + (1 << 20), 64, 2)}
 THIN_CASES = [
     # n,h,w,cin,cout,k,s
     (1, 32, 64, 16, 16, 3, 1),    # 16-wide MFMA tile kernel
@@ -175,7 +205,9 @@ def force_conv():
 
 
 WS_OF = {"plain": 0, "wave_spec": 1, "lds_dma": 2, "lds_dma_split3": 2, "tile8": 3, "tile4": 3, "self_staging": 6,
-         "self_staging_128": 6, "self_staging_split2": 6, "self_staging_n32": 6, "self_staging_256x32": 6}
+         "self_staging_128": 6, "self_staging_split2": 6, "self_staging_n32": 6, "self_staging_256x32": 6,
+         "wave_spec_split4_fold": 1, "wave_spec_split4_2pass": 1, "plain_split2_fold": 0, "lds_dma_split3_2pass": 2,
+         "lds_dma_split5_fold_64": 2, "self_staging_split2_2pass": 6}
 
 
 @pytest.mark.parametrize("family", list(FAMILIES))
@@ -193,6 +225,9 @@ def test_conv_kernel_families(ops, force_conv, family, case):
     got = ops.conv2d(x.detach().float().cuda(), wt.float().cuda(), b.float().cuda(), s, 1, "leaky", 0.1, False).cpu()
     if WS_OF[family] != 3 or _tile_fits(8 if family == "tile8" else 4, cin, cout, k, s):
         assert (force_conv.udet_debug_last_conv() & 0xff) == WS_OF[family]  # the family under test really ran
+    if "_fold" in family or "_2pass" in family:  # ... with the split count and the summation mode asked for
+        last = force_conv.udet_debug_last_conv()
+        assert (last >> 20) & 0xff > 1 and (last >> 28) & 1 == (1 if "_fold" in family else 0)
     assert (got - y.detach().float()).abs().max() < 1e-4 * max(1.0, float(y.abs().max()))
     # backward-data of the linear layer (no act' on load: the form the step uses, dU being materialised by its producer)
     dx = ops.conv2d_backward_data(dy.float().cuda(), lin.detach().float().cuda(), wt.float().cuda(), (h, w), s, 1, "none", 0.0).cpu()

@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Data-parallel consistency check of the real engine ("verify replicas stay bit-identical after N
+steps"), runnable on a ONE-GPU box: R ranks share cuda:0 and exchange gradients over gloo.
+
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29544 tools/dp_check.py
+
+Every rank trains the same seeded weights on ITS OWN frame pairs for the schedule BOTH, REC, GEN, BOTH (trainer.train_step:
+forward, backward, gradient mean over ranks, clip / escape noise, Adam).  Then
+  (a) the weights and Adam slots of all ranks must be bit-identical (torch.equal), and
+  (b) rank 0 repeats the schedule alone on the concatenated R*B batch; the result must agree within 1e-6:
+      grad(global batch) = mean over ranks of grad(local batch) is the whole data-parallel contract of the path.
+--epsilon 1e15 makes every generator step take the escape-noise branch of train_op (loss_utils.py:19-26: the generator
+gradient is ~1/epsilon, far below the 1e-5 threshold), whose |U(-0.2,0.2)| draws come from a counter-based stream keyed by
+(seed, step, index) and therefore must also be identical on every rank.  Prints one JSON line on rank 0; exit code 1 on failure."""
+import argparse
+import json
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def pairs(batch, seed, h, w):
+    g = torch.Generator().manual_seed(seed)
+    a = torch.rand(batch, h, w, 3, generator=g) - 0.5
+    b = torch.rand(batch, h, w, 3, generator=g) - 0.5
+    return a, b
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=2)
+    ap.add_argument("--epsilon", type=float, default=75.0)
+    ap.add_argument("--in-hw", type=int, nargs=2, default=(128, 192))
+    ap.add_argument("--img-hw", type=int, nargs=2, default=(64, 128))
+    args = ap.parse_args()
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo")
+    from unsupervised_detection_amd.engine import BOTH, GEN, REC, Engine, EngineConfig
+    from unsupervised_detection_amd.trainer import TrainState, train_step
+
+    def cfg(b):
+        return EngineConfig(batch_size=b, in_height=args.in_hw[0], in_width=args.in_hw[1], img_height=args.img_hw[0],
+                            img_width=args.img_hw[1], epsilon=args.epsilon)
+    schedule = (BOTH, REC, GEN, BOTH)
+    data = [pairs(args.batch, 1000 + 10 * s + r, *args.in_hw) for s in range(len(schedule)) for r in range(world)]  # [step][rank]
+    st = TrainState(Engine(cfg(args.batch)), seed=5)
+    noise_steps = 0
+    for s, which in enumerate(schedule):
+        a, b = data[s * world + rank]
+        train_step(st, a.cuda(), b.cuda(), which)
+        if which & GEN:
+            noise_steps += int(float(st.engine.buffer("noise_flag").view(-1)[1]) != 0.0)
+    torch.cuda.synchronize()
+    mine = {k: getattr(st, k).cpu() for k in ("w_gen", "w_rec", "m_gen", "v_gen", "m_rec", "v_rec")}
+    identical = True
+    for k, t in mine.items():
+        gathered = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
+        identical = identical and all(torch.equal(gathered[0], g) for g in gathered[1:])
+    ok, report = True, None
+    if rank == 0:
+        ref = TrainState(Engine(cfg(args.batch * world)), seed=5)
+        for s, which in enumerate(schedule):
+            a = torch.cat([data[s * world + r][0] for r in range(world)], 0)
+            b = torch.cat([data[s * world + r][1] for r in range(world)], 0)
+            train_step(ref, a.cuda(), b.cuda(), which, group=False)
+        torch.cuda.synchronize()
+        diff = {k: float((mine[k] - getattr(ref, k).cpu()).abs().max()) for k in ("w_gen", "w_rec")}
+        ok = identical and all(v <= 1e-6 for v in diff.values())
+        report = {"world": world, "local_batch": args.batch, "schedule": "BOTH,REC,GEN,BOTH", "epsilon": args.epsilon,
+                  "replicas_bit_identical": identical, "generator_steps_on_the_noise_branch": noise_steps,
+                  "max_abs_diff_vs_single_process_global_batch": diff, "ok": ok}
+        print(json.dumps(report), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

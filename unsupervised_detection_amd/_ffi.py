@@ -61,7 +61,10 @@ _sig("udet_generator_layers", c_i, c_p, c_p, c_p)
 _sig("udet_generator_backward", c_i, c_p, c_p, c_p, c_p, c_p)
 _sig("udet_recover_backward", c_i, c_p, c_p, c_p, c_p, c_p)
 _sig("udet_grad_absmean", c_i, c_p, c_i, c_p, c_p, c_p, c_p)
+_sig("udet_stream_wait_grads", c_i, c_p, c_i, c_p)
 _sig("udet_tune_rejected", c_i)
+_sig("udet_tune_save", c_i, ctypes.c_char_p)
+_sig("udet_tune_load", c_i, ctypes.c_char_p)
 
 
 class UdetError(RuntimeError):

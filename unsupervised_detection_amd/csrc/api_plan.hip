@@ -140,6 +140,34 @@ int udet_autotune(udet_plan* h, const float* w_gen, const float* w_rec, float* g
   return rc;
 }
 int udet_tuned_shapes(void) { return conv_tuned_shapes() + wgrad_tuned_shapes(); }
+int udet_tune_save(const char* path) {
+  FILE* f = path ? fopen(path, "w") : nullptr;
+  if (!f) { set_error("tune_save: cannot open %s", path ? path : "(null)"); return UDET_ERR_ARG; }
+  fprintf(f, "udet-tune 1\n");
+  conv_tune_dump(f);
+  wgrad_tune_dump(f);
+  fclose(f);
+  return UDET_OK;
+}
+int udet_tune_load(const char* path) {
+  FILE* f = path ? fopen(path, "r") : nullptr;
+  if (!f) { set_error("tune_load: cannot open %s", path ? path : "(null)"); return UDET_ERR_ARG; }
+  char line[256];
+  int n = 0, ver = 0;
+  if (!fgets(line, sizeof(line), f) || sscanf(line, "udet-tune %d", &ver) != 1 || ver != 1) {
+    fclose(f);
+    set_error("tune_load: %s is not a udet-tune 1 file", path);
+    return UDET_ERR_ARG;
+  }
+  while (fgets(line, sizeof(line), f)) {
+    unsigned long long key;
+    int a, b, c, d, e;
+    if (sscanf(line, "c %llu %d %d %d %d %d", &key, &a, &b, &c, &d, &e) == 6) { conv_tune_put(key, a, b, c, d, e); ++n; }
+    else if (sscanf(line, "w %llu %d", &key, &a) == 2) { wgrad_tune_put(key, a); ++n; }
+  }
+  fclose(f);
+  return n;
+}
 
 /* profiling: per-category HIP-event timing of the conv / warp / cost-volume launches */
 int udet_profile_begin(udet_plan* h) {
@@ -190,6 +218,13 @@ int udet_grad_absmean(udet_plan* h, int net, const float* g, float* out2, void* 
   const NetParams& np = net_params(net);
   const long* tab = reinterpret_cast<const long*>(ws + P->seg_off[net]);
   return launch_grad_absmean(g, tab, tab + np.p.size(), (int)np.p.size(), ws + P->small_off + 2048, 1e-5f, out2, (hipStream_t)stream);
+}
+/* `stream` waits until the gradient buffer of `net` written by the last udet_backward is final (not for the other pass) */
+int udet_stream_wait_grads(udet_plan* h, int net, void* stream) {
+  if (net != NET_GEN && net != NET_REC) { set_error("stream_wait_grads: net must be 1 or 2"); return UDET_ERR_ARG; }
+  if (!h->p->grad_ev[net]) { set_error("stream_wait_grads: no udet_backward has produced that gradient yet"); return UDET_ERR_ARG; }
+  UDET_HIP(hipStreamWaitEvent((hipStream_t)stream, h->p->grad_ev[net], 0));
+  return UDET_OK;
 }
 int udet_tune_rejected(void) { return conv_tune_rejected(); }
 

@@ -15,7 +15,11 @@ void conv_tune_note_reject();
 float* tune_scratch(size_t floats, int which);
 bool tune_compare(const float* a, const float* b, size_t n, hipStream_t stream, float* diff_out, float* scale_out);
 void wgrad_set_tuning(int on);
-int wgrad_tuned_shapes();  // debugging / tuning hook: bm == 0 and ks < 0 restore the heuristics
+int wgrad_tuned_shapes();
+void conv_tune_dump(FILE* f);
+void conv_tune_put(unsigned long long key, int bm, int bn, int ks, int ws, int fold);
+void wgrad_tune_dump(FILE* f);
+void wgrad_tune_put(unsigned long long key, int cfg);  // debugging / tuning hook: bm == 0 and ks < 0 restore the heuristics
 bool conv_setup_dgrad(ConvParams& p, int cls, int N, int H, int W, int kh, int kw, int s, int d);
 int launch_pack_weights(const float* src, float* dst, int T, int R, int C, int Kc, int ldw, int k_split, int k_gap,
                         int mode, const float* scale, hipStream_t stream);

@@ -968,6 +968,17 @@ static void tune_scratch_free();
 void conv_set_tuning(int on) { g_tuning = on; if (!on) tune_scratch_free(); }
 int conv_tuned_shapes() { std::lock_guard<std::mutex> l(g_cache_mu); return (int)g_cache.size(); }
 void conv_clear_tuning() { std::lock_guard<std::mutex> l(g_cache_mu); g_cache.clear(); }
+// text form of the cache ("c <problem key> bm bn ks ws fold" per line): lets a second process (a rocprofv3 trace of timed
+// steps only) run exactly the configurations a tuning run picked
+void conv_tune_dump(FILE* f) {
+  std::lock_guard<std::mutex> l(g_cache_mu);
+  for (auto& kv : g_cache)
+    fprintf(f, "c %llu %d %d %d %d %d\n", (unsigned long long)kv.first, kv.second.bm, kv.second.bn, kv.second.ks, kv.second.ws, kv.second.fold);
+}
+void conv_tune_put(unsigned long long key, int bm, int bn, int ks, int ws, int fold) {
+  std::lock_guard<std::mutex> l(g_cache_mu);
+  g_cache[(uint64_t)key] = ConvCfg{bm, bn, ks, ws, fold};
+}
 
 // ---- candidate verification -------------------------------------------------------------------------------------------
 // The tuner selects on time; a configuration that is fast because it computes something else must never be cached.  Before

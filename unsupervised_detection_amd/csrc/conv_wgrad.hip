@@ -418,6 +418,14 @@ static std::mutex g_wcache_mu;
 static int g_wtuning = 0;
 void wgrad_set_tuning(int on) { g_wtuning = on; }
 int wgrad_tuned_shapes() { std::lock_guard<std::mutex> l(g_wcache_mu); return (int)g_wcache.size(); }
+void wgrad_tune_dump(FILE* f) {
+  std::lock_guard<std::mutex> l(g_wcache_mu);
+  for (auto& kv : g_wcache) fprintf(f, "w %llu %d\n", (unsigned long long)kv.first, kv.second);
+}
+void wgrad_tune_put(unsigned long long key, int cfg) {
+  std::lock_guard<std::mutex> l(g_wcache_mu);
+  g_wcache[(uint64_t)key] = cfg;
+}
 
 template <int BM, int BN, int WM_, int WN_>
 static void wgrad_launch(const WgradParams& p, int m_tiles, int co_tiles, int nsplit, bool dma, hipStream_t stream) {

@@ -77,6 +77,7 @@ struct Plan {
   enum { NLANE = 6 };
   hipStream_t side[NLANE - 1] = {nullptr, nullptr, nullptr, nullptr, nullptr};
   hipEvent_t prefetch_ev = nullptr;  // completion of the last udet_prefetch_flow (lane 4)
+  hipEvent_t grad_ev[3] = {nullptr, nullptr, nullptr};  // [net]: that network's gradient buffer is final (last udet_backward)
   bool prefetch_pending = false;
   std::vector<hipEvent_t> ev_pool, ev_pool_prefetch;  // recycled per call (step) / per prefetch
   size_t ev_next = 0, ev_next_prefetch = 0;

@@ -686,19 +686,30 @@ static int backward_generator(Plan* P, const float* w_gen, float* g_gen, float* 
 int plan_backward(Plan* P, int which, const float* w_gen, const float* w_rec, float* g_gen, float* g_rec, float* ws, hipStream_t s) {
   P->ev_next = 0;
   const Lane L0 = lane_of(P, s, 0), L1 = lane_of(P, s, 1), L2 = lane_of(P, s, 2), L3 = lane_of(P, s, 3);
+  // grad_ev[net]: recorded where that network's flat gradient buffer is final, BEFORE the caller's stream joins the other
+  // pass -- a communication stream that waits on it (udet_stream_wait_grads) can exchange the recover gradients while the
+  // (longer) generator-loss pass is still running
+  auto mark = [&](int net) {
+    if (!P->grad_ev[net]) (void)hipEventCreateWithFlags(&P->grad_ev[net], hipEventDisableTiming);
+    (void)hipEventRecord(P->grad_ev[net], s);
+  };
   if (which == 3) {
     order_after(P, L0, L1);
     UDET_TRY(backward_recover(P, w_rec, g_rec, ws, L0, L2));
     UDET_TRY(backward_generator(P, w_gen, g_gen, ws, L1, L3));
-    order_after(P, L1, L0);
     order_after(P, L2, L0);
+    mark(NET_REC);
+    order_after(P, L1, L0);
     order_after(P, L3, L0);
+    mark(NET_GEN);
   } else if (which == 2) {
     UDET_TRY(backward_recover(P, w_rec, g_rec, ws, L0, L2));
     order_after(P, L2, L0);
+    mark(NET_REC);
   } else {
     UDET_TRY(backward_generator(P, w_gen, g_gen, ws, L0, L3));
     order_after(P, L3, L0);
+    mark(NET_GEN);
   }
   return UDET_OK;
 }

@@ -135,16 +135,29 @@ class Engine:
         check(lib.udet_pack_trainable(self._h, _ptr(w_gen), _ptr(w_rec), self.ws.data_ptr(), self._stream()))
 
     # ---- forward -------------------------------------------------------------------------
+    def _check_pair(self, img1, img2):
+        """The plan is specialised to one batch shape and the kernels read exactly that many bytes: a short last batch of a
+        one-pass reader (or any other shape) must be rejected here, not read out of bounds on the device."""
+        c = self.cfg
+        want = (c.batch_size, c.in_height, c.in_width, 3)
+        for name, t in (("img1", img1), ("img2", img2)):
+            if tuple(t.shape) != want:
+                raise ValueError("%s has shape %s, this plan takes %s (pad the last batch of a one-pass reader: "
+                                 "learner.pad_batch)" % (name, tuple(t.shape), want))
+
     def pwc_forward(self, img1, img2):
+        self._check_pair(img1, img2)
         check(lib.udet_pwc_forward(self._h, _ptr(img1), _ptr(img2), self.ws.data_ptr(), self._stream()))
         return self.buffer("flow_full")
 
     def forward(self, img1, img2, ncalls=3):
+        self._check_pair(img1, img2)
         check(lib.udet_forward(self._h, _ptr(img1), _ptr(img2), ncalls, self.ws.data_ptr(), self._stream()))
 
     def prefetch_flow(self, img1, img2):
         """PWC flow + resizes of the NEXT step's pair on the plan's side streams (PWC-Net is frozen); overlaps whatever
         is enqueued next.  Keep img1/img2 alive until forward_prefetched()."""
+        self._check_pair(img1, img2)
         self._prefetch_keep = (img1, img2)
         check(lib.udet_prefetch_flow(self._h, _ptr(img1), _ptr(img2), self.ws.data_ptr(), self._stream()))
 
@@ -162,6 +175,8 @@ class Engine:
         self._prefetch_keep = None
 
     def forward_from_flow(self, image, flow, ncalls=3):
+        if tuple(image.shape) != tuple(self.buffer("image").shape) or tuple(flow.shape) != tuple(self.buffer("flow").shape):
+            raise ValueError("image / flow must be %s / %s" % (tuple(self.buffer("image").shape), tuple(self.buffer("flow").shape)))
         self.buffer("image").copy_(image)
         self.buffer("flow").copy_(flow)
         check(lib.udet_forward_from_flow(self._h, ncalls, self.ws.data_ptr(), self._stream()))
@@ -179,6 +194,7 @@ class Engine:
         check(lib.udet_apply(self._h, net, _ptr(w), _ptr(g), _ptr(m), _ptr(v), self.ws.data_ptr(), self._stream()))
 
     def train_step(self, which, img1, img2, w_gen, w_rec, g_gen, g_rec, m_gen, v_gen, m_rec, v_rec):
+        self._check_pair(img1, img2)
         check(lib.udet_train_step(self._h, which, _ptr(img1), _ptr(img2), _ptr(w_gen), _ptr(w_rec), _ptr(g_gen), _ptr(g_rec),
                                   _ptr(m_gen), _ptr(v_gen), _ptr(m_rec), _ptr(v_rec), self.ws.data_ptr(), self._stream()))
 

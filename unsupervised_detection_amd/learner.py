@@ -36,6 +36,23 @@ def _engine_config(config, batch=None, in_hw=(384, 640)):
                         cbn=g("cbn", 0.5), epsilon=g("epsilon", 75.0), beta1=g("beta1", 0.9))
 
 
+def pad_batch(batch, batch_size):
+    """A one-pass reader (test_inputs, drop_remainder=False) ends with a short batch; the plans are batch-specialised, so the
+    last batch is padded by repeating its final sample.  Returns (padded batch, number of valid rows): callers evaluate
+    only the valid rows."""
+    n = batch["img1"].shape[0]
+    if n == batch_size:
+        return batch, n
+    if n > batch_size:
+        raise ValueError("batch of %d pairs for a plan of %d" % (n, batch_size))
+    out = dict(batch)
+    for k in ("img1", "img2", "gt_mask"):
+        t = batch.get(k)
+        if t is not None:
+            out[k] = torch.cat([t, t[-1:].expand(batch_size - n, *t.shape[1:])], 0).contiguous()
+    return out, n
+
+
 class _SyntheticSource:
     def __init__(self, batch, n_batches, seed=8964):
         self.batch, self.n, self.seed = batch, n_batches, seed
@@ -152,16 +169,19 @@ class AdversarialLearner(object):
         graph's generator on each pair, disambiguated masks against gt > 0.01."""
         from .evaluation import compute_all_IoU
         e = self.engine
-        total, steps = 0.0, 0
+        total, steps, samples = 0.0, 0, 0
         for batch in source:
             if n_steps is not None and steps >= n_steps:
                 break
             if batch.get("gt_mask") is None:
                 continue
+            batch, valid = pad_batch(batch, e.cfg.batch_size)
             e.forward(batch["img1"], batch["img2"], 0)
-            total += float(compute_all_IoU(e.buffer("mask").contiguous(), self._resize_gt(batch["gt_mask"]).contiguous()).sum())
+            total += float(compute_all_IoU(e.buffer("mask")[:valid].contiguous(), self._resize_gt(batch["gt_mask"])[:valid].contiguous()).sum())
             steps += 1
-        return total / max(steps * self.config.batch_size, 1)
+            samples += valid
+        # the reference divides by steps * batch_size (its repeat()ed reader never yields a short batch); equal when none is short
+        return total / max(samples, 1)
 
     def epoch_end_callback(self, epoch_num):
         """:422-448: validation IoU over `config.val_source` (when given), 'best' checkpoint when it improves, periodic
@@ -206,8 +226,11 @@ class AdversarialLearner(object):
         4-crop graph (batch 1, generator only, :525-592)."""
         self.config = config
         self.aug_test = aug_test
+        # the augmented graph feeds ONE frame pair (batch 1, :547) through four central crops: here the crops are the batch of
+        # one plan, so a frame costs one PWC-Net + generator pass at batch 4 instead of four passes at batch 1 (every op of
+        # the path is per sample, so the masks are the same numbers)
         B = 1 if aug_test else config.batch_size
-        self.engine = Engine(_engine_config(config, B))
+        self.engine = Engine(_engine_config(config, len(TEST_CROPS) if aug_test else B))
         self.state = TrainState(self.engine, seed=getattr(config, "seed", 8964), **self._load_weights(config))
         source = getattr(config, "data_source", None) or _SyntheticSource(B, 4)
         self.test_iterator = iter(source)
@@ -235,22 +258,25 @@ class AdversarialLearner(object):
         e = self.engine
         if self.aug_test:
             outs = {"pred_masks": {}, "gt_masks": {}, "img_1s": {}}
-            for crop in self.test_crops:
-                i1 = self._central_crop_resize(batch["img1"], crop)
-                i2 = self._central_crop_resize(batch["img2"], crop)
-                e.forward(i1, i2, 0)
-                outs["pred_masks"][crop] = e.buffer("mask")[0].cpu().numpy()
-                outs["img_1s"][crop] = e.buffer("image")[0].cpu().numpy()
-                gt = batch.get("gt_mask")  # seg_1s[crop]: central_cropping of the annotation (bilinear, :348), then nearest
+            if batch["img1"].shape[0] != 1:
+                raise ValueError("the augmented test graph takes one frame pair per step (adversarial_learner.py:547)")
+            i1 = torch.cat([self._central_crop_resize(batch["img1"], crop) for crop in self.test_crops], 0)
+            i2 = torch.cat([self._central_crop_resize(batch["img2"], crop) for crop in self.test_crops], 0)
+            e.forward(i1, i2, 0)
+            masks, images = e.buffer("mask").cpu().numpy(), e.buffer("image").cpu().numpy()
+            gt = batch.get("gt_mask")  # seg_1s[crop]: central_cropping of the annotation (bilinear, :348), then nearest
+            for k, crop in enumerate(self.test_crops):
+                outs["pred_masks"][crop] = masks[k]
+                outs["img_1s"][crop] = images[k]
                 outs["gt_masks"][crop] = None if gt is None else \
                     self._resize_gt(self._central_crop_resize(gt, crop))[0].cpu().numpy()
             return {"outs": outs, "img_fname": batch["fname"][0]}
+        batch, n = pad_batch(batch, e.cfg.batch_size)  # short last batch of a one-pass reader: only its valid rows are returned
         e.forward(batch["img1"], batch["img2"], 1)
-        B = e.cfg.batch_size
         gt = self._resize_gt(batch.get("gt_mask"))
-        return {"gen_masks": e.buffer("mask").cpu().numpy(), "pred_flow": e.buffer("pred")[:B].cpu().numpy(),
-                "input_image": e.buffer("image").cpu().numpy(), "gt_flow": e.buffer("flow").cpu().numpy(),
-                "gt_masks": None if gt is None else gt.cpu().numpy(), "img_fname": np.array(batch["fname"])}
+        return {"gen_masks": e.buffer("mask")[:n].cpu().numpy(), "pred_flow": e.buffer("pred")[:n].cpu().numpy(),
+                "input_image": e.buffer("image")[:n].cpu().numpy(), "gt_flow": e.buffer("flow")[:n].cpu().numpy(),
+                "gt_masks": None if gt is None else gt[:n].cpu().numpy(), "img_fname": np.array(batch["fname"])}
 
 
 # ---------------------------------------------------------------- functional API ----

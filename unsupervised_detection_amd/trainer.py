@@ -33,6 +33,7 @@ class TrainState:
         self.m_rec, self.v_rec = torch.zeros_like(self.w_rec), torch.zeros_like(self.w_rec)
         engine.pack_pwc(self.w_pwc)
         engine.pack_trainable(self.w_gen, self.w_rec)
+        self._dirty = 0  # networks whose flat weights changed since their last re-layout (GEN | REC bits)
         if autotune:
             self.tuned_shapes = engine.autotune(self.w_gen, self.w_rec, self.g_gen, self.g_rec)
 
@@ -40,13 +41,44 @@ class TrainState:
 def allreduce_mean_(t: torch.Tensor, group=None, async_op=False):
     """In-place mean over the data-parallel group (no-op without an initialised process group)."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return None
+    if group is False or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return None  # group=False: this process trains alone even though a process group exists (reference runs of the tests)
     if dist.get_backend(group) == "nccl":
         return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group, async_op=async_op)
     work = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=False)
     t.div_(dist.get_world_size(group))
     return work if async_op else None
+
+
+def _exchange_gradients(st: TrainState, which: int, group):
+    """grad(global batch) = mean over ranks of grad(local batch): the step's only collective(s).
+    RCCL ("nccl"), which=BOTH: the recover gradients are exchanged on a communication stream that waits only for THEIR
+    completion event (udet_stream_wait_grads), i.e. under the rest of the longer generator-loss pass; the generator gradients
+    follow when the whole backward is done.  Both collectives are issued in the same order on every rank.
+    Other backends (gloo in the tests) and single-network steps: one blocking exchange of what the step computed."""
+    import torch.distributed as dist
+    if group is False or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    e = st.engine
+    if which == BOTH and dist.get_backend(group) == "nccl":
+        from ._ffi import check, lib
+        comm = getattr(st, "_comm_stream", None)
+        if comm is None:
+            comm = st._comm_stream = torch.cuda.Stream(device=e.device)
+        check(lib.udet_stream_wait_grads(e._h, W.NET_REC, comm.cuda_stream))
+        with torch.cuda.stream(comm):
+            w_rec = dist.all_reduce(st.g_rec, op=dist.ReduceOp.AVG, group=group, async_op=True)
+        w_gen = dist.all_reduce(st.g_gen, op=dist.ReduceOp.AVG, group=group, async_op=True)
+        w_rec.wait()  # the compute stream waits for both before the optimizer applies
+        w_gen.wait()
+        return
+    if which == BOTH and getattr(st, "g_all", None) is not None:
+        allreduce_mean_(st.g_all, group)  # one collective for both networks
+        return
+    if which & REC:
+        allreduce_mean_(st.g_rec, group)
+    if which & GEN:
+        allreduce_mean_(st.g_gen, group)
 
 
 def train_step(st: TrainState, img1, img2, which: int = BOTH, group=None, next_pair=None):
@@ -58,7 +90,12 @@ def train_step(st: TrainState, img1, img2, which: int = BOTH, group=None, next_p
     streams right after this step's forward and overlaps its backward; the next call (which must be given that same
     pair) then starts from the prefetched flow.  Every step still does all of its work, one step earlier for PWC."""
     e = st.engine
-    e.pack_trainable(st.w_gen if which & GEN else None, st.w_rec if which & REC else None)
+    # re-layout of whichever network the PREVIOUS steps updated (every forward reads both networks, so a recover step right
+    # after a generator step must see the new generator too)
+    dirty = getattr(st, "_dirty", GEN | REC)
+    if dirty:
+        e.pack_trainable(st.w_gen if dirty & GEN else None, st.w_rec if dirty & REC else None)
+    st._dirty = 0
     if getattr(st, "_prefetched", None) is not None:
         p1, p2 = st._prefetched
         if p1.data_ptr() != img1.data_ptr() or p2.data_ptr() != img2.data_ptr():
@@ -76,18 +113,9 @@ def train_step(st: TrainState, img1, img2, which: int = BOTH, group=None, next_p
             st._prefetched = (next_pair[0], next_pair[1])
     # one call: with BOTH the two backward passes run concurrently on the plan's side streams (udet_backward)
     e.backward(which, st.w_gen, st.w_rec, st.g_gen, st.g_rec)
-    works = []
-    if which == BOTH and getattr(st, "g_all", None) is not None:
-        works.append(allreduce_mean_(st.g_all, group, async_op=True))  # one collective for both networks
-    else:
-        if which & REC:
-            works.append(allreduce_mean_(st.g_rec, group, async_op=True))
-        if which & GEN:
-            works.append(allreduce_mean_(st.g_gen, group, async_op=True))
-    for wk in works:
-        if wk is not None:
-            wk.wait()
+    _exchange_gradients(st, which, group)
     if which & GEN:
         e.apply(W.NET_GEN, st.w_gen, st.g_gen, st.m_gen, st.v_gen)
     if which & REC:
         e.apply(W.NET_REC, st.w_rec, st.g_rec, st.m_rec, st.v_rec)
+    st._dirty = which & (GEN | REC)
