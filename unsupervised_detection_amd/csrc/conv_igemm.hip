@@ -141,7 +141,7 @@ __device__ __forceinline__ void splitk_fold(const ConvParams& p, const int* rowo
   constexpr int C4 = BN / 4, ROWS = NT / C4;
   const int c4 = t % C4, n = n0 + c4 * 4;
   const size_t slab = (size_t)p.ncls * Mtot * p.ldp;
-  if (n < p.ldp) {
+  if (n < p.ldp && t < ROWS * C4) {  // (BN = 96: 240 of the 256 threads tile the [ROWS][C4] grid exactly)
     for (int row = t / C4; row < BM; row += ROWS) {
       const int off = rowoff[row];
       if (off < 0) continue;
