@@ -31,6 +31,7 @@ def _cfg(**kw):
     from unsupervised_detection_amd.config import default_flags
     c = default_flags()
     c.img_height, c.img_width, c.batch_size = 64, 128, 2
+    c.synthetic = True  # explicit opt-in: seeded random weights instead of the mandatory checkpoints
     for k, v in kw.items():
         setattr(c, k, v)
     return c
@@ -146,9 +147,52 @@ def test_cli_entry_points_run_on_synthetic_data(gpu, monkeypatch, capsys):
     monkeypatch.setattr(Lr._data, "READER_W", 192)
     monkeypatch.setattr(Lr._data, "preprocess_image", lambda f, out_h=128, out_w=192: Lr._data.crop_flip_resize(f, 128, 192, None, False, 255.0, -0.5))
     common = ["--img_height", "64", "--img_width", "128", "--batch_size", "2", "--root_dir", "/nonexistent"]
+    # like the reference, a missing dataset / flow checkpoint is an error (adversarial_learner.py:66-67,339-343) ...
+    with pytest.raises(IOError):
+        cli.main(["train"] + common)
+    with pytest.raises(IOError):
+        cli.main(["test_generator"] + common + ["--dataset", "FBMS"])
+    common = common + ["--synthetic"]  # ... unless synthetic pairs and seeded random weights are asked for
     assert cli.main(["train"] + common + ["--num_samples_train", "8", "--max_epochs", "1", "--summary_freq", "2"]) == 0
     out = capsys.readouterr().out
     assert "Training completed successfully" in out and "loss_generator" in out
     assert cli.main(["test_generator"] + common) == 0
     assert cli.main(["test_generator_ensemble"] + common) == 0
     assert cli.main(["bogus"]) == 2
+
+
+def test_checkpoint_policy(gpu, monkeypatch, tmp_path, capsys):
+    """save() stores every trainable variable the reference's Saver would (pwcnet/* included) + global_step; resume_train
+    restores the latest model-* of checkpoint_dir (or full_model_ckpt) incl. global_step; without resume_train
+    full_model_ckpt is not read; a checkpoint path given as its `.data-00000-of-00001` / `.index` file resolves to the prefix;
+    a missing flow checkpoint raises unless synthetic weights were asked for (adversarial_learner.py:339-360)."""
+    from unsupervised_detection_amd import learner as Lr
+    from unsupervised_detection_amd import weights as W
+    monkeypatch.setattr(Lr, "_engine_config", lambda config, batch=None, in_hw=(128, 192): Lr.EngineConfig(
+        batch_size=batch or config.batch_size, in_height=128, in_width=192, img_height=config.img_height, img_width=config.img_width))
+    ck = str(tmp_path / "ck")
+    lr = Lr.AdversarialLearner()
+    lr.train(_cfg(data_source=_Src(2, 8), num_samples_train=16, max_epochs=1, summary_freq=100, checkpoint_dir=ck, save_freq=1,
+                  save_tf_checkpoint=True))
+    saved = torch.load(ck + "/model-1")
+    names = set(saved)
+    for net in (W.NET_PWC, W.NET_GEN, W.NET_REC):
+        assert all(n in names for n, _, _ in W.param_table(net))
+    assert int(saved["global_step"]) == lr.global_step == 2
+    w_gen = lr.state.w_gen.clone()
+    # no flow checkpoint and no synthetic opt-in -> IOError, never a silent random PWC-Net
+    with pytest.raises(IOError):
+        Lr.AdversarialLearner()._load_weights(_cfg(synthetic=False), "train")
+    with pytest.raises(IOError):
+        Lr.AdversarialLearner()._load_weights(_cfg(synthetic=False, flow_ckpt=ck + "/model-1"), "test")  # ckpt_file missing
+    # resume: latest checkpoint of the directory, every network + global_step
+    lr2 = Lr.AdversarialLearner()
+    got = lr2._load_weights(_cfg(synthetic=False, flow_ckpt=ck + "/model-1", resume_train=True, checkpoint_dir=ck), "train")
+    assert set(got) == {"w_pwc", "w_gen", "w_rec"} and torch.equal(got["w_gen"], w_gen.cpu()) and lr2.global_step == 2
+    # not resuming: full_model_ckpt is ignored (the reference reads it only under resume_train)
+    got = Lr.AdversarialLearner()._load_weights(_cfg(synthetic=False, flow_ckpt=ck + "/model-1", full_model_ckpt=ck + "/model-1"), "train")
+    assert set(got) == {"w_pwc"}
+    # the TF-format export, addressed the way the reference's test script does (the .data file itself)
+    got = Lr.AdversarialLearner()._load_weights(_cfg(synthetic=False, flow_ckpt=ck + "/model-1.tf.data-00000-of-00001",
+                                                    ckpt_file=ck + "/model-1.tf.index"), "test")
+    assert torch.equal(got["w_gen"], w_gen.cpu()) and torch.equal(got["w_pwc"], lr.state.w_pwc.cpu())

@@ -5,8 +5,9 @@
   python -m unsupervised_detection_amd.cli test_generator_ensemble --root_dir ... --test_save_dir ...       (test_generator_ensemble.py)
 
 The TF-specific lines of the originals (tf.train.Saver / Supervisor, `train.py:19`, `test_generator.py:45-55`) have no
-counterpart; checkpoints are torch.save'd {tf_name: tensor} dicts.  Without a dataset under
---root_dir the learner falls back to synthetic DAVIS-shaped pairs."""
+counterpart; checkpoints are torch.save'd {tf_name: tensor} dicts.  Like the reference, a missing
+dataset, an unsupported --dataset or a missing --flow_ckpt is an IOError; --synthetic opts in to synthetic DAVIS-shaped pairs
+and seeded random weights (benchmarks, smoke runs)."""
 from __future__ import annotations
 
 import os
@@ -18,17 +19,26 @@ import numpy as np
 def _sources(flags, mode):
     """data_source / val_source of the learner from the dataset flags (DAVIS2016 layout; adversarial_learner.py:45-70)."""
     from . import data
+    if getattr(flags, "synthetic", False):
+        return
+    if flags.dataset != "DAVIS2016":
+        # the FBMS / SegTrackV2 directory layouts are not built (their per-image pipeline is the DAVIS one); never fall back silently
+        raise IOError("Dataset should be DAVIS2016 (FBMS / SEGTRACK readers are not built in this port)")
     root = getattr(flags, "root_dir", "")
     if not (root and os.path.isfile(os.path.join(root, "ImageSets", "480p", "val.txt"))):
-        return
+        raise IOError("Partition file not found under --root_dir {!r} (DAVIS2016 layout: ImageSets/480p/val.txt)".format(root))
+    import torch.distributed as dist
+    rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
     rd = data.Davis2016Reader(root, max_temporal_len=flags.max_temporal_len, min_temporal_len=flags.min_temporal_len,
-                              num_threads=flags.num_threads, seed=8964)
+                              num_threads=flags.num_threads, seed=8964 + rank)  # every rank draws its own pairs
     if mode == "train":
         flags.data_source = rd.image_inputs(batch_size=flags.batch_size, partition=flags.train_partition, train_crop=flags.train_crop)
 
         class _Val:
             def __iter__(self_inner):
-                return iter(rd.test_inputs(batch_size=flags.batch_size, partition="val", t_len=1, test_crop=1.0))
+                # adversarial_learner.py:34-37: the validation reader uses test_temporal_shift / test_crop
+                return iter(rd.test_inputs(batch_size=flags.batch_size, partition="val", t_len=flags.test_temporal_shift,
+                                           test_crop=flags.test_crop))
         flags.val_source = _Val()
     elif mode == "test":
         src = list(rd.test_inputs(batch_size=flags.batch_size, partition=flags.test_partition, t_len=flags.test_temporal_shift,

@@ -14,6 +14,9 @@ _DEFS = [
     ("test_temporal_shift", int, 1), ("ckpt_file", str, ""), ("test_partition", str, "val"), ("test_save_dir", str, ""),
     # not a reference flag: also write checkpoints in tf.train.Saver format under the reference's variable names
     ("save_tf_checkpoint", bool, False),
+    # not a reference flag: explicit opt-in to synthetic DAVIS-shaped pairs / seeded random weights when no dataset or checkpoint
+    # is given (the reference raises IOError in those cases, adversarial_learner.py:66-67,339-343; so does this port without it)
+    ("synthetic", bool, False),
 ]
 
 

@@ -132,12 +132,22 @@ __device__ __forceinline__ void igemm_store(const ConvParams& p, floatx16 (&acc)
 template <int BM, int BN, int NT>
 __device__ __forceinline__ void splitk_fold(const ConvParams& p, const int* rowoff, int* s_last, int t, int n0, int prow0, int Mtot,
                                             int tile_id) {
-  __threadfence();  // release: this thread's partial stores are visible device-wide before the ticket is drawn
+  // Release / acquire once per WORKGROUP, not per thread: every wave first waits until its own partial stores are
+  // acknowledged by this XCD's L2 (the vector L1 is write-through), the workgroup meets, and ONE wave performs the
+  // device-scope release (L2 write-back: the other XCDs' L2s are not coherent with this one) before it draws the ticket.
+  // The same wave performs the acquire (invalidate of this CU's L1 and this XCD's non-coherent L2 lines) for the workgroup
+  // that drew the last ticket; the second barrier orders the other waves' loads behind it.  A fence in every wave cost more
+  // than the second launch it replaces.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (t == 0) *s_last = atomicAdd(p.tickets + tile_id, 1) == p.ksplit - 1;
+  if (t == 0) {
+    __threadfence();
+    const int last = atomicAdd(p.tickets + tile_id, 1) == p.ksplit - 1;
+    if (last) __threadfence();
+    *s_last = last;
+  }
   __syncthreads();
   if (!*s_last) return;
-  __threadfence();  // acquire: the other workgroups' slabs (written through other XCDs' L2) are read from memory
   constexpr int C4 = BN / 4, ROWS = NT / C4;
   const int c4 = t % C4, n = n0 + c4 * 4;
   const size_t slab = (size_t)p.ncls * Mtot * p.ldp;
@@ -934,7 +944,8 @@ static ConvCfg heuristic_cfg(const ConvParams& p) {
     const int cap = max_ksplit(p), half = cap / 2 > 0 ? cap / 2 : 1;  // keep >= 4 stages per split
     c.ks = ks > half ? half : ks;
   }
-  c.fold = c.ks <= 16;  // the last-arriving workgroup sums the slabs alone: beyond ~16 slabs the chip-wide second pass is faster
+  c.fold = 0;  // measured (r2a): the release / acquire of the folded form costs more than the second launch on almost every shape;
+               // the tuner still tries it for its winner
   return c;
 }
 static int run_cfg(ConvParams& p, const ConvCfg& c, hipStream_t stream) {
@@ -1079,7 +1090,7 @@ static ConvCfg tune_cfg(ConvParams& p, hipStream_t stream) {
     for (int ks : kss) {
       if (ks > 1 && (tiles >= 512 || tiles * ks > 4096)) continue;
       if (tiles * ks < 96 && ks * 2 <= kcap) continue;  // hopelessly under-filled
-      cand.push_back({bm, bn, ks, 1, ks <= 16});
+      cand.push_back({bm, bn, ks, 1, 0});
     }
   }
   cand.push_back(h);
@@ -1119,10 +1130,15 @@ static ConvCfg tune_cfg(ConvParams& p, hipStream_t stream) {
     }
   }
   if (best.ks > 1 && best.ws != 3) {  // the other way of summing the slabs: last-arriving workgroup <-> second launch
-    ConvCfg d = best;
-    d.fold = !best.fold;
-    const float ms = time_cfg(p, d, 5, stream);
-    if (ms < (a < b ? a : b) * 0.98f) { a = b = ms; best = d; }
+    const ConvCfg w = best;
+    for (int ks : {w.ks, w.ks / 2, w.ks / 4}) {  // the folded form sums its slabs in one workgroup: fewer slabs may suit it better
+      if (ks < 2) continue;
+      ConvCfg d = w;
+      d.fold = !w.fold;
+      d.ks = ks;
+      const float ms = time_cfg(p, d, 5, stream);
+      if (ms < (a < b ? a : b) * 0.98f) { a = b = ms; best = d; }
+    }
   }
   // verification against the reference configuration on the tuning data (see above)
   if (best.bm != h.bm || best.bn != h.bn || best.ks != h.ks || best.ws != h.ws || best.fold != h.fold) {

@@ -36,6 +36,23 @@ def _engine_config(config, batch=None, in_hw=(384, 640)):
                         cbn=g("cbn", 0.5), epsilon=g("epsilon", 75.0), beta1=g("beta1", 0.9))
 
 
+def _latest_checkpoint(checkpoint_dir):
+    """tf.train.latest_checkpoint analogue for the files save() writes: the model-<epoch> with the largest epoch, else
+    model.best; '' when the directory holds none."""
+    import os
+    import re
+    if not (checkpoint_dir and os.path.isdir(checkpoint_dir)):
+        return ""
+    best, best_n = "", -1
+    for name in os.listdir(checkpoint_dir):
+        m = re.fullmatch(r"model-(\d+)", name)
+        if m and int(m.group(1)) > best_n:
+            best, best_n = os.path.join(checkpoint_dir, name), int(m.group(1))
+    if not best and os.path.isfile(os.path.join(checkpoint_dir, "model.best")):
+        best = os.path.join(checkpoint_dir, "model.best")
+    return best
+
+
 def pad_batch(batch, batch_size):
     """A one-pass reader (test_inputs, drop_remainder=False) ends with a short batch; the plans are batch-specialised, so the
     last batch is padded by repeating its final sample.  Returns (padded batch, number of valid rows): callers evaluate
@@ -71,39 +88,33 @@ class AdversarialLearner(object):
         self.state = None
 
     # ------------------------------------------------------------------ training ----
-    def _load_weights(self, config):
-        """Checkpoint policy of train() (:339-360) and of the test scripts (test_generator.py:45-55): PWC weights are
-        mandatory in the reference; here synthetic weights with the reference's initializers stand in when no file is
-        given (README.md:59-64 checkpoints are external downloads).  Accepted: a tf.train.Saver V2 checkpoint prefix
-        (`<prefix>.index` + `<prefix>.data-*`, read by tf_checkpoint.py), or {variable name: array} dicts -- torch.save'd, or
-        .npz -- under the TF checkpoint's own names ("MaskNet//conv1/kernel", "MaskNet//batch_normalization_3/gamma", ...;
-        optimizer slots and BN moving statistics are ignored) or the canonical ones of weights.param_table().
-          flow_ckpt        -> PWC-Net                       (flow_saver, :329)
-          recover_ckpt     -> recover net                   (recover_saver, :327)
-          full_model_ckpt  -> every network it holds        (self.saver = all trainable variables: resume_train, :346-353)
-          ckpt_file        -> every network it holds        (test_generator.py:45-55, test_generator_ensemble.py)"""
+    def _load_weights(self, config, mode="train"):
+        """Checkpoint policy of train() (:339-360) and of the test scripts (test_generator.py:45-55).  Accepted: a
+        tf.train.Saver V2 checkpoint prefix (`<prefix>.index` + `<prefix>.data-*`, read by tf_checkpoint.py; a path that names
+        the `.index` / `.data-00000-of-00001` file itself is reduced to its prefix, as the reference's own test script passes
+        it), or {variable name: array} dicts -- torch.save'd, or .npz -- under the TF checkpoint's own names
+        ("MaskNet//conv1/kernel", ...; optimizer slots and BN moving statistics are ignored) or the canonical ones of
+        weights.param_table().
+          flow_ckpt        -> PWC-Net, mandatory (flow_saver, :329,339-343; IOError when missing unless config.synthetic)
+          train, resume_train:      full_model_ckpt, else the latest model-* of checkpoint_dir -> every network + global_step (:345-353)
+          train, not resume_train:  recover_ckpt -> recover net (:354-356); full_model_ckpt is NOT read
+          test:            ckpt_file -> every network it holds (test_generator.py:45-55, test_generator_ensemble.py)"""
         import os
+        import re
+
+        def prefix_of(path):
+            return re.sub(r"\.(index|data-\d{5}-of-\d{5})$", "", path)
 
         def read(path):
-            if os.path.isfile(path + ".index"):  # a Saver prefix, e.g. pwcnet.ckpt-595000
+            pre = prefix_of(path)
+            if os.path.isfile(pre + ".index"):  # a Saver prefix, e.g. pwcnet.ckpt-595000
                 from .tf_checkpoint import read_checkpoint
-                return read_checkpoint(path), "restored from TF checkpoint"
+                return read_checkpoint(pre), "restored from TF checkpoint"
             if os.path.isfile(path):
                 return (dict(np.load(path)) if path.endswith(".npz") else torch.load(path, map_location="cpu")), "loaded from"
             raise IOError("Could not find checkpoint file {}. Aborting.".format(path))
 
-        out = {}
-        for key, flag, net in (("w_pwc", "flow_ckpt", W.NET_PWC), ("w_rec", "recover_ckpt", W.NET_REC)):
-            path = getattr(config, flag, "")
-            if path:
-                d, how = read(path)
-                out[key] = W.from_tf_dict(d, net)
-                print("{} {} {}".format(flag, how, path))
-        for flag in ("full_model_ckpt", "ckpt_file"):
-            path = getattr(config, flag, "")
-            if not path:
-                continue
-            d, how = read(path)
+        def restore_all(d, flag, path, how):
             found = []
             for key, net in (("w_pwc", W.NET_PWC), ("w_gen", W.NET_GEN), ("w_rec", W.NET_REC)):
                 try:
@@ -113,7 +124,43 @@ class AdversarialLearner(object):
                     pass  # this checkpoint does not hold that network
             if not found:
                 raise IOError("{} {} holds none of the networks' variables".format(flag, path))
+            for k in ("global_step", "train_op/global_step"):
+                if k in d:
+                    self.global_step = int(np.asarray(d[k]))
             print("{} {} {} ({})".format(flag, how, path, ", ".join(found)))
+
+        out = {}
+        synthetic = bool(getattr(config, "synthetic", False))
+        path = getattr(config, "flow_ckpt", "")
+        if path:
+            d, how = read(path)
+            out["w_pwc"] = W.from_tf_dict(d, W.NET_PWC)
+            print("Flow net loaded from {}".format(path))
+        if mode == "train":
+            if getattr(config, "resume_train", False):
+                ckpt = getattr(config, "full_model_ckpt", "")
+                if not ckpt:
+                    ckpt = _latest_checkpoint(getattr(config, "checkpoint_dir", ""))
+                assert ckpt, "Found no checkpoint to resume training!"
+                d, how = read(ckpt)
+                restore_all(d, "full_model_ckpt", ckpt, how)
+                print("Resumed training from model {}".format(ckpt))
+            elif getattr(config, "recover_ckpt", ""):
+                d, how = read(config.recover_ckpt)
+                out["w_rec"] = W.from_tf_dict(d, W.NET_REC)
+                print("Recover net loaded from previous ckpt")
+            else:
+                print("No recover checkpoint found! Train Recover from Scratch")
+        else:
+            ckpt = getattr(config, "ckpt_file", "")
+            if ckpt:
+                d, how = read(ckpt)
+                restore_all(d, "ckpt_file", ckpt, how)
+                print("Resume model from checkpoint {}".format(ckpt))
+            elif not synthetic:
+                raise IOError("Checkpoint file not found")  # test_generator.py:52-53
+        if "w_pwc" not in out and not synthetic:
+            raise IOError("Could not find flow ckpt file. Aborting.")  # :342-343 -- a random-init PWC-Net is never used silently
         return out
 
     def train(self, config):
@@ -122,7 +169,8 @@ class AdversarialLearner(object):
         self.config = config
         B = config.batch_size
         self.engine = Engine(_engine_config(config, B))
-        self.state = TrainState(self.engine, seed=getattr(config, "seed", 8964), **self._load_weights(config))
+        self.global_step = 0
+        self.state = TrainState(self.engine, seed=getattr(config, "seed", 8964), **self._load_weights(config, "train"))
         n_params = sum(W.param_total(n) for n in (W.NET_PWC, W.NET_GEN, W.NET_REC))
         print("Number of params: {}".format(n_params))
         self.train_steps_per_epoch = int(math.ceil(config.num_samples_train / config.batch_size))
@@ -132,8 +180,12 @@ class AdversarialLearner(object):
         print("-------------------------------------")
         sum_iters = iters_rec + iters_gen
         max_steps = self.train_steps_per_epoch * config.max_epochs
-        source = getattr(config, "data_source", None) or _SyntheticSource(B, max_steps)
-        self.global_step = 0
+        source = getattr(config, "data_source", None)
+        if source is None:
+            if not getattr(config, "synthetic", False):
+                raise IOError("no dataset: pass config.data_source (cli.py builds it from --root_dir) or opt in to synthetic pairs "
+                              "with config.synthetic / --synthetic")
+            source = _SyntheticSource(B, max_steps)
         it = iter(source)
         # cross-step pipelining (trainer.train_step): one batch of look-ahead, so that the frozen PWC-Net's flow of the
         # next batch is computed beside this step's backward pass
@@ -206,7 +258,11 @@ class AdversarialLearner(object):
     def save(self, checkpoint_dir, step):
         import os
         print(" [*] Saving checkpoint to {}/model-{}".format(checkpoint_dir, step))
-        d = {}
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_rank() != 0:
+            return  # replicas are identical: rank 0 writes
+        d = {}  # self.saver = every trainable variable (:317-319): pwcnet/* is trainable in the reference graph and is stored too
+        d.update(W.as_dict(self.state.w_pwc.cpu(), W.NET_PWC))
         d.update(W.as_dict(self.state.w_gen.cpu(), W.NET_GEN))
         d.update(W.as_dict(self.state.w_rec.cpu(), W.NET_REC))
         d["global_step"] = torch.tensor(self.global_step)
@@ -231,8 +287,12 @@ class AdversarialLearner(object):
         # the path is per sample, so the masks are the same numbers)
         B = 1 if aug_test else config.batch_size
         self.engine = Engine(_engine_config(config, len(TEST_CROPS) if aug_test else B))
-        self.state = TrainState(self.engine, seed=getattr(config, "seed", 8964), **self._load_weights(config))
-        source = getattr(config, "data_source", None) or _SyntheticSource(B, 4)
+        self.state = TrainState(self.engine, seed=getattr(config, "seed", 8964), **self._load_weights(config, "test"))
+        source = getattr(config, "data_source", None)
+        if source is None:
+            if not getattr(config, "synthetic", False):
+                raise IOError("no dataset: pass config.data_source or opt in to synthetic pairs with config.synthetic / --synthetic")
+            source = _SyntheticSource(B, 4)
         self.test_iterator = iter(source)
         self.test_samples = getattr(source, "n", 4) * B
         if aug_test:
