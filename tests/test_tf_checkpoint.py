@@ -79,7 +79,7 @@ def test_learner_restores_a_saver_prefix(tmp_path):
     tensors = {C.tf_variable_name(n): np.full(s, 0.25, np.float32) for n, s, _ in W.param_table(W.NET_REC)}
     prefix = str(tmp_path / "model-175")
     C.write_checkpoint(prefix, tensors)
-    out = AdversarialLearner()._load_weights(types.SimpleNamespace(flow_ckpt="", recover_ckpt=prefix, full_model_ckpt=""))
+    out = AdversarialLearner()._load_weights(types.SimpleNamespace(flow_ckpt="", recover_ckpt=prefix, full_model_ckpt="", synthetic=True), "train")
     assert set(out) == {"w_rec"} and out["w_rec"].numel() == W.param_total(W.NET_REC) and float(out["w_rec"].min()) == 0.25
 
 
@@ -94,7 +94,14 @@ def test_full_model_checkpoint_restores_every_network_it_holds(tmp_path):
     tensors["train_op/global_step"] = np.array(7, np.int64)
     prefix = str(tmp_path / "model.best")
     C.write_checkpoint(prefix, tensors)
-    out = AdversarialLearner()._load_weights(types.SimpleNamespace(flow_ckpt="", recover_ckpt="", full_model_ckpt="", ckpt_file=prefix))
+    lr = AdversarialLearner()
+    out = lr._load_weights(types.SimpleNamespace(flow_ckpt="", recover_ckpt="", full_model_ckpt="", ckpt_file=prefix, synthetic=True), "test")
     assert set(out) == {"w_gen", "w_rec"} and float(out["w_gen"].max()) == 0.5 and float(out["w_rec"].max()) == 0.25
+    assert lr.global_step == 7
+    # the path of the .data / .index file itself resolves to the prefix (the reference's test script passes it that way)
+    out = AdversarialLearner()._load_weights(types.SimpleNamespace(flow_ckpt="", ckpt_file=prefix + ".data-00000-of-00001", synthetic=True), "test")
+    assert set(out) == {"w_gen", "w_rec"}
     with pytest.raises(IOError):
-        AdversarialLearner()._load_weights(types.SimpleNamespace(flow_ckpt=str(tmp_path / "missing"), recover_ckpt="", full_model_ckpt=""))
+        AdversarialLearner()._load_weights(types.SimpleNamespace(flow_ckpt=str(tmp_path / "missing"), recover_ckpt="", full_model_ckpt=""), "train")
+    with pytest.raises(IOError):  # the flow checkpoint is mandatory (adversarial_learner.py:339-343) unless synthetic weights are asked for
+        AdversarialLearner()._load_weights(types.SimpleNamespace(flow_ckpt="", ckpt_file=prefix), "test")
