@@ -115,7 +115,13 @@ __device__ __forceinline__ void igemm_store(const ConvParams& p, floatx16 (&acc)
         const int n = n0 + wn * WTN + j * 32 + li;
         const float v = acc[i][j][r];
         if (p.ksplit > 1) {
-          if (n < p.ldp) p.partial[((size_t)blockIdx.z * p.ncls * Mtot + prow0 + row) * p.ldp + n] = v;
+          if (n < p.ldp) {
+            float* dst = p.partial + ((size_t)blockIdx.z * p.ncls * Mtot + prow0 + row) * p.ldp + n;
+            // folded form: the slab is published write-through (device-scope store, `sc1`): it is in memory when the store is
+            // acknowledged, so no L2 write-back fence is needed before the ticket (MI355X_MICROARCH.md "publish-large")
+            if (p.fold) __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else *dst = v;
+          }
           continue;
         }
         if (n >= p.Cout) continue;
@@ -125,27 +131,27 @@ __device__ __forceinline__ void igemm_store(const ConvParams& p, floatx16 (&acc)
   }
 }
 
-// Split-K without a second launch: after storing its partial tile every workgroup of an output tile draws a ticket; the one
-// that draws the last sums the slabs IN SPLIT ORDER (the result does not depend on which workgroup arrives last) and runs the
-// epilogue, then resets the ticket for the next launch on this stream.  Called by the NT threads [0, NT) of the workgroup
-// that are still alive (the staging waves of the wave-specialised kernels have exited: s_barrier counts surviving waves only).
+// Split-K without a second launch: every workgroup publishes its partial tile write-through (igemm_store), drains its
+// stores, and one lane draws a ticket; the workgroup that draws the last sums the slabs IN SPLIT ORDER (the result does not
+// depend on which workgroup arrives last) with device-scope (`sc1`) loads -- they read memory, not a stale line of this XCD's
+// L2, which is not coherent with the L2s the other workgroups wrote through -- and runs the epilogue, then resets the ticket
+// for the next launch on this stream.  No release / acquire fences: a fence writes back / invalidates the whole L2 and cost
+// more than the launch it replaces (r2a: the folded form with __threadfence() lost on every one of 141 split shapes).
+// Called by the NT threads [0, NT) of the workgroup that are still alive (the staging waves of the wave-specialised kernels
+// have exited: s_barrier counts surviving waves only).
+__device__ __forceinline__ float4 load4_device_scope(const float* p) {
+  const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
+  const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return make_float4(__uint_as_float((unsigned)a), __uint_as_float((unsigned)(a >> 32)), __uint_as_float((unsigned)b),
+                     __uint_as_float((unsigned)(b >> 32)));
+}
 template <int BM, int BN, int NT>
 __device__ __forceinline__ void splitk_fold(const ConvParams& p, const int* rowoff, int* s_last, int t, int n0, int prow0, int Mtot,
                                             int tile_id) {
-  // Release / acquire once per WORKGROUP, not per thread: every wave first waits until its own partial stores are
-  // acknowledged by this XCD's L2 (the vector L1 is write-through), the workgroup meets, and ONE wave performs the
-  // device-scope release (L2 write-back: the other XCDs' L2s are not coherent with this one) before it draws the ticket.
-  // The same wave performs the acquire (invalidate of this CU's L1 and this XCD's non-coherent L2 lines) for the workgroup
-  // that drew the last ticket; the second barrier orders the other waves' loads behind it.  A fence in every wave cost more
-  // than the second launch it replaces.
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's slab stores are acknowledged (write-through: in memory)
   __syncthreads();
-  if (t == 0) {
-    __threadfence();
-    const int last = atomicAdd(p.tickets + tile_id, 1) == p.ksplit - 1;
-    if (last) __threadfence();
-    *s_last = last;
-  }
+  if (t == 0) *s_last = atomicAdd(p.tickets + tile_id, 1) == p.ksplit - 1;
   __syncthreads();
   if (!*s_last) return;
   constexpr int C4 = BN / 4, ROWS = NT / C4;
@@ -159,17 +165,17 @@ __device__ __forceinline__ void splitk_fold(const ConvParams& p, const int* rowo
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       int s = 0;
       for (; s + 3 < p.ksplit; s += 4) {  // four slabs in flight, added in split order
-        const float4 a0 = *reinterpret_cast<const float4*>(src + (size_t)s * slab);
-        const float4 a1 = *reinterpret_cast<const float4*>(src + (size_t)(s + 1) * slab);
-        const float4 a2 = *reinterpret_cast<const float4*>(src + (size_t)(s + 2) * slab);
-        const float4 a3 = *reinterpret_cast<const float4*>(src + (size_t)(s + 3) * slab);
+        const float4 a0 = load4_device_scope(src + (size_t)s * slab);
+        const float4 a1 = load4_device_scope(src + (size_t)(s + 1) * slab);
+        const float4 a2 = load4_device_scope(src + (size_t)(s + 2) * slab);
+        const float4 a3 = load4_device_scope(src + (size_t)(s + 3) * slab);
         v.x += a0.x; v.y += a0.y; v.z += a0.z; v.w += a0.w;
         v.x += a1.x; v.y += a1.y; v.z += a1.z; v.w += a1.w;
         v.x += a2.x; v.y += a2.y; v.z += a2.z; v.w += a2.w;
         v.x += a3.x; v.y += a3.y; v.z += a3.z; v.w += a3.w;
       }
       for (; s < p.ksplit; ++s) {
-        const float4 a0 = *reinterpret_cast<const float4*>(src + (size_t)s * slab);
+        const float4 a0 = load4_device_scope(src + (size_t)s * slab);
         v.x += a0.x; v.y += a0.y; v.z += a0.z; v.w += a0.w;
       }
       if (n < p.Cout) conv_epilogue(p, off, n, v.x);
