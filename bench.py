@@ -305,6 +305,7 @@ def main():
     os.environ.pop("UDET_PROF_DUMP", None)
     if os.path.exists(dump):
         with open(dump) as f:
+            # category, layer, kernel ms (sum of the launches' own start -> stop times), algorithmic GFLOP, MB[, bracket ms, kernels]
             layers = [(int(r[0]), r[1], float(r[2]), float(r[3]), float(r[4])) for r in csv.reader(f)]
         if not keep:
             os.remove(dump)
@@ -312,6 +313,7 @@ def main():
     rc = 0
     if rank == 0:
         conv_ms = sum(prof[c]["ms"] for c in ("conv_fwd", "conv_dgrad", "conv_wgrad"))
+        conv_bracket_ms = sum(prof[c]["bracket_ms"] for c in ("conv_fwd", "conv_dgrad", "conv_wgrad"))
         conv_groups = sum(prof[c]["groups"] for c in ("conv_fwd", "conv_dgrad", "conv_wgrad"))
         alg_flops = ALG_GFLOP_PER_PAIR * 1e9 * args.batch
         # FLOPs of the launches actually executed: below the algorithmic figure because the image encoder of the three recover
@@ -330,8 +332,9 @@ def main():
                           "frac": round(top_tf / PEAK_FP32_MFMA_TFLOPS, 4)}
         roofline = {"bound": "mfma",
                     "kernel": "conv_igemm_dma_kernel / conv_igemm_kernel / conv_tile_kernel / conv_wgrad_kernel (v_mfma_f32_32x32x2_f32, "
-                              "16x16x4 for <=16 output channels): every convolution launch of one step, timed stand-alone with HIP "
-                              "events on the launch stream (serial pass)",
+                              "16x16x4 for <=16 output channels): every convolution launch of one step, executed serially; duration = "
+                              "the launch's own start -> stop HIP events (carried by its dispatch packet on the launch stream: the "
+                              "kernel execution time rocprofv3 --kernel-trace reports)",
                     "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4),
                     "numerator": "executed GFLOP of the launches (recover encoder A once, not three times)",
@@ -341,7 +344,11 @@ def main():
                     # passes, summaries under profiles/); filled here only from a --pmc-json of this build, else null
                     "traffic": pmc.get("traffic_bytes_per_launch"), "traffic_source": args.pmc_json or None,
                     "launch_groups_per_step": int(conv_groups), "avg_group_ms": round(conv_ms / max(conv_groups, 1), 4),
-                    "conv_ms_per_step_serial": round(conv_ms, 3), "top_launch": top_launch}
+                    "conv_ms_per_step_serial": round(conv_ms, 3),
+                    # the same launch groups bracketed by hipEventRecord before / after (adds event packets + dispatch gaps)
+                    "conv_bracket_ms_per_step_serial": round(conv_bracket_ms, 3),
+                    "frac_on_bracket_time": round(exe_flops / (conv_bracket_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4) if conv_bracket_ms > 0 else None,
+                    "top_launch": top_launch}
         hbm = {}
         p = prof["cost_volume"]
         if p["ms"] > 0:

@@ -237,9 +237,11 @@ int udet_tuned_shapes(void);
  * read (>= 0) or an error code; entries are trusted (they were verified when they were tuned). */
 int udet_tune_save(const char* path);
 int udet_tune_load(const char* path);
-/* Measurement aid (bench.py): between begin/end every convolution / warp / cost-volume launch group is
- * bracketed by HIP events on the launch stream.  out[cat*4 + {0,1,2,3}] = {groups, total ms, algorithmic
- * FLOPs, algorithmic bytes} for cat 0 conv fwd, 1 conv dgrad, 2 conv wgrad, 3 warp, 4 cost volume. */
+/* Measurement aid (bench.py): between begin/end every convolution / warp-cost-volume launch group is timed on the launch
+ * stream.  out[cat*5 + {0..4}] = {groups, kernel ms, algorithmic FLOPs, algorithmic bytes, bracket ms} for cat 0 conv fwd,
+ * 1 conv dgrad, 2 conv wgrad, 3 (unused), 4 warp + cost volume.  "kernel ms" sums the kernels' own start -> stop times (event
+ * pairs carried by the dispatch packets: what rocprofv3 --kernel-trace reports); "bracket ms" is hipEventRecord before / after
+ * each group, which additionally contains the event packets and dispatch gaps. */
 int udet_profile_begin(udet_plan* plan);
 int udet_profile_end(udet_plan* plan, double* out, int ncat, void* stream);
 

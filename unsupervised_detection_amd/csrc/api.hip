@@ -22,6 +22,18 @@ int hip_fail(hipError_t e, const char* what) {
   return UDET_ERR_HIP;
 }
 
+thread_local LaunchSink* g_launch_sink = nullptr;
+bool launch_sink_next(hipEvent_t* a, hipEvent_t* b) {
+  LaunchSink* s = g_launch_sink;
+  if (!s || s->n >= s->cap) return false;
+  if (hipEventCreate(a) != hipSuccess) return false;
+  if (hipEventCreate(b) != hipSuccess) { (void)hipEventDestroy(*a); return false; }
+  s->ev[2 * s->n] = *a;
+  s->ev[2 * s->n + 1] = *b;
+  ++s->n;
+  return true;
+}
+
 // bump allocator over the caller's workspace (256-byte granules)
 struct Arena {
   char* base;

@@ -169,32 +169,45 @@ int udet_tune_load(const char* path) {
   return n;
 }
 
-/* profiling: per-category HIP-event timing of the conv / warp / cost-volume launches */
+/* measurement: per-category timing of the conv / warp-cost-volume launches */
 int udet_profile_begin(udet_plan* h) {
+  for (auto* r : h->p->prof) delete r;
   h->p->prof.clear();
   h->p->profiling = true;
   return UDET_OK;
 }
-/* out[cat][4] = {launch groups, total ms, algorithmic flops, algorithmic bytes}; synchronises the stream */
+/* out[cat][5] = {launch groups, kernel ms (sum of the kernels' own start -> stop times), algorithmic flops, algorithmic bytes,
+ * bracket ms (hipEventRecord before / after each group: adds the event packets and the dispatch gaps)}; synchronises the stream */
 int udet_profile_end(udet_plan* h, double* out, int ncat, void* stream) {
   Plan* P = h->p;
   P->profiling = false;
+  g_launch_sink = nullptr;
   UDET_HIP(hipStreamSynchronize((hipStream_t)stream));
-  for (int i = 0; i < ncat * 4; ++i) out[i] = 0.0;
-  FILE* dump = nullptr;  // UDET_PROF_DUMP=<file>: one CSV line per launch group (category,name,ms,algorithmic GFLOP,MB)
+  for (int i = 0; i < ncat * 5; ++i) out[i] = 0.0;
+  FILE* dump = nullptr;  // UDET_PROF_DUMP=<file>: one CSV line per launch group (category,name,kernel ms,algorithmic GFLOP,MB,bracket ms,kernels)
   if (const char* path = getenv("UDET_PROF_DUMP")) dump = fopen(path, "a");
-  for (auto& r : P->prof) {
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, r.a, r.b);
-    if (dump) fprintf(dump, "%d,%s,%.4f,%.4f,%.4f\n", r.cat, r.name.c_str(), ms, r.flops * 1e-9, r.bytes * 1e-6);
-    if (r.cat < ncat) {
-      out[r.cat * 4 + 0] += 1.0;
-      out[r.cat * 4 + 1] += ms;
-      out[r.cat * 4 + 2] += r.flops;
-      out[r.cat * 4 + 3] += r.bytes;
+  for (auto* r : P->prof) {
+    float wall = 0.f;
+    (void)hipEventElapsedTime(&wall, r->a, r->b);
+    double kern = 0.0;
+    for (int k = 0; k < r->sink.n; ++k) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, r->kev[2 * k], r->kev[2 * k + 1]) == hipSuccess) kern += ms;
+      (void)hipEventDestroy(r->kev[2 * k]);
+      (void)hipEventDestroy(r->kev[2 * k + 1]);
     }
-    (void)hipEventDestroy(r.a);
-    (void)hipEventDestroy(r.b);
+    if (r->sink.n == 0) kern = wall;  // (a group whose launches did not go through the sink)
+    if (dump) fprintf(dump, "%d,%s,%.4f,%.4f,%.4f,%.4f,%d\n", r->cat, r->name.c_str(), kern, r->flops * 1e-9, r->bytes * 1e-6, wall, r->sink.n);
+    if (r->cat < ncat) {
+      out[r->cat * 5 + 0] += 1.0;
+      out[r->cat * 5 + 1] += kern;
+      out[r->cat * 5 + 2] += r->flops;
+      out[r->cat * 5 + 3] += r->bytes;
+      out[r->cat * 5 + 4] += wall;
+    }
+    (void)hipEventDestroy(r->a);
+    (void)hipEventDestroy(r->b);
+    delete r;
   }
   if (dump) fclose(dump);
   P->prof.clear();

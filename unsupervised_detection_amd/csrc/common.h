@@ -2,6 +2,7 @@
 // gfx950 (MI355X / CDNA4) only.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
@@ -22,6 +23,26 @@ int hip_fail(hipError_t e, const char* what);
   do {                         \
     int _s = (x);              \
     if (_s != 0) return _s;    \
+  } while (0)
+
+// ------------------------------------------------------------- launches ----
+// Every hot kernel is launched through UDET_LAUNCH.  While a measurement pass is active (udet_profile_begin) the launch
+// carries a start / stop event pair on its own dispatch packet (hipExtLaunchKernelGGL): the elapsed time between them is
+// the kernel's execution time on the device -- the figure `rocprofv3 --kernel-trace` reports -- without the event-record
+// packets and dispatch gaps that a hipEventRecord bracket around the launch adds (several microseconds per bracket).
+struct LaunchSink {
+  hipEvent_t* ev;  // pairs
+  int n, cap;
+};
+extern thread_local LaunchSink* g_launch_sink;
+bool launch_sink_next(hipEvent_t* a, hipEvent_t* b);
+#define UDET_LAUNCH(kernel, grid, block, shmem, stream, ...)                                             \
+  do {                                                                                                   \
+    hipEvent_t ea_, eb_;                                                                                 \
+    if (udet::g_launch_sink && udet::launch_sink_next(&ea_, &eb_))                                       \
+      hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, ea_, eb_, 0, __VA_ARGS__);               \
+    else                                                                                                 \
+      hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                               \
   } while (0)
 
 // ----------------------------------------------------------- activations ----

@@ -129,7 +129,7 @@ int launch_pack_weights(const float* src, float* dst, int T, int R, int C, int K
   const long total = (long)T * Kc * ldw;
   int nb = (int)((total + 255) / 256);
   if (nb > 2048) nb = 2048;
-  hipLaunchKernelGGL(pack_weights_kernel, dim3(nb), dim3(256), 0, stream, src, dst, T, R, C, Kc, ldw, k_split, k_gap,
+  UDET_LAUNCH(pack_weights_kernel, dim3(nb), dim3(256), 0, stream, src, dst, T, R, C, Kc, ldw, k_split, k_gap,
                      mode, scale);
   UDET_HIP(hipGetLastError());
   return UDET_OK;
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
 }
 int launch_pack_jobs(const PackJob* jobs_dev, int njobs, const float* wsrc, float* ws, float bn_c, hipStream_t stream) {
   if (njobs < 1) return UDET_OK;
-  hipLaunchKernelGGL(pack_jobs_kernel, dim3(48, njobs), dim3(256), 0, stream, jobs_dev, wsrc, ws, bn_c);
+  UDET_LAUNCH(pack_jobs_kernel, dim3(48, njobs), dim3(256), 0, stream, jobs_dev, wsrc, ws, bn_c);
   UDET_HIP(hipGetLastError());
   return UDET_OK;
 }
@@ -200,7 +200,7 @@ int launch_pack_taps_into_n(const float* src, float* dst, int T, int R, int C, i
   j.mode = transposed ? 4 : 3; j.total = (long)Kc * ldz; j.gamma_off = -1;
   int nb = (int)((j.total + 255) / 256);
   if (nb > 1024) nb = 1024;
-  hipLaunchKernelGGL(pack_job_kernel, dim3(nb), dim3(256), 0, stream, j, src, dst);
+  UDET_LAUNCH(pack_job_kernel, dim3(nb), dim3(256), 0, stream, j, src, dst);
   UDET_HIP(hipGetLastError());
   return UDET_OK;
 }
@@ -276,14 +276,14 @@ int launch_tap_gather(const ConvParams& g, const float* z, int ldz, hipStream_t 
     const long pixels = (long)q.N * q.OH * q.OW;
     int nb2 = (int)((pixels + 255) / 256);
     if (nb2 > 4096) nb2 = 4096;
-    hipLaunchKernelGGL(tap_gather2_kernel, dim3(nb2), dim3(256), 0, stream, q, z, ldz);
+    UDET_LAUNCH(tap_gather2_kernel, dim3(nb2), dim3(256), 0, stream, q, z, ldz);
     UDET_HIP(hipGetLastError());
     return UDET_OK;
   }
   const long total = (long)q.N * q.OH * q.OW * q.Cout;
   int nb = (int)((total + 255) / 256);
   if (nb > 4096) nb = 4096;
-  hipLaunchKernelGGL(tap_gather_kernel, dim3(nb), dim3(256), 0, stream, q, z, ldz);
+  UDET_LAUNCH(tap_gather_kernel, dim3(nb), dim3(256), 0, stream, q, z, ldz);
   UDET_HIP(hipGetLastError());
   return UDET_OK;
 }
@@ -300,7 +300,7 @@ __global__ void fold_bn_kernel(const float* __restrict__ b, const float* __restr
 }
 int launch_fold_bn(const float* b, const float* gamma, const float* beta, float c, float* scale, float* bias_f, int n,
                    hipStream_t stream) {
-  hipLaunchKernelGGL(fold_bn_kernel, dim3((n + 127) / 128), dim3(128), 0, stream, b, gamma, beta, c, scale, bias_f, n);
+  UDET_LAUNCH(fold_bn_kernel, dim3((n + 127) / 128), dim3(128), 0, stream, b, gamma, beta, c, scale, bias_f, n);
   UDET_HIP(hipGetLastError());
   return UDET_OK;
 }
@@ -322,7 +322,7 @@ int launch_copy_channels(const float* src, int lds, int s_coff, float* dst, int 
   int nb = (int)((total + 255) / 256);
   if (nb > 4096) nb = 4096;
   if (nb < 1) nb = 1;
-  hipLaunchKernelGGL(copy_channels_kernel, dim3(nb), dim3(256), 0, stream, src, lds, s_coff, dst, ldd, d_coff, P, C, mul,
+  UDET_LAUNCH(copy_channels_kernel, dim3(nb), dim3(256), 0, stream, src, lds, s_coff, dst, ldd, d_coff, P, C, mul,
                      add);
   UDET_HIP(hipGetLastError());
   return UDET_OK;

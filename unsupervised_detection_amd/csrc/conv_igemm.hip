@@ -879,17 +879,17 @@ static int launch_cfg(const ConvParams& p, int ws, hipStream_t stream) {
   dim3 grid(p.ncls * ((Mtot + BM - 1) / BM), (p.Cout + BN - 1) / BN, p.ksplit > 1 ? p.ksplit : 1);
   if (ws == 6) {
     if constexpr (BM % 64 == 0 && BN % 64 == 0 && BM <= 128) {
-      hipLaunchKernelGGL((conv_igemm_dma4_kernel<BM, BN, 2, 2>), grid, dim3(256), 0, stream, p);
+      UDET_LAUNCH((conv_igemm_dma4_kernel<BM, BN, 2, 2>), grid, dim3(256), 0, stream, p);
     } else if constexpr (BN == 32 && BM % 128 == 0) {
-      hipLaunchKernelGGL((conv_igemm_dma4_kernel<BM, BN, 4, 1>), grid, dim3(256), 0, stream, p);
+      UDET_LAUNCH((conv_igemm_dma4_kernel<BM, BN, 4, 1>), grid, dim3(256), 0, stream, p);
     } else {
       set_error("conv: no self-staging kernel for tile %dx%d", BM, BN);
       return UDET_ERR_UNSUPPORTED;
     }
   }
-  else if (ws == 2) hipLaunchKernelGGL((conv_igemm_dma_kernel<BM, BN, WAVES_M, WAVES_N>), grid, dim3(512), 0, stream, p);
-  else if (ws) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, true>), grid, dim3(512), 0, stream, p);
-  else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, false>), grid, dim3(256), 0, stream, p);
+  else if (ws == 2) UDET_LAUNCH((conv_igemm_dma_kernel<BM, BN, WAVES_M, WAVES_N>), grid, dim3(512), 0, stream, p);
+  else if (ws) UDET_LAUNCH((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, true>), grid, dim3(512), 0, stream, p);
+  else UDET_LAUNCH((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, false>), grid, dim3(256), 0, stream, p);
   UDET_HIP(hipGetLastError());
   if (p.ksplit > 1 && !p.fold) {
     const long total = (long)p.ncls * Mtot * p.Cout;
@@ -897,9 +897,9 @@ static int launch_cfg(const ConvParams& p, int ws, hipStream_t stream) {
     const int sl = (p.ksplit >= 16 && total * 16 <= 262144) ? 16 : ((p.ksplit >= 4 && total * 4 <= 262144) ? 4 : 1);
     long nbl = (total * sl + 255) / 256;
     const int nb = (int)(nbl > 4096 ? 4096 : nbl);
-    if (sl == 16) hipLaunchKernelGGL(conv_splitk_epilogue_kernel<16>, dim3(nb), dim3(256), 0, stream, p);
-    else if (sl == 4) hipLaunchKernelGGL(conv_splitk_epilogue_kernel<4>, dim3(nb), dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL(conv_splitk_epilogue_kernel<1>, dim3(nb), dim3(256), 0, stream, p);
+    if (sl == 16) UDET_LAUNCH(conv_splitk_epilogue_kernel<16>, dim3(nb), dim3(256), 0, stream, p);
+    else if (sl == 4) UDET_LAUNCH(conv_splitk_epilogue_kernel<4>, dim3(nb), dim3(256), 0, stream, p);
+    else UDET_LAUNCH(conv_splitk_epilogue_kernel<1>, dim3(nb), dim3(256), 0, stream, p);
     UDET_HIP(hipGetLastError());
   }
   return UDET_OK;

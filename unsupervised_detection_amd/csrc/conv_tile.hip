@@ -368,7 +368,7 @@ int launch_conv_tile(const ConvParams& p, int th, hipStream_t stream) {
   const int ncls = p.ncls > 1 ? p.ncls : 1;
   const bool n16 = p.Cout <= 16;
   dim3 grid(tiles, n16 ? 1 : (p.Cout + 31) / 32, ncls);
-  hipLaunchKernelGGL(K[th == 4][n16][big], grid, dim3(256), lds, stream, p, g);
+  UDET_LAUNCH(K[th == 4][n16][big], grid, dim3(256), lds, stream, p, g);
   UDET_HIP(hipGetLastError());
   return UDET_OK;
 }

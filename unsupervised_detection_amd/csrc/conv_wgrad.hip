@@ -430,8 +430,8 @@ void wgrad_tune_put(unsigned long long key, int cfg) {
 template <int BM, int BN, int WM_, int WN_>
 static void wgrad_launch(const WgradParams& p, int m_tiles, int co_tiles, int nsplit, bool dma, hipStream_t stream) {
   dim3 grid(m_tiles * co_tiles, nsplit);
-  if (dma) hipLaunchKernelGGL((conv_wgrad_dma_kernel<BM, BN, WM_, WN_>), grid, dim3(512), 0, stream, p, co_tiles, nsplit);
-  else hipLaunchKernelGGL((conv_wgrad_kernel<BM, BN, WM_, WN_>), grid, dim3(256), 0, stream, p, co_tiles, nsplit);
+  if (dma) UDET_LAUNCH((conv_wgrad_dma_kernel<BM, BN, WM_, WN_>), grid, dim3(512), 0, stream, p, co_tiles, nsplit);
+  else UDET_LAUNCH((conv_wgrad_kernel<BM, BN, WM_, WN_>), grid, dim3(256), 0, stream, p, co_tiles, nsplit);
 }
 
 // p.taps must list the (non-culled) taps with widx = ky*kw+kx; T = kh*kw.
@@ -513,9 +513,9 @@ int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream) {
     const int sl = (ns >= 64 && total * 64 <= 262144) ? 64 : ((ns >= 8 && total * 8 <= 262144) ? 8 : 1);
     const long nbl = (total * sl + 255) / 256;
     const int nb = (int)(nbl > 4096 ? 4096 : nbl);
-    if (sl == 64) hipLaunchKernelGGL(wgrad_reduce_kernel<64>, dim3(nb), dim3(256), 0, stream, q, ldn, ns);
-    else if (sl == 8) hipLaunchKernelGGL(wgrad_reduce_kernel<8>, dim3(nb), dim3(256), 0, stream, q, ldn, ns);
-    else hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(nb), dim3(256), 0, stream, q, ldn, ns);
+    if (sl == 64) UDET_LAUNCH(wgrad_reduce_kernel<64>, dim3(nb), dim3(256), 0, stream, q, ldn, ns);
+    else if (sl == 8) UDET_LAUNCH(wgrad_reduce_kernel<8>, dim3(nb), dim3(256), 0, stream, q, ldn, ns);
+    else UDET_LAUNCH(wgrad_reduce_kernel<1>, dim3(nb), dim3(256), 0, stream, q, ldn, ns);
   };
   // autotuned split count (see conv_igemm.hip): kernel + reduction timed together
   {
@@ -590,9 +590,9 @@ int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream) {
       set_error("wgrad: BN finalisation needs db, dgamma, dbeta, w and b");
       return UDET_ERR_ARG;
     }
-    hipLaunchKernelGGL(bn_dot_kernel, dim3((p.Cout + 63) / 64, BND_SPLIT), dim3(256), 0, stream, p.w, p.dw, T * p.Cin,
+    UDET_LAUNCH(bn_dot_kernel, dim3((p.Cout + 63) / 64, BND_SPLIT), dim3(256), 0, stream, p.w, p.dw, T * p.Cin,
                        p.Cout, pd);
-    hipLaunchKernelGGL(bn_finish_kernel, dim3(nbw), dim3(256), 0, stream, p.dw, (long)wsz, p.Cout, p.gamma, p.b, p.bn_c, pd,
+    UDET_LAUNCH(bn_finish_kernel, dim3(nbw), dim3(256), 0, stream, p.dw, (long)wsz, p.Cout, p.gamma, p.b, p.bn_c, pd,
                        p.db, p.dgamma, p.dbeta);
     UDET_HIP(hipGetLastError());
   }

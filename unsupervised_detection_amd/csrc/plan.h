@@ -95,9 +95,14 @@ struct Plan {
   size_t jobs_off[3] = {0, 0, 0}; // PackJob tables on device
   int njobs[3] = {0, 0, 0};
   // optional per-category timing with HIP events on the launch stream (bench.py roofline)
-  struct ProfRec { int cat; double flops, bytes; hipEvent_t a, b; std::string name; };
+  struct ProfRec {
+    int cat; double flops, bytes; hipEvent_t a, b; std::string name;
+    enum { MAXK = 16 };
+    hipEvent_t kev[2 * MAXK];  // start / stop pairs of the kernels launched inside the group
+    LaunchSink sink;
+  };
   bool profiling = false;
-  std::vector<ProfRec> prof;
+  std::vector<ProfRec*> prof;
   long adam_t = 0;               // number of optimizer applies so far (shared beta powers)
   bool pwc_packed = false;
   int add_buf(const std::string& name, int n, int h, int w, int ld);

@@ -174,6 +174,7 @@ Plan::~Plan() {
   for (auto& e : ev_pool) (void)hipEventDestroy(e);
   for (auto& e : ev_pool_prefetch) (void)hipEventDestroy(e);
   if (prefetch_ev) (void)hipEventDestroy(prefetch_ev);
+  for (auto* r : prof) delete r;
   for (auto& ev : grad_ev)
     if (ev) (void)hipEventDestroy(ev);
 }

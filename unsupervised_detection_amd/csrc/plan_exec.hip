@@ -28,16 +28,19 @@ static std::string S(const char* fmt, int a, int b = 0) {
 // ------------------------------------------------------------ profiling ----
 void prof_begin(Plan* P, int cat, double flops, double bytes, hipStream_t s, const char* name) {
   if (!P->profiling) return;
-  Plan::ProfRec r;
-  r.cat = cat; r.flops = flops; r.bytes = bytes; r.name = name ? name : "";
-  (void)hipEventCreate(&r.a);
-  (void)hipEventCreate(&r.b);
-  (void)hipEventRecord(r.a, s);
+  Plan::ProfRec* r = new Plan::ProfRec();
+  r->cat = cat; r->flops = flops; r->bytes = bytes; r->name = name ? name : "";
+  r->sink.ev = r->kev; r->sink.n = 0; r->sink.cap = Plan::ProfRec::MAXK;
+  (void)hipEventCreate(&r->a);
+  (void)hipEventCreate(&r->b);
+  (void)hipEventRecord(r->a, s);
   P->prof.push_back(r);
+  g_launch_sink = &r->sink;  // kernels launched until prof_end carry their own start / stop events
 }
 void prof_end(Plan* P, hipStream_t s) {
   if (!P->profiling) return;
-  (void)hipEventRecord(P->prof.back().b, s);
+  g_launch_sink = nullptr;
+  (void)hipEventRecord(P->prof.back()->b, s);
 }
 // algorithmic FLOPs of the convolution a layer stands for (2*MACs, unpadded channels)
 static double layer_flops(const Layer& L, int N) {

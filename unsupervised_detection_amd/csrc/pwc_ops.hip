@@ -71,7 +71,7 @@ int launch_warp(const float* img, const float* flow, int ldf, int f_coff, float 
   int nb = (int)((total + 255) / 256);
   if (nb > 4096) nb = 4096;
   if (nb < 1) nb = 1;
-  hipLaunchKernelGGL(warp_kernel, dim3(nb), dim3(256), 0, stream, img, flow, ldf, f_coff, flow_scale, out, N, H, W, C,
+  UDET_LAUNCH(warp_kernel, dim3(nb), dim3(256), 0, stream, img, flow, ldf, f_coff, flow_scale, out, N, H, W, C,
                      dbg_idx, dbg_alpha);
   UDET_HIP(hipGetLastError());
   return UDET_OK;
@@ -205,7 +205,7 @@ int launch_cost_volume(const float* c1, const float* wr, float* out, int ldo, in
     return UDET_ERR_SHAPE;
   }
   const int tiles = ((W + CV_T - 1) / CV_T) * ((H + CV_T - 1) / CV_T) * N;
-  hipLaunchKernelGGL(cost_volume_kernel, dim3(tiles), dim3(256), 0, stream, c1, wr, out, ldo, o_coff, N, H, W, C);
+  UDET_LAUNCH(cost_volume_kernel, dim3(tiles), dim3(256), 0, stream, c1, wr, out, ldo, o_coff, N, H, W, C);
   UDET_HIP(hipGetLastError());
   return UDET_OK;
 }
@@ -410,10 +410,10 @@ int launch_warp_cost_volume(const float* c1, const float* c2, const float* flow,
   const int per = (tiles + xcds - 1) / xcds;
   const dim3 grid(per * 8);
   if (T == 4)
-    hipLaunchKernelGGL(warp_cost_volume_kernel<4>, grid, dim3(256), 0, stream, c1, c2, flow, ldf, f_coff, flow_scale, out, ldo, corr_coff,
+    UDET_LAUNCH(warp_cost_volume_kernel<4>, grid, dim3(256), 0, stream, c1, c2, flow, ldf, f_coff, flow_scale, out, ldo, corr_coff,
                        c1_coff, warped_dbg, N, H, W, C, xcds);
   else
-    hipLaunchKernelGGL(warp_cost_volume_kernel<8>, grid, dim3(256), 0, stream, c1, c2, flow, ldf, f_coff, flow_scale, out, ldo, corr_coff,
+    UDET_LAUNCH(warp_cost_volume_kernel<8>, grid, dim3(256), 0, stream, c1, c2, flow, ldf, f_coff, flow_scale, out, ldo, corr_coff,
                        c1_coff, warped_dbg, N, H, W, C, xcds);
   UDET_HIP(hipGetLastError());
   return UDET_OK;

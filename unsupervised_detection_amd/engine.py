@@ -205,15 +205,18 @@ class Engine:
         return int(lib.udet_tuned_shapes())
 
     def profile(self, fn):
-        """Run fn() with per-category HIP-event timing (udet_profile_begin/end). Returns {category: {...}}."""
+        """Run fn() with per-category kernel timing (udet_profile_begin/end). Returns {category: {...}}."""
         cats = ("conv_fwd", "conv_dgrad", "conv_wgrad", "warp", "cost_volume")
         check(lib.udet_profile_begin(self._h))
         try:
             fn()
         finally:
-            out = (ctypes.c_double * (4 * len(cats)))()
+            out = (ctypes.c_double * (5 * len(cats)))()
             check(lib.udet_profile_end(self._h, out, len(cats), self._stream()))
-        return {c: dict(groups=out[4 * i], ms=out[4 * i + 1], flops=out[4 * i + 2], bytes=out[4 * i + 3]) for i, c in enumerate(cats)}
+        # ms: sum of the kernels' own start -> stop times; bracket_ms: hipEventRecord around each launch group (adds the event
+        # packets and dispatch gaps)
+        return {c: dict(groups=out[5 * i], ms=out[5 * i + 1], flops=out[5 * i + 2], bytes=out[5 * i + 3], bracket_ms=out[5 * i + 4])
+                for i, c in enumerate(cats)}
 
     @property
     def adam_step(self):
