@@ -75,6 +75,36 @@ int udet_crop_flip_resize(const void* src, int src_is_u8, int nearest, int n, in
 int udet_mask_stats(const float* pred_masks, const float* gt_masks, int n, int h, int w, float threshold, float gt_threshold,
                     double* stats8, void* stream);
 
+/* Post-processing stage ("next" row N4; post_processing/generate_soft_score_from_buffer.py, crf_refine.py).  The third-party
+ * routines those scripts call are absent from the reference tree; each entry point names the routine it restates and the call
+ * site that fixes its arguments.  Frames are small (192x384): one workgroup reductions, double accumulation like numpy float64.
+ *  - udet_post_border_mean: sanity_check (:116-125): mean over the four two-pixel border strips of n masks [n,h,w] -> out[n].
+ *  - udet_post_bytescale / udet_post_resample_u8 / udet_post_place: rectify_pred_mask (:98-114) = scipy.misc.imresize (scipy <=
+ *    1.2: bytescale with the window's own min / max + Pillow's 8-bit BILINEAR resampler, Resample.c; kk [n_out][ksize] 22-bit
+ *    fixed-point coefficients and bounds [n_out][2] = (first tap, taps) are computed by the host exactly as Pillow does; axis 1 =
+ *    horizontal pass, 0 = vertical pass) and the placement on a zero canvas divided by (max + 1e-6).
+ *  - udet_post_minmax_norm: pred_mask = (score - min) / (max - min + 1e-6) (:88-90).
+ *  - udet_post_remap: cv2.remap(src, flow + pixel grid, None, INTER_LINEAR) with BORDER_CONSTANT 0 (propagate :166-176; OpenCV
+ *    remapBilinear: coordinates rounded to 1/32 pixel, float 4-tap weights); flow_uv [h,w,2] = (u, v).
+ *  - udet_post_blend: y = a * x / (max(x) + 1e-8) + b * y, optionally followed by y /= (max(y) + 1e-8) (propagate :177-184).
+ *  - udet_post_gauss1d: one axis of scipy.ndimage.gaussian_filter (mode 'reflect'), weights k[2r+1] on the device (crf_refine :113).
+ *  - udet_post_dense_crf: DenseCRF2D + setUnaryEnergy + addPairwiseBilateral(sxy, srgb, rgbim, compat) + inference(iters)
+ *    (crf_refine.py:110-130; Kraehenbuehl & Koltun 2011, mean field with one bilateral Potts term, symmetric normalisation), the
+ *    Gaussian kernel evaluated exactly inside a (2*radius+1)^2 window; unary [2,h,w] energies, image_rgb uint8 [h,w,3],
+ *    q [2,h,w] marginals out. */
+int udet_post_border_mean(const float* s, int n, int h, int w, double* out, void* stream);
+int udet_post_bytescale(const double* src, int ld, int y0, int x0, int h, int w, unsigned char* dst, void* stream);
+int udet_post_resample_u8(const unsigned char* src, int h, int w, unsigned char* dst, int oh, int ow, const int* kk, const int* bounds,
+                          int ksize, int axis, void* stream);
+int udet_post_place(const unsigned char* patch, int hh, int ww, int y0, int x0, int h, int w, double* canvas, void* stream);
+int udet_post_minmax_norm(const double* score, int n, double* out, void* stream);
+int udet_post_remap(const float* src, const float* flow_uv, float* dst, int h, int w, void* stream);
+int udet_post_blend(const float* x, float a, float* y, float b, int n, int renorm, void* stream);
+int udet_post_gauss1d(const double* src, double* dst, int h, int w, const double* k, int r, int axis, void* stream);
+size_t udet_post_crf_workspace_bytes(int h, int w);
+int udet_post_dense_crf(const float* unary, const unsigned char* image_rgb, int h, int w, float sxy, float srgb, float compat, int iters,
+                        int radius, float* q, void* workspace, size_t workspace_bytes, void* stream);
+
 /* tf.nn.conv2d / tf.layers.conv2d, padding='SAME', + bias + activation
  * (models/utils/convolution_utils.py:46,81-84; models/PWCNet/model_pwcnet.py:161-165,484-504,562-574).
  * upsample2x != 0 first applies tf.image.resize_nearest_neighbor(x2, align_corners=True)

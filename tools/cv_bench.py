@@ -35,7 +35,10 @@ def main():
         mb = 4 * h * w * (2 * c + 81) * 4 / 1e6
         uw = timed(lambda: ops.dense_image_warp(c2, flow))
         mbw = 4 * h * w * (2 * c + 2) * 4 / 1e6
-        print(f"level {lvl} {h}x{w}x{c}: cost_volume {us:6.1f} us {mb / us * 1e3:7.1f} GB/s | warp {uw:6.1f} us {mbw / uw * 1e3:7.1f} GB/s", flush=True)
+        uf = timed(lambda: ops.warp_cost_volume(c1, c2, flow if lvl != 6 else None, 20.0 / 2 ** lvl))
+        mbf = 4 * h * w * (2 * c + 2 + 81) * 4 / 1e6  # read c1 + c2 + flow, write 81 channels (the plan's launch also writes c1 into the slab)
+        print(f"level {lvl} {h}x{w}x{c}: cost_volume {us:6.1f} us {mb / us * 1e3:7.1f} GB/s | warp {uw:6.1f} us {mbw / uw * 1e3:7.1f} GB/s | "
+              f"fused warp+cost_volume {uf:6.1f} us {mbf / uf * 1e3:7.1f} GB/s (two kernels: {us + uw:6.1f} us)", flush=True)
 
 
 if __name__ == "__main__":

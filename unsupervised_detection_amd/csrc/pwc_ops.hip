@@ -231,6 +231,7 @@ __global__ __launch_bounds__(256) void warp_cost_volume_kernel(const float* __re
   constexpr int HALO = T + 2 * CV_R, NHP = HALO * HALO, NP = T * T, NG = 256 / NP, ND = (81 + NG - 1) / NG;
   constexpr int HL = (NHP * 8 + 255) / 256;  // float4 halo items per thread and slice
   constexpr int TL = (NP * 8 + 255) / 256;   // float4 c1 items per thread and slice
+  constexpr int GB = 2;                      // gather batch: items per thread whose four corner loads are in flight together
   __shared__ __attribute__((aligned(16))) float sw[(NHP * CV_CS > NP * 81 ? NHP * CV_CS : NP * 81)];
   __shared__ __attribute__((aligned(16))) float s1[NP * CV_CS];
   __shared__ int h_off[NHP];       // element offset of the top-left corner in c2 (-1: halo pixel outside the image)
@@ -282,8 +283,13 @@ __global__ __launch_bounds__(256) void warp_cost_volume_kernel(const float* __re
     toff[u] = (tp < NP && yy < H && xx < W) ? ((n * H + yy) * W + xx) : -1;
   }
   float acc[ND];
+  int woff[ND];  // LDS offset of displacement g + NG*j's halo pixel for this thread's pixel
 #pragma unroll
-  for (int j = 0; j < ND; ++j) acc[j] = 0.f;
+  for (int j = 0; j < ND; ++j) {
+    acc[j] = 0.f;
+    const int d = g + NG * j, dy = d / 9, dx = d - dy * 9;
+    woff[j] = ((py + dy) * HALO + px + dx) * CV_CS;
+  }
   const int c4 = t & 7;
   const long rowC = (long)W * C;
   __syncthreads();
@@ -303,13 +309,13 @@ __global__ __launch_bounds__(256) void warp_cost_volume_kernel(const float* __re
         *reinterpret_cast<float4*>(&s1[(e >> 3) * CV_CS + c4 * 4]) = v;
       }
     }
-    // warped halo: four corner gathers per (halo pixel, channel quad), in batches of 4 items (16 loads in flight)
+    // warped halo: four corner gathers per (halo pixel, channel quad), in batches of GB items (4*GB loads in flight)
+#pragma unroll 1  // one batch of 16 gathers in flight (unrolling both batches doubled the VGPR count)
+    for (int ub = 0; ub < HL; ub += GB) {
+      float4 tl[GB], tr[GB], bl[GB], br[GB];
+      int hp[GB];
 #pragma unroll
-    for (int ub = 0; ub < HL; ub += 4) {
-      float4 tl[4], tr[4], bl[4], br[4];
-      int hp[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < GB; ++k) {
         const int e = t + (ub + k) * 256;
         hp[k] = e >> 3;
         tl[k] = tr[k] = bl[k] = br[k] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -327,7 +333,7 @@ __global__ __launch_bounds__(256) void warp_cost_volume_kernel(const float* __re
         }
       }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < GB; ++k) {
         if (ub + k < HL && hp[k] < NHP) {
           float4 o = tl[k];
           if (flow) {
@@ -348,25 +354,23 @@ __global__ __launch_bounds__(256) void warp_cost_volume_kernel(const float* __re
       }
     }
     __syncthreads();
-    float4 a[8];
+    // channel quad outer, displacement inner: one a quad and a handful of b quads live at a time (the displacement-outer form
+    // kept 8 a quads + all unrolled b loads alive: 196 VGPRs, 2 waves per SIMD).  Every accumulator still sees its channels in
+    // the order q = 0..7, (x, y, z, w): bit-identical to cost_volume_kernel.
+#pragma unroll 1
+    for (int q = 0; q < 8; ++q) {
+      const float4 a = *reinterpret_cast<const float4*>(&s1[p * CV_CS + q * 4]);
 #pragma unroll
-    for (int q = 0; q < 8; ++q) a[q] = *reinterpret_cast<const float4*>(&s1[p * CV_CS + q * 4]);
-#pragma unroll
-    for (int j = 0; j < ND; ++j) {
-      const int d = g + NG * j;
-      if (d < 81) {
-        const int dy = d / 9, dx = d - dy * 9;
-        const float* wp = &sw[((py + dy) * HALO + px + dx) * CV_CS];
-        float s = acc[j];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const float4 b = *reinterpret_cast<const float4*>(wp + q * 4);
-          s = fmaf(a[q].x, b.x, s);
-          s = fmaf(a[q].y, b.y, s);
-          s = fmaf(a[q].z, b.z, s);
-          s = fmaf(a[q].w, b.w, s);
+      for (int j = 0; j < ND; ++j) {
+        if (g + NG * j < 81) {
+          const float4 b = *reinterpret_cast<const float4*>(&sw[woff[j] + q * 4]);
+          float s = acc[j];
+          s = fmaf(a.x, b.x, s);
+          s = fmaf(a.y, b.y, s);
+          s = fmaf(a.z, b.z, s);
+          s = fmaf(a.w, b.w, s);
+          acc[j] = s;
         }
-        acc[j] = s;
       }
     }
     __syncthreads();
