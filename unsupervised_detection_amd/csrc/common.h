@@ -160,6 +160,7 @@ struct PackJob {
   long total;
   int T, R, C, Kc, ldw, k_split, k_gap, mode;  // mode 0 forward, 1 transposed, 2 bias (dst[c] = b*gamma*c + beta | b),
                                                // 3/4 taps-into-N: dst[kmap(r)][t*C+c] = src[t][r][c] (3) | src[t][c][r] (4)
+                                               // 5/6 NN x2 + 3x3 as four 2x2 convolutions (T = 16 = class*4 + tap), forward / transposed
 };
 
 // --------------------------------------------------------------- wgrad ----

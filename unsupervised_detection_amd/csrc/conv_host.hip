@@ -157,11 +157,27 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
     int ks = k;  // source index of packed row k (-1 inside the zero gap)
     if (k >= j.k_split) ks = (k < j.k_split + j.k_gap) ? -1 : k - j.k_gap;
     int r = j.mode == 0 ? ks : n, c = j.mode == 0 ? n : ks;
-    if (j.mode >= 3) {  // taps folded into the N axis: column n = t*C + c
+    if (j.mode == 3 || j.mode == 4) {  // taps folded into the N axis: column n = t*C + c
       t = n / j.C;
       c = n - t * j.C;
       r = ks;
       if (t >= j.T) r = -1;
+    }
+    if (j.mode >= 5) {
+      // NN x2 + 3x3 as four 2x2 convolutions: t = class*4 + tap, class (py,px), tap (ty,tx); the taps of the 3x3 filter that
+      // read the same low-resolution row: py=0: {0}, {1,2}; py=1: {0,1}, {2} (columns alike).  mode 5: [t][k=ci][n=co],
+      // mode 6 (backward-data): [t][k=co][n=ci]
+      const int cls = t >> 2, ty = (t >> 1) & 1, tx = t & 1, py = cls >> 1, px = cls & 1;
+      const int y0 = py == 0 ? (ty == 0 ? 0 : 1) : (ty == 0 ? 0 : 2), y1 = py == 0 ? (ty == 0 ? 0 : 2) : (ty == 0 ? 1 : 2);
+      const int x0 = px == 0 ? (tx == 0 ? 0 : 1) : (tx == 0 ? 0 : 2), x1 = px == 0 ? (tx == 0 ? 0 : 2) : (tx == 0 ? 1 : 2);
+      const int ci = j.mode == 5 ? ks : n, co = j.mode == 5 ? n : ks;
+      if (ci >= 0 && ci < j.R && co >= 0 && co < j.C) {
+        for (int ky = y0; ky <= y1; ++ky)
+          for (int kx = x0; kx <= x1; ++kx) v += src[((long)(ky * 3 + kx) * j.R + ci) * j.C + co];
+        if (gamma) v *= gamma[co] * bn_c;
+      }
+      dst[e] = v;
+      continue;
     }
     if (r >= 0 && r < j.R && c >= 0 && c < j.C) {
       v = j.mode == 4 ? src[((long)t * j.C + c) * j.R + r] : src[((long)t * j.R + r) * j.C + c];

@@ -48,6 +48,9 @@ struct Layer {
   int KcT = 0, ldwT = 0;
   size_t wpT_off = 0;
   size_t bias_f_off = 0, scale_off = 0;  // BN-folded bias / per-channel scale (generator)
+  // NN x2 upsample + 3x3 convolution as four 2x2 convolutions on the low-resolution grid (one per output parity class, weights of
+  // taps that read the same low-resolution pixel pre-added): [16 = class*4 + tap][Kc][ldw] and its transpose for backward-data
+  size_t wu_off = 0, wuT_off = 0;
   // tensors
   int x = -1, x_coff = 0, y = -1, y_coff = 0;
   int res = -1, res_coff = 0, y2 = -1;

@@ -463,6 +463,10 @@ Plan* plan_build(const Config& cfg) {
       L.ldwT = round_up(L.cin, 4);
       L.wpT_off = off; off = align64(off + (size_t)T * L.KcT * L.ldwT);
     }
+    if (L.up) {
+      L.wu_off = off; off = align64(off + (size_t)16 * L.Kc * L.ldw);
+      L.wuT_off = off; off = align64(off + (size_t)16 * L.KcT * L.ldwT);
+    }
   };
   for (auto& L : P->pwc) place(L, false);
   for (auto& L : P->gen) place(L, true);

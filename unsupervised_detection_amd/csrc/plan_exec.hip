@@ -89,6 +89,40 @@ static void order_after(Plan* P, const Lane& from, const Lane& to) {
 }
 
 // ------------------------------------------------------------- runners ----
+// tf.image.resize_nearest_neighbor(x2) followed by a SAME 3x3 convolution (gen_deconv, convolution_utils.py:58-75) reads, for
+// the output pixel (2q+p), up-sampled rows 2q+p-1 .. 2q+p+1 = low-resolution rows {q-1, q, q} (p = 0) or {q, q, q+1} (p = 1): per
+// output parity class it is a 2x2 convolution over the low-resolution grid whose weights are sums of the 3x3 taps that read the
+// same pixel -- 16 instead of 36 tap products per low-resolution pixel, exactly the arithmetic of the reference up to the order of
+// the additions.  Tap t of class (py,px): row offset d(py,ty), column offset d(px,tx), weight matrix class*4 + t.
+static inline int up_off(int parity, int t) { return parity == 0 ? (t == 0 ? -1 : 0) : (t == 0 ? 0 : 1); }
+// forward: ncls = 4 launch on the low-resolution grid writing the four output sub-lattices
+static void setup_up_fwd(ConvParams& p, int N, int H, int W) {
+  p.N = N; p.H = H; p.W = W;
+  p.OH = 2 * H; p.OW = 2 * W; p.OHq = H; p.OWq = W;
+  p.osy = p.osx = 2; p.ooy = p.oox = 0; p.isy = p.isx = 1;
+  p.ncls = 4; p.ntaps = 16;
+  for (int c = 0; c < 4; ++c) {
+    p.cls_tap[c] = 4 * c;
+    for (int t = 0; t < 4; ++t) {
+      ConvTap& tp = p.taps[4 * c + t];
+      tp.dy = up_off(c >> 1, t >> 1); tp.dx = up_off(c & 1, t & 1); tp.widx = 4 * c + t;
+    }
+  }
+  p.cls_tap[4] = 16;
+}
+// backward-data: dX[q] = sum_{class, tap} dU[2(q - d) + p] Weff[class][tap]^T -- a stride-2 walk over the full-resolution dU
+static void setup_up_dgrad(ConvParams& p, int N, int H, int W) {
+  p.N = N; p.H = 2 * H; p.W = 2 * W;
+  p.OH = H; p.OW = W; p.OHq = H; p.OWq = W;
+  p.osy = p.osx = 1; p.ooy = p.oox = 0; p.isy = p.isx = 2;
+  p.ncls = 1; p.ntaps = 16;
+  for (int c = 0; c < 4; ++c)
+    for (int t = 0; t < 4; ++t) {
+      ConvTap& tp = p.taps[4 * c + t];
+      tp.dy = (c >> 1) - 2 * up_off(c >> 1, t >> 1); tp.dx = (c & 1) - 2 * up_off(c & 1, t & 1); tp.widx = 4 * c + t;
+    }
+}
+
 static void fill_common(Plan* P, ConvParams& p, float* ws, int slot) {
   p.partial = ws + P->scratch_off[slot];
   p.partial_cap = P->scratch_floats;
@@ -100,7 +134,9 @@ static int run_fwd(Plan* P, const Layer& L, int N, float* ws, const Lane& ln, si
   hipStream_t s = ln.s;
   const Buf &bx = P->buf(L.x), &by = P->buf(L.y);
   const int ncls = L.transposed ? conv_dgrad_classes(2, 2 * L.H, 2 * L.W) : 1;
-  prof_begin(P, PROF_CONV_FWD, layer_flops(L, N), 0, s, L.name.c_str());
+  // (the measurement pass books the multiply-adds the launch executes: 16 of the reference's 36 tap products per low-resolution
+  // pixel for the up-sampling layers)
+  prof_begin(P, PROF_CONV_FWD, layer_flops(L, N) * ((L.up && L.wu_off) ? 4.0 / 9.0 : 1.0), 0, s, L.name.c_str());
   if (L.col2im && (!L.transposed || ncls == 1) && x_extra == 0 && y_extra == 0) {
     // 2-channel head: the (tap, output channel) pairs become the N axis of ONE 1x1 GEMM over the deep channel axis
     // (every input byte read once, no 16x padding of the MFMA columns per tap), then a gather-sum over the taps
@@ -129,12 +165,14 @@ static int run_fwd(Plan* P, const Layer& L, int N, float* ws, const Lane& ln, si
     memset(&p, 0, sizeof(p));
     if (L.transposed) {
       if (!conv_setup_dgrad(p, cls, N, 2 * L.H, 2 * L.W, L.kh, L.kw, 2, 1)) continue;
+    } else if (L.up && L.wu_off) {
+      setup_up_fwd(p, N, L.H, L.W);
     } else {
       conv_setup_fwd(p, N, L.H << (L.up ? 1 : 0), L.W << (L.up ? 1 : 0), L.kh, L.kw, L.stride, L.dil);
       p.up_shift = L.up ? 1 : 0;
     }
     p.x = ws + bx.off + x_extra; p.ldx = bx.ld; p.x_coff = L.x_coff;
-    p.wp = ws + L.wp_off; p.Kc = L.Kc; p.ldw = L.ldw; p.bias = ws + L.bias_f_off;
+    p.wp = ws + ((L.up && L.wu_off) ? L.wu_off : L.wp_off); p.Kc = L.Kc; p.ldw = L.ldw; p.bias = ws + L.bias_f_off;
     p.y = ws + by.off + y_extra; p.ldy = by.ld; p.y_coff = L.y_coff; p.Cout = L.cout;
     p.act = L.act; p.alpha = L.alpha;
     if (L.res >= 0) { p.res = ws + P->buf(L.res).off; p.ldres = P->buf(L.res).ld; p.res_coff = L.res_coff; }
@@ -165,14 +203,16 @@ static int run_dgrad(Plan* P, const Layer& L, int N, int dy, bool dy_is_du, int 
     return UDET_ERR_SHAPE;
   }
   const int up = L.up ? 1 : 0;
-  prof_begin(P, PROF_CONV_DGRAD, layer_flops(L, N), 0, s, L.name.c_str());
-  for (int cls = 0; cls < conv_dgrad_classes(L.stride, L.H << up, L.W << up); ++cls) {
+  prof_begin(P, PROF_CONV_DGRAD, layer_flops(L, N) * ((L.up && L.wuT_off) ? 4.0 / 9.0 : 1.0), 0, s, L.name.c_str());
+  const bool upeff = L.up && L.wuT_off;  // gradient w.r.t. the LOW-resolution input in one launch (no up-sampled gradient, no pooling)
+  for (int cls = 0; cls < (upeff ? 1 : conv_dgrad_classes(L.stride, L.H << up, L.W << up)); ++cls) {
     ConvParams p;
     memset(&p, 0, sizeof(p));
-    if (!conv_setup_dgrad(p, cls, N, L.H << up, L.W << up, L.kh, L.kw, L.stride, L.dil)) continue;
+    if (upeff) setup_up_dgrad(p, N, L.H, L.W);
+    else if (!conv_setup_dgrad(p, cls, N, L.H << up, L.W << up, L.kh, L.kw, L.stride, L.dil)) continue;
     p.x = ws + bdy.off; p.ldx = bdy.ld; p.x_coff = L.y_coff;
     if (L.act != ACT_NONE && !dy_is_du) { p.xa = ws + ba.off; p.xact = L.act; p.xalpha = L.alpha; }
-    p.wp = ws + L.wpT_off; p.Kc = L.KcT; p.ldw = L.ldwT;
+    p.wp = ws + (upeff ? L.wuT_off : L.wpT_off); p.Kc = L.KcT; p.ldw = L.ldwT;
     p.y = ws + bdx.off; p.ldy = bdx.ld; p.y_coff = dx_coff; p.Cout = L.cin;
     p.accumulate = accumulate;
     if (res >= 0) { p.res = ws + P->buf(res).off; p.ldres = P->buf(res).ld; p.res_coff = 0; }
@@ -263,6 +303,16 @@ int plan_init_workspace(Plan* P, float* ws, hipStream_t s) {
         j.dst_off = (long)L.wz_off; j.R = L.cin; j.C = L.cout; j.Kc = L.Kc; j.ldw = L.ldz; j.k_split = L.k_split; j.k_gap = L.k_gap;
         j.mode = 3; j.total = (long)L.Kc * L.ldz;
         jobs.push_back(j);
+      }
+      if (L.up) {  // NN x2 + 3x3 as four 2x2 convolutions on the low-resolution grid (run_fwd / run_dgrad)
+        j.T = 16;
+        j.dst_off = (long)L.wu_off; j.R = L.cin; j.C = L.cout; j.Kc = L.Kc; j.ldw = L.ldw; j.k_split = L.Kc; j.k_gap = 0;
+        j.mode = 5; j.total = (long)16 * L.Kc * L.ldw;
+        jobs.push_back(j);
+        j.dst_off = (long)L.wuT_off; j.Kc = L.KcT; j.ldw = L.ldwT; j.k_split = L.KcT; j.k_gap = 0;
+        j.mode = 6; j.total = (long)16 * L.KcT * L.ldwT;
+        jobs.push_back(j);
+        j.T = T;
       }
       // bias (BN-folded for the generator)
       j.src_off = (long)np.p[L.b_idx].offset; j.dst_off = (long)L.bias_f_off; j.mode = 2; j.total = L.cout;
@@ -667,15 +717,9 @@ static int backward_generator(Plan* P, const float* w_gen, float* g_gen, float* 
     const int dx = B_(S("gen.d%d", i));
     const Layer& Lp = P->gen[i - 1];  // the layer whose output gradient this launch produces
     const int ap = Lp.y2 >= 0 ? Lp.y2 : Lp.y;
-    if (L.up) {
-      const int dup = B_(S("gen.dup%d", i + 1));
-      UDET_TRY(run_dgrad(P, L, B, dy, has_act, dup, 0, 0, -1, Emit(), ws, LD));
-      const Buf& bd = P->buf(dx);
-      UDET_TRY(launch_pool2x2_sum(ws + P->buf(dup).off, ws + bd.off, B, bd.h, bd.w, bd.ld, s));
-      if (Lp.act != ACT_NONE)
-        UDET_TRY(launch_emit_du(ws + bd.off, ws + P->buf(ap).off, ws + P->buf(B_(S("gen.u%d", i))).off, (long)B * bd.h * bd.w, bd.ld, 0,
-                                bd.ld, Lp.act, Lp.alpha, s));
-    } else {
+    {
+      // (up-sampling layers too: their backward-data launch walks the full-resolution dU with stride 2 and produces the gradient of
+      // the low-resolution input directly -- see setup_up_dgrad)
       Emit em;
       if (Lp.act != ACT_NONE) { em.ubuf = B_(S("gen.u%d", i)); em.abuf = ap; em.c0 = 0; em.c1 = L.cin; em.act = Lp.act; em.alpha = Lp.alpha; }
       UDET_TRY(run_dgrad(P, L, B, dy, has_act, dx, 0, 0, res, em, ws, LD));
