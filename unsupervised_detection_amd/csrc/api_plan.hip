@@ -184,20 +184,26 @@ int udet_profile_end(udet_plan* h, double* out, int ncat, void* stream) {
   g_launch_sink = nullptr;
   UDET_HIP(hipStreamSynchronize((hipStream_t)stream));
   for (int i = 0; i < ncat * 5; ++i) out[i] = 0.0;
-  FILE* dump = nullptr;  // UDET_PROF_DUMP=<file>: one CSV line per launch group (category,name,kernel ms,algorithmic GFLOP,MB,bracket ms,kernels)
+  FILE* dump = nullptr;  // UDET_PROF_DUMP=<file>: one CSV line per launch group (category,name,kernel ms,GFLOP,MB,bracket ms,kernels,each kernel's us)
   if (const char* path = getenv("UDET_PROF_DUMP")) dump = fopen(path, "a");
   for (auto* r : P->prof) {
     float wall = 0.f;
     (void)hipEventElapsedTime(&wall, r->a, r->b);
     double kern = 0.0;
+    std::string each;  // the kernels' own durations in launch order, microseconds, '+'-separated (last CSV column)
     for (int k = 0; k < r->sink.n; ++k) {
       float ms = 0.f;
       if (hipEventElapsedTime(&ms, r->kev[2 * k], r->kev[2 * k + 1]) == hipSuccess) kern += ms;
+      char buf[32];
+      snprintf(buf, sizeof(buf), "%s%.1f", k ? "+" : "", ms * 1e3f);
+      each += buf;
       (void)hipEventDestroy(r->kev[2 * k]);
       (void)hipEventDestroy(r->kev[2 * k + 1]);
     }
     if (r->sink.n == 0) kern = wall;  // (a group whose launches did not go through the sink)
-    if (dump) fprintf(dump, "%d,%s,%.4f,%.4f,%.4f,%.4f,%d\n", r->cat, r->name.c_str(), kern, r->flops * 1e-9, r->bytes * 1e-6, wall, r->sink.n);
+    if (dump)
+      fprintf(dump, "%d,%s,%.4f,%.4f,%.4f,%.4f,%d,%s\n", r->cat, r->name.c_str(), kern, r->flops * 1e-9, r->bytes * 1e-6, wall, r->sink.n,
+              each.c_str());
     if (r->cat < ncat) {
       out[r->cat * 5 + 0] += 1.0;
       out[r->cat * 5 + 1] += kern;

@@ -176,6 +176,9 @@ struct WgradParams {
   int yact;
   float yalpha;
   int OH, OW, isy, isx;
+  // ycls != 0 (NN x2 + 3x3 as four 2x2 convolutions, see plan_exec.hip): tap t belongs to output parity class t >> 2 and pairs X
+  // at its offset with dU on that class's sub-lattice of the (OHf, OWf) = (2 OH, 2 OW) grid; an M tile never straddles classes
+  int ycls, OHf, OWf;
   int ntaps;
   ConvTap taps[UDET_MAX_TAPS];  // widx = tap index in the HWIO weight
   float* dw;        // [ntaps_total][Cin][Cout]  (HWIO, written, not accumulated)
@@ -197,6 +200,9 @@ struct WgradParams {
   float bn_c;
 };
 int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream);
+int launch_bn_finalize(float* dw, int T, int Cin, int Cout, const float* w, const float* b, const float* gamma, float bn_c, float* pd,
+                       float* db, float* dgamma, float* dbeta, hipStream_t stream);
+int launch_wgrad_up_combine(const float* deff, float* dw, int Cin, int Cout, hipStream_t stream);
 size_t wgrad_partial_floats_needed(int T, int Cin, int Cout);
 
 }  // namespace udet

@@ -61,6 +61,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, in
   const int b_c4 = t % B_F4_ROW;
   const int b_co = co0 + b_c4 * 4;
   const bool b_on = b_co < cout4;
+  const int ycl = p.ycls ? (m0 / p.Cin4) >> 2 : 0;
+  // bias gradient = column sums of dU: by the first M tile (plain), by the first M tile of every parity class (class-structured
+  // form: each class sees its own quarter of the pixels; the reduction adds the four)
+  const bool bias_wg = p.ycls ? (m0 % (4 * p.Cin4) == 0) : (mt == 0);
+  const int bias_groups = p.ycls ? 4 : 1;
 
   floatx16 acc[TM][TN];
 #pragma unroll
@@ -95,7 +100,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, in
       const int q = q0 + t / B_F4_ROW + j * B_PIX;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (b_on && q < Q) {
-        const size_t off = (size_t)q * p.ldy + p.y_coff + b_co;
+        size_t pix = (size_t)q;
+        if (p.ycls) {  // this M tile's parity class: dU on its sub-lattice of the full-resolution grid
+          const int n = (int)fdiv(q, p.fd_ohw), rem = q - n * OHW;
+          const int oy = (int)fdiv(rem, p.fd_ow), ox = rem - oy * p.OW;
+          pix = ((size_t)n * p.OHf + 2 * oy + (ycl >> 1)) * p.OWf + 2 * ox + (ycl & 1);
+        }
+        const size_t off = pix * p.ldy + p.y_coff + b_co;
         v = *reinterpret_cast<const float4*>(p.dy + off);
         if (p.ya) {
           const float4 a = *reinterpret_cast<const float4*>(p.ya + off);
@@ -151,7 +162,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, in
 #pragma unroll
         for (int k = 0; k < BKP; ++k) bsum += As[buf][k][p.bias_m - m0 + t];
       }
-    } else if (mt == 0 && t < BN) {
+    } else if (bias_wg && t < BN) {
 #pragma unroll
       for (int k = 0; k < BKP; ++k) bsum += Bs[buf][k][t];
     }
@@ -173,8 +184,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, in
     }
   if (p.swapped) {
     if (co0 == 0 && t < p.Cin4 && p.bias_m >= m0 && p.bias_m < m0 + BM) p.pbias[(size_t)blockIdx.y * ldn + t] = bsum;
-  } else if (mt == 0 && t < BN) {
-    p.pbias[(size_t)blockIdx.y * ldn + co0 + t] = bsum;
+  } else if (bias_wg && t < BN) {
+    p.pbias[((size_t)blockIdx.y * bias_groups + ycl) * ldn + co0 + t] = bsum;
   }
 }
 
@@ -213,6 +224,7 @@ __global__ __launch_bounds__(512, 4) void conv_wgrad_dma_kernel(const WgradParam
   __syncthreads();
 
   if (role == 1) {
+    const int ycl = p.ycls ? (m0 / p.Cin4) >> 2 : 0;
     const int a_m4 = t % A_F4_ROW;
     const int a_m = m0 + a_m4 * 4;
     const int a_tap = a_m / p.Cin4, a_ci = a_m - a_tap * p.Cin4;
@@ -245,7 +257,13 @@ __global__ __launch_bounds__(512, 4) void conv_wgrad_dma_kernel(const WgradParam
         if (B_F4 % 256 != 0 && idx - lane + 63 >= B_F4 && idx - lane >= B_F4) continue;  // whole wave beyond the tile
         const int kp = idx / B_F4_ROW, c4 = idx - kp * B_F4_ROW;
         const int q = q0 + kp, co = co0 + c4 * 4;
-        const float* src = (idx < B_F4 && q < Q && co < cout4) ? p.dy + ((size_t)q * p.ldy + p.y_coff + co) : zero;
+        size_t pix = (size_t)q;
+        if (p.ycls && q < Q) {
+          const int n = (int)fdiv(q, p.fd_ohw), rem = q - n * OHW;
+          const int oy = (int)fdiv(rem, p.fd_ow), ox = rem - oy * p.OW;
+          pix = ((size_t)n * p.OHf + 2 * oy + (ycl >> 1)) * p.OWf + 2 * ox + (ycl & 1);
+        }
+        const float* src = (idx < B_F4 && q < Q && co < cout4) ? p.dy + (pix * p.ldy + p.y_coff + co) : zero;
         __builtin_amdgcn_global_load_lds(src, (lds_ptr)(&Bs[buf][0][0] + (j * 256 + wave * 64) * 4), 16, 0, 0);
       }
     };
@@ -264,6 +282,9 @@ __global__ __launch_bounds__(512, 4) void conv_wgrad_dma_kernel(const WgradParam
     return;
   }
 
+  const int ycl = p.ycls ? (m0 / p.Cin4) >> 2 : 0;
+  const bool bias_wg = p.ycls ? (m0 % (4 * p.Cin4) == 0) : (mt == 0);
+  const int bias_groups = p.ycls ? 4 : 1;
   floatx16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -306,7 +327,7 @@ __global__ __launch_bounds__(512, 4) void conv_wgrad_dma_kernel(const WgradParam
 #pragma unroll
         for (int k = 0; k < BKP; ++k) bsum += As[buf][k][p.bias_m - m0 + t];
       }
-    } else if (mt == 0 && t < BN) {
+    } else if (bias_wg && t < BN) {
 #pragma unroll
       for (int k = 0; k < BKP; ++k) bsum += Bs[buf][k][t];
     }
@@ -325,8 +346,8 @@ __global__ __launch_bounds__(512, 4) void conv_wgrad_dma_kernel(const WgradParam
     }
   if (p.swapped) {
     if (co0 == 0 && t < p.Cin4 && p.bias_m >= m0 && p.bias_m < m0 + BM) p.pbias[(size_t)blockIdx.y * ldn + t] = bsum;
-  } else if (mt == 0 && t < BN) {
-    p.pbias[(size_t)blockIdx.y * ldn + co0 + t] = bsum;
+  } else if (bias_wg && t < BN) {
+    p.pbias[((size_t)blockIdx.y * bias_groups + ycl) * ldn + co0 + t] = bsum;
   }
 }
 
@@ -345,16 +366,17 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradParams p, 
     if (is_bias && p.swapped && co >= p.oCout) continue;  // (uniform over the SL lanes of an element)
     const float* src = is_bias ? p.pbias + co : p.partial + (size_t)m * ldn + co;
     const size_t stride = is_bias ? (size_t)ldn : slab;
+    const int nsum = is_bias && p.ycls ? 4 * nsplit : nsplit;  // (class-structured form: four class partials per split)
     float s = 0.f;  // eight partials in flight per trip, added in split order
     int k = sl;
-    for (; k + 7 * SL < nsplit; k += 8 * SL) {
+    for (; k + 7 * SL < nsum; k += 8 * SL) {
       float a[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) a[u] = src[(size_t)(k + u * SL) * stride];
 #pragma unroll
       for (int u = 0; u < 8; ++u) s += a[u];
     }
-    for (; k < nsplit; k += SL) s += src[k * stride];
+    for (; k < nsum; k += SL) s += src[k * stride];
 #pragma unroll
     for (int d = SL / 2; d > 0; d >>= 1) s += __shfl_xor(s, d, SL);
     if (sl != 0) continue;
@@ -407,6 +429,37 @@ __global__ __launch_bounds__(256) void bn_finish_kernel(float* __restrict__ dw, 
   }
 }
 
+// BN-folded generator layers: dw (holding G) *= gamma*c ; dgamma = c*(sum W*G + b*S) ; dbeta = S ; db = gamma*c*S  (S arrives in db)
+int launch_bn_finalize(float* dw, int T, int Cin, int Cout, const float* w, const float* b, const float* gamma, float bn_c, float* pd,
+                       float* db, float* dgamma, float* dbeta, hipStream_t stream) {
+  const size_t wsz = (size_t)T * Cin * Cout;
+  int nbw = (int)((wsz + 255) / 256);
+  if (nbw > 2048) nbw = 2048;
+  UDET_LAUNCH(bn_dot_kernel, dim3((Cout + 63) / 64, BND_SPLIT), dim3(256), 0, stream, w, dw, T * Cin, Cout, pd);
+  UDET_LAUNCH(bn_finish_kernel, dim3(nbw), dim3(256), 0, stream, dw, (long)wsz, Cout, gamma, b, bn_c, pd, db, dgamma, dbeta);
+  UDET_HIP(hipGetLastError());
+  return UDET_OK;
+}
+// dW[ky][kx] = sum over the four parity classes of dWeff[class][tap of that class that contains (ky,kx)]   (NN x2 + 3x3)
+__global__ __launch_bounds__(256) void wgrad_up_combine_kernel(const float* __restrict__ deff, float* __restrict__ dw, int CC) {
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < 9 * CC; e += gridDim.x * 256) {
+    const int k = e / CC, r = e - k * CC, ky = k / 3, kx = k - ky * 3;
+    float v = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int py = c >> 1, px = c & 1;
+      const int ty = py == 0 ? (ky == 0 ? 0 : 1) : (ky == 2 ? 1 : 0), tx = px == 0 ? (kx == 0 ? 0 : 1) : (kx == 2 ? 1 : 0);
+      v += deff[(size_t)(4 * c + 2 * ty + tx) * CC + r];
+    }
+    dw[e] = v;
+  }
+}
+int launch_wgrad_up_combine(const float* deff, float* dw, int Cin, int Cout, hipStream_t stream) {
+  const int CC = Cin * Cout;
+  UDET_LAUNCH(wgrad_up_combine_kernel, dim3((9 * CC + 255) / 256 > 1024 ? 1024 : (9 * CC + 255) / 256), dim3(256), 0, stream, deff, dw, CC);
+  UDET_HIP(hipGetLastError());
+  return UDET_OK;
+}
 size_t wgrad_partial_floats_needed(int T, int Cin, int Cout) {
   // BN dot partials + one split of (bias, filter) partials at the padded tile sizes
   const size_t cin4 = (size_t)((Cin + 3) & ~3), mpad = (T * cin4 + 127) / 128 * 128, ldn = (size_t)(Cout + 127) / 128 * 128;
@@ -473,6 +526,10 @@ int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream) {
   const int BM = 128;
   const int bn = g.Cout > 64 ? 128 : (g.Cout > 32 ? 64 : 32);
   g.Cin4 = (g.Cin + 3) & ~3;
+  if (p.ycls && (g.swapped || (4 * g.Cin4) % BM != 0 || p.ntaps != 16)) {
+    set_error("wgrad: class-structured form needs 16 taps and 4*Cin a multiple of %d (Cin=%d)", BM, p.Cin);
+    return UDET_ERR_SHAPE;
+  }
   const int Mreal = g.ntaps * g.Cin4;
   const int m_tiles = Mreal > 0 ? (Mreal + BM - 1) / BM : 1, co_tiles = (g.Cout + bn - 1) / bn;
   g.Mpad = m_tiles * BM;
@@ -485,7 +542,8 @@ int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream) {
   float* base = pd + (size_t)BND_SPLIT * p.Cout;
   base += (16 - ((uintptr_t)base / sizeof(float)) % 16) % 16;  // keep the slabs 64-byte aligned
   const size_t fixed = (size_t)(base - p.partial);
-  const size_t per_split = (size_t)ldn + (size_t)g.Mpad * ldn;
+  const size_t bgroups = p.ycls ? 4 : 1;
+  const size_t per_split = bgroups * (size_t)ldn + (size_t)g.Mpad * ldn;
   if (p.partial_floats < fixed + per_split) {
     set_error("wgrad: workspace too small (%zu < %zu floats)", p.partial_floats, fixed + per_split);
     return UDET_ERR_ARG;
@@ -505,8 +563,8 @@ int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream) {
     const int ns = cfg & 0xfffff;
     const bool dma = dma_ok && (cfg >> 20) != 0;
     WgradParams q = g;
-    q.pbias = base;                              // [ns][ldn]
-    q.partial = base + (size_t)ns * ldn;        // [ns][Mpad][ldn]
+    q.pbias = base;                                        // [ns][bias groups][ldn]
+    q.partial = base + (size_t)ns * bgroups * ldn;        // [ns][Mpad][ldn]
     if (bn == 128) wgrad_launch<128, 128, 2, 2>(q, m_tiles, co_tiles, ns, dma, stream);
     else if (bn == 64) wgrad_launch<128, 64, 2, 2>(q, m_tiles, co_tiles, ns, dma, stream);
     else wgrad_launch<128, 32, 4, 1>(q, m_tiles, co_tiles, ns, dma, stream);
@@ -519,7 +577,7 @@ int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream) {
   };
   // autotuned split count (see conv_igemm.hip): kernel + reduction timed together
   {
-    const int f[] = {p.N, p.H, p.W, p.up_shift, p.Cin, p.Cout, p.ntaps, p.OH, p.OW, p.isy, p.ya ? 1 : 0, p.ldx, p.ldy, cap, dma_ok ? 1 : 0, g.swapped};
+    const int f[] = {p.N, p.H, p.W, p.up_shift, p.Cin, p.Cout, p.ntaps, p.OH, p.OW, p.isy, p.ya ? 1 : 0, p.ldx, p.ldy, cap, dma_ok ? 1 : 0, g.swapped, p.ycls};
     uint64_t key = 1469598103934665603ull;
     for (int v : f) { key ^= (uint64_t)(uint32_t)v; key *= 1099511628211ull; }
     bool have = false;

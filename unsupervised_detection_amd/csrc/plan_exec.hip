@@ -260,6 +260,35 @@ static int run_wgrad(Plan* P, const Layer& L, int N, int dy, bool dy_is_du, cons
     q.dbeta = g_flat + np.p[L.be_idx].offset;
     q.bn_c = BN_C;
   }
+  if (L.up && L.wu_off && L.g_idx >= 0 && dy_is_du) {
+    // NN x2 + 3x3 as four 2x2 convolutions (setup_up_fwd): dWeff[class][tap] = sum_q X[q + d]^T dU[2q + p] over the low-resolution
+    // pixels (16 instead of 36 tap products each), then dW[ky][kx] = sum over the classes of the effective tap that contains it,
+    // then the BN finalisation
+    ConvParams u;
+    memset(&u, 0, sizeof(u));
+    setup_up_fwd(u, N, L.H, L.W);
+    q.H = L.H; q.W = L.W; q.up_shift = 0;
+    q.OH = L.H; q.OW = L.W; q.isy = q.isx = 1;
+    q.ycls = 1; q.OHf = 2 * L.H; q.OWf = 2 * L.W;
+    q.ntaps = 16;
+    memcpy(q.taps, u.taps, sizeof(u.taps));
+    const size_t reserve = (size_t)16 * L.cin * L.cout + 64 * (size_t)L.cout + 1024;
+    float* deff = ws + P->wgrad_off[ln.slot] + (P->wgrad_floats - reserve);  // [16][Cin][Cout] + BN-dot partials
+    float* pd = deff + (size_t)16 * L.cin * L.cout;
+    q.partial_floats = P->wgrad_floats - reserve;
+    float* dw = q.dw;
+    float* db = q.db;
+    q.dw = deff;  // (q.db: the kernel's own column sums of dU, four class partials per split)
+    const float *w_ = q.w, *b_ = q.b, *gamma_ = q.gamma;
+    float *dgamma_ = q.dgamma, *dbeta_ = q.dbeta;
+    q.w = q.b = q.gamma = nullptr; q.dgamma = q.dbeta = nullptr;
+    prof_begin(P, PROF_CONV_WGRAD, layer_flops(L, N) * 4.0 / 9.0, 0, s, L.name.c_str());
+    int rc = launch_wgrad_T(q, 16, s);
+    if (rc == UDET_OK) rc = launch_wgrad_up_combine(deff, dw, L.cin, L.cout, s);
+    if (rc == UDET_OK) rc = launch_bn_finalize(dw, 9, L.cin, L.cout, w_, b_, gamma_, BN_C, pd, db, dgamma_, dbeta_, s);
+    prof_end(P, s);
+    return rc;
+  }
   prof_begin(P, PROF_CONV_WGRAD, layer_flops(L, N), 0, s, L.name.c_str());
   const int rc = launch_wgrad_T(q, L.kh * L.kw, s);
   prof_end(P, s);
