@@ -499,7 +499,9 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_dma_kernel(const ConvParams
     rowoff[r] = off;
   }
   const int Kc = p.Kc;
-  const int nchunks = (ntc * Kc + BK - 1) / BK;
+  // kfast (Kc >= 32, no up-sampled read): a stage is ONE (channel block, tap) pair -- the last, narrower block is padded with zero
+  // lanes instead of straddling into the next tap -- so the K cursor is wave-uniform (see the staging waves)
+  const int nchunks = p.kfast ? ntc * ((Kc + 31) >> 5) : (ntc * Kc + BK - 1) / BK;
   int c_begin = 0, c_end = nchunks;
   if (p.ksplit > 1) {
     c_begin = (int)((long)nchunks * blockIdx.z / p.ksplit);
@@ -527,12 +529,15 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_dma_kernel(const ConvParams
         a_ix0[j] = 0;
       }
     }
-    const KOrder ko = korder(Kc, ntc);
-    KCursor ka = kc_init(ko, c_begin * BK + kqs * 4), kb[B_LD];
-#pragma unroll
-    for (int j = 0; j < B_LD; ++j) kb[j] = kc_init(ko, c_begin * BK + (t + j * 256) / B_F4_ROW);
     const float* zero = p.zero16;
-    auto issue = [&](int buf) {
+    // Generic K cursor (stages may straddle taps: Kc < 32 or an up-sampled read): per-lane (block, tap, channel) cursors advanced
+    // with data-dependent control flow -- ~1500 instructions per stage for a 128x128 tile, more than the 4096 MFMA cycles of the
+    // stage leave room for on a SIMD that also hosts an MFMA wave.  The uniform cursor below needs ~100.
+    const KOrder ko = korder(Kc, ntc);
+    KCursor ka = kc_init(ko, p.kfast ? 0 : c_begin * BK + kqs * 4), kb[B_LD];
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) kb[j] = kc_init(ko, p.kfast ? 0 : c_begin * BK + (t + j * 256) / B_F4_ROW);
+    auto issue_generic = [&](int buf) {
       int dy = 0, dx = 0;
       const bool a_ok = kc_valid(ko, ka);
       const int a_c = kc_chan(ko, ka);
@@ -562,6 +567,48 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_dma_kernel(const ConvParams
       kc_advance(ko, ka, BK);
 #pragma unroll
       for (int j = 0; j < B_LD; ++j) kc_advance(ko, kb[j], BK);
+    };
+    // Uniform K cursor: stage s = (block s / ntc, tap s % ntc), kept in scalars.  Per lane and row only constants remain: the
+    // element offset of the row's pixel at tap (0,0) and channel slot kqs, the weight row / column of each B quad.
+    int a_off[A_LD];
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j)
+      a_off[j] = a_iy0[j] < -(1 << 27) ? 0 : (a_base[j] + a_iy0[j] * Ws + a_ix0[j]) * p.ldx + p.x_coff + kqs * 4;  // (rows past the grid: never read)
+    int b_off[B_LD], b_row[B_LD];
+    bool b_col[B_LD];
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) {
+      const int idx = t + j * 256, row = idx / B_F4_ROW, n = n0 + (idx - row * B_F4_ROW) * 4;
+      b_row[j] = row;
+      b_off[j] = row * p.ldw + n;
+      b_col[j] = n < p.ldw;
+    }
+    int s_blk = __builtin_amdgcn_readfirstlane(c_begin / (ntc > 0 ? ntc : 1));
+    int s_tap = __builtin_amdgcn_readfirstlane(c_begin - s_blk * ntc);
+    auto issue_fast = [&](int buf) {
+      const int2 yx = tap_yx[s_tap];
+      const int dy = yx.x, dx = yx.y, c0 = s_blk << 5;
+      const int tap_off = (dy * Ws + dx) * p.ldx + c0;
+      const bool ch_ok = c0 + kqs * 4 < Kc;
+#pragma unroll
+      for (int j = 0; j < A_LD; ++j) {
+        const int iy = a_iy0[j] + dy, ix = a_ix0[j] + dx;
+        const bool ok = ch_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const float* src = ok ? p.x + (a_off[j] + tap_off) : zero;
+        __builtin_amdgcn_global_load_lds(src, (lds_ptr)&As[buf][j * 32 + wave * 8][0], 16, 0, 0);
+      }
+      const float* wrow = p.wp + ((size_t)tap_w[s_tap] * Kc + c0) * p.ldw;
+#pragma unroll
+      for (int j = 0; j < B_LD; ++j) {
+        const bool ok = b_col[j] && c0 + b_row[j] < Kc;
+        const float* src = ok ? wrow + b_off[j] : zero;
+        __builtin_amdgcn_global_load_lds(src, (lds_ptr)(&Bs[buf][0][0] + (j * 256 + wave * 64) * 4), 16, 0, 0);
+      }
+      if (++s_tap == ntc) { s_tap = 0; ++s_blk; }
+    };
+    auto issue = [&](int buf) {
+      if (p.kfast) issue_fast(buf);
+      else issue_generic(buf);
     };
     auto landed = [&]() {  // all DMA of this wave has been written to LDS, then meet the MFMA waves
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -700,7 +747,8 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_dma4_kernel(const ConvParam
     rowoff[r] = off;
   }
   const int Kc = p.Kc;
-  const int nchunks = (ntc * Kc + BK - 1) / BK;
+  // kfast: a stage is one half (16 channels) of ONE (32-channel block, tap) pair -- uniform K cursor, see conv_igemm_dma_kernel
+  const int nchunks = p.kfast ? 2 * ntc * ((Kc + 31) >> 5) : (ntc * Kc + BK - 1) / BK;
   int c_begin = 0, c_end = nchunks;
   if (p.ksplit > 1) {
     c_begin = (int)((long)nchunks * blockIdx.z / p.ksplit);
@@ -727,12 +775,12 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_dma4_kernel(const ConvParam
       a_ix0[j] = 0;
     }
   }
-  const KOrder ko = korder(Kc, ntc);
-  KCursor ka = kc_init(ko, c_begin * BK + kqs * 4), kb[B_LD];
-#pragma unroll
-  for (int j = 0; j < B_LD; ++j) kb[j] = kc_init(ko, c_begin * BK + (t + j * 256) / B_F4_ROW);
   const float* zero = p.zero16;
-  auto issue = [&](int buf) {
+  const KOrder ko = korder(Kc, ntc);
+  KCursor ka = kc_init(ko, p.kfast ? 0 : c_begin * BK + kqs * 4), kb[B_LD];
+#pragma unroll
+  for (int j = 0; j < B_LD; ++j) kb[j] = kc_init(ko, p.kfast ? 0 : c_begin * BK + (t + j * 256) / B_F4_ROW);
+  auto issue_generic = [&](int buf) {
     int dy = 0, dx = 0;
     const bool a_ok = kc_valid(ko, ka);
     const int a_c = kc_chan(ko, ka);
@@ -764,6 +812,54 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_dma4_kernel(const ConvParam
     kc_advance(ko, ka, BK);
 #pragma unroll
     for (int j = 0; j < B_LD; ++j) kc_advance(ko, kb[j], BK);
+  };
+  // uniform cursor: stage s = (block, tap, half) = (s / (2 ntc), (s / 2) % ntc, s & 1), kept in scalars
+  int a_off[A_LD];
+#pragma unroll
+  for (int j = 0; j < A_LD; ++j)
+    a_off[j] = a_iy0[j] < -(1 << 27) ? 0 : (a_base[j] + a_iy0[j] * Ws + a_ix0[j]) * p.ldx + p.x_coff + kqs * 4;
+  int b_off[B_LD], b_row[B_LD];
+  bool b_col[B_LD];
+#pragma unroll
+  for (int j = 0; j < B_LD; ++j) {
+    const int idx = t + j * 256, row = idx / B_F4_ROW, n = n0 + (idx - row * B_F4_ROW) * 4;
+    b_row[j] = row;
+    b_off[j] = row * p.ldw + n;
+    b_col[j] = n < p.ldw;
+  }
+  const int ntc_ = ntc > 0 ? ntc : 1;
+  int s_half = __builtin_amdgcn_readfirstlane(c_begin & 1);
+  int s_blk = __builtin_amdgcn_readfirstlane((c_begin >> 1) / ntc_);
+  int s_tap = __builtin_amdgcn_readfirstlane((c_begin >> 1) - s_blk * ntc_);
+  auto issue_fast = [&](int buf) {
+    const int2 yx = tap_yx[s_tap];
+    const int dy = yx.x, dx = yx.y, c0 = (s_blk << 5) + (s_half << 4);
+    const int tap_off = (dy * Ws + dx) * p.ldx + c0;
+    const bool ch_ok = c0 + kqs * 4 < Kc;
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) {
+      const int iy = a_iy0[j] + dy, ix = a_ix0[j] + dx;
+      const bool ok = ch_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const float* src = ok ? p.x + (a_off[j] + tap_off) : zero;
+      __builtin_amdgcn_global_load_lds(src, (lds_ptr)&As[buf][j * 64 + wave * 16][0], 16, 0, 0);
+    }
+    const float* wrow = p.wp + ((size_t)tap_w[s_tap] * Kc + c0) * p.ldw;
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) {
+      if (j * 256 + wave * 64 < B_F4) {  // wave-uniform
+        const bool ok = b_col[j] && c0 + b_row[j] < Kc;
+        const float* src = ok ? wrow + b_off[j] : zero;
+        __builtin_amdgcn_global_load_lds(src, (lds_ptr)(&Bs[buf][0][0] + (j * 256 + wave * 64) * 4), 16, 0, 0);
+      }
+    }
+    if (++s_half == 2) {
+      s_half = 0;
+      if (++s_tap == ntc) { s_tap = 0; ++s_blk; }
+    }
+  };
+  auto issue = [&](int buf) {
+    if (p.kfast) issue_fast(buf);
+    else issue_generic(buf);
   };
   auto meet = [&]() {  // this wave's DMA has landed and its fragment reads are done, then meet the other waves
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -1199,6 +1295,7 @@ int launch_conv(ConvParams& p, hipStream_t stream) {
   }
   p.fd_ohw = make_fastdiv((unsigned)(p.OHq * p.OWq));
   p.fd_ow = make_fastdiv((unsigned)p.OWq);
+  p.kfast = p.Kc >= 32 && p.up_shift == 0;
   ConvCfg c;
   bool have = false;
   const uint64_t key = conv_key(p);
