@@ -958,6 +958,46 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const ConvPar
   }
 }
 
+// the one-lane-per-element form with four consecutive channels per thread: 16-byte slab loads (a quarter of the load instructions
+// and address arithmetic per byte), the same per-element summation order as conv_splitk_epilogue_kernel<1>
+__global__ __launch_bounds__(256) void conv_splitk_epilogue4_kernel(const ConvParams p) {
+  const int OHWq = p.OHq * p.OWq;
+  const int Mtot = p.N * OHWq;
+  const int Mall = p.ncls * Mtot;
+  const int nq = p.ldp >> 2;  // quads per partial row (ldp = Cout rounded up to 4)
+  const long total = (long)Mall * nq;
+  const size_t slab = (size_t)Mall * p.ldp;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int ma = (int)(e / nq), n = (int)(e - (long)ma * nq) * 4;
+    const float* src = p.partial + (size_t)ma * p.ldp + n;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    int s = 0;
+    for (; s + 3 < p.ksplit; s += 4) {
+      const float4 a0 = *reinterpret_cast<const float4*>(src + (size_t)s * slab);
+      const float4 a1 = *reinterpret_cast<const float4*>(src + (size_t)(s + 1) * slab);
+      const float4 a2 = *reinterpret_cast<const float4*>(src + (size_t)(s + 2) * slab);
+      const float4 a3 = *reinterpret_cast<const float4*>(src + (size_t)(s + 3) * slab);
+      v.x += a0.x; v.y += a0.y; v.z += a0.z; v.w += a0.w;
+      v.x += a1.x; v.y += a1.y; v.z += a1.z; v.w += a1.w;
+      v.x += a2.x; v.y += a2.y; v.z += a2.z; v.w += a2.w;
+      v.x += a3.x; v.y += a3.y; v.z += a3.z; v.w += a3.w;
+    }
+    for (; s < p.ksplit; ++s) {
+      const float4 a0 = *reinterpret_cast<const float4*>(src + (size_t)s * slab);
+      v.x += a0.x; v.y += a0.y; v.z += a0.z; v.w += a0.w;
+    }
+    const int cls = ma / Mtot, m = ma - cls * Mtot;
+    const int ooy = p.ncls > 1 ? (cls >> 1) : p.ooy, oox = p.ncls > 1 ? (cls & 1) : p.oox;
+    const int nb = (int)fdiv(m, p.fd_ohw), rem = m - nb * OHWq;
+    const int qy = (int)fdiv(rem, p.fd_ow), qx = rem - qy * p.OWq;
+    const int off = (nb * p.OH + qy * p.osy + ooy) * p.OW + qx * p.osx + oox;
+    if (n < p.Cout) conv_epilogue(p, off, n, v.x);
+    if (n + 1 < p.Cout) conv_epilogue(p, off, n + 1, v.y);
+    if (n + 2 < p.Cout) conv_epilogue(p, off, n + 2, v.z);
+    if (n + 3 < p.Cout) conv_epilogue(p, off, n + 3, v.w);
+  }
+}
+
 static int g_force_bm = 0, g_force_bn = 0, g_force_ks = -1, g_force_ws = -1, g_force_fold = -1;
 static int g_last_cfg = 0;  // kernel family / tile / split count of the most recent launch_conv (debug query)
 int conv_last_config() { return g_last_cfg; }
@@ -995,7 +1035,10 @@ static int launch_cfg(const ConvParams& p, int ws, hipStream_t stream) {
     const int nb = (int)(nbl > 4096 ? 4096 : nbl);
     if (sl == 16) UDET_LAUNCH(conv_splitk_epilogue_kernel<16>, dim3(nb), dim3(256), 0, stream, p);
     else if (sl == 4) UDET_LAUNCH(conv_splitk_epilogue_kernel<4>, dim3(nb), dim3(256), 0, stream, p);
-    else UDET_LAUNCH(conv_splitk_epilogue_kernel<1>, dim3(nb), dim3(256), 0, stream, p);
+    else if (p.ldp % 4 == 0 && !(reinterpret_cast<uintptr_t>(p.partial) & 15)) {
+      const long nb4l = ((long)p.ncls * Mtot * (p.ldp >> 2) + 255) / 256;
+      UDET_LAUNCH(conv_splitk_epilogue4_kernel, dim3((int)(nb4l > 4096 ? 4096 : nb4l)), dim3(256), 0, stream, p);
+    } else UDET_LAUNCH(conv_splitk_epilogue_kernel<1>, dim3(nb), dim3(256), 0, stream, p);
     UDET_HIP(hipGetLastError());
   }
   return UDET_OK;
