@@ -10,6 +10,9 @@ extern "C" {
  * second launch, bit 21: split-K summed by the last-arriving workgroup); (0,0,-1) restores.  A forced family a launch is not
  * eligible for falls back to the built-in choice.  Process-global state: never call it from product code. */
 void udet_debug_force_conv(int bm, int bn, int ks);
+/* while on, the first single-op launch of every distinct problem shape times its candidate configurations and caches the winner
+ * (what udet_autotune does for a plan); tools/conv_bench.py / wgrad_bench.py use it to measure the tuned kernels stand-alone */
+void udet_debug_set_tuning(int on);
 /* what the most recent convolution launch actually ran: family (0 plain, 1 wave-specialised, 2 LDS-DMA, 3 tile-resident,
  * 6 self-staging LDS-DMA) | tile rows << 8 | split count << 20 | folded split-K << 28 */
 int udet_debug_last_conv(void);
