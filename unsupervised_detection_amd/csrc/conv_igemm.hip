@@ -98,11 +98,94 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, int off, int 
     p.uo[(size_t)off * p.ldu + p.u_coff + n] = v * act_dfo(p.ua[(size_t)off * p.ldua + p.ua_coff + n], p.uact, p.ualpha);
 }
 
+// Four consecutive channels of one output element row at once (every operand 16-byte aligned: epilogue4_ok).
+__device__ __forceinline__ float4 act_fwd4(float4 v, int act, float alpha) {
+  return make_float4(act_fwd(v.x, act, alpha), act_fwd(v.y, act, alpha), act_fwd(v.z, act, alpha), act_fwd(v.w, act, alpha));
+}
+__device__ __forceinline__ void conv_epilogue4(const ConvParams& p, int off, int n, float4 v) {
+  if (p.bias) {
+    v.x += p.bias[n]; v.y += p.bias[n + 1]; v.z += p.bias[n + 2]; v.w += p.bias[n + 3];
+  }
+  v = act_fwd4(v, p.act, p.alpha);
+  if (p.y2) *reinterpret_cast<float4*>(p.y2 + (size_t)off * p.ldy2 + p.y2_coff + n) = v;
+  if (p.res) {
+    const float4 r = *reinterpret_cast<const float4*>(p.res + (size_t)off * p.ldres + p.res_coff + n);
+    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+  }
+  float4* dst = reinterpret_cast<float4*>(p.y + (size_t)off * p.ldy + p.y_coff + n);
+  if (p.accumulate) {
+    const float4 o = *dst;
+    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+  }
+  *dst = v;
+  if (p.uo && n >= p.u_c0 && n < p.u_c1) {  // (u_c0, u_c1 multiples of 4: the quad is inside or outside as a whole)
+    const float4 ua = *reinterpret_cast<const float4*>(p.ua + (size_t)off * p.ldua + p.ua_coff + n);
+    *reinterpret_cast<float4*>(p.uo + (size_t)off * p.ldu + p.u_coff + n) =
+        make_float4(v.x * act_dfo(ua.x, p.uact, p.ualpha), v.y * act_dfo(ua.y, p.uact, p.ualpha), v.z * act_dfo(ua.z, p.uact, p.ualpha),
+                    v.w * act_dfo(ua.w, p.uact, p.ualpha));
+  }
+}
+__device__ __forceinline__ bool epilogue4_ok(const ConvParams& p) {
+  auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  if (p.ksplit > 1) return al(p.partial);  // slab rows are ldp = 4k floats wide
+  bool ok = (p.Cout & 3) == 0 && ((p.ldy | p.y_coff) & 3) == 0 && al(p.y);
+  if (p.y2) ok = ok && ((p.ldy2 | p.y2_coff) & 3) == 0 && al(p.y2);
+  if (p.res) ok = ok && ((p.ldres | p.res_coff) & 3) == 0 && al(p.res);
+  if (p.uo) ok = ok && ((p.ldu | p.u_coff | p.ldua | p.ua_coff | p.u_c0 | p.u_c1) & 3) == 0 && al(p.uo) && al(p.ua);
+  return ok;
+}
+// per-wave LDS scratch of the transposing store below: 16 rows x UDET_XP floats, carved out of the (now idle) stage buffers
+#define UDET_XP 40
+template <size_t SA, size_t SB>
+__device__ __forceinline__ float* xpose_scratch(float* a, float* b, int wave) {
+  constexpr size_t W = 16 * UDET_XP * sizeof(float);
+  if constexpr (SA >= 4 * W) return a + wave * 16 * UDET_XP;
+  else if constexpr (SB >= 4 * W) return b + wave * 16 * UDET_XP;
+  else if constexpr (SA >= 2 * W && SB >= 2 * W) return (wave < 2 ? a : b) + (wave & 1) * 16 * UDET_XP;
+  else return nullptr;
+}
+
 // Result of one workgroup: plain launches run the epilogue; split-K launches store the partial tile into slab blockIdx.z
 // (row index = parity class * Mtot + pixel).
+// The MFMA accumulator holds COLUMN n = lane of 8+8 rows, so a direct store is one dword per lane and (bias, activation, 64-bit
+// address, flag tests) once per element -- ~13,000 instructions for a 128x128 tile, more than the instruction cache holds, and
+// ~15 % of the run time of a mid-size layer.  With `xp` (16 x UDET_XP floats of LDS per wave) the tile goes through LDS half a
+// 32x32 block at a time and leaves as float4 rows: 8 lanes x 16 B per pixel, epilogue arithmetic once per quad, and the
+// store loop is not unrolled (4 x 2 copies of its body instead of 256).
 template <int TM, int TN, int WTM, int WTN>
 __device__ __forceinline__ void igemm_store(const ConvParams& p, floatx16 (&acc)[TM][TN], const int* rowoff, int wm, int wn, int li,
-                                            int lh, int n0, int prow0, int Mtot) {
+                                            int lh, int n0, int prow0, int Mtot, float* xp = nullptr) {
+  const bool slab = p.ksplit > 1;
+  if (xp != nullptr && !(slab && p.fold) && epilogue4_ok(p)) {
+    const int lane = lh * 32 + li, rr = lane >> 3, c4 = (lane & 7) * 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int nb = n0 + wn * WTN + j * 32 + c4;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {  // accumulator registers 8h .. 8h+7 are rows 16h .. 16h+15 of the block
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int r = 0; r < 8; ++r) xp[((r & 3) + 8 * (r >> 2) + 4 * lh) * UDET_XP + li] = acc[i][j][8 * h + r];
+          __builtin_amdgcn_wave_barrier();  // same wave: LDS serves its instructions in order, only the compiler must not reorder
+#pragma unroll 1
+          for (int pass = 0; pass < 2; ++pass) {
+            const int row = wm * WTM + i * 32 + h * 16 + pass * 8 + rr;
+            const int off = rowoff[row];
+            const float4 v = *reinterpret_cast<const float4*>(&xp[(pass * 8 + rr) * UDET_XP + c4]);
+            if (off < 0) continue;
+            if (slab) {
+              if (nb < p.ldp) *reinterpret_cast<float4*>(p.partial + ((size_t)blockIdx.z * p.ncls * Mtot + prow0 + row) * p.ldp + nb) = v;
+            } else if (nb < p.Cout) {
+              conv_epilogue4(p, off, nb, v);
+            }
+          }
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -206,7 +289,7 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 2) void conv_igemm_kernel(
   constexpr int B_LD = BK * B_F4_ROW / 256;
   static_assert(B_LD * 256 == BK * B_F4_ROW, "BK*BN/4 must be a multiple of 256");
 
-  __shared__ float As[2][BK][LDA];
+  __shared__ __attribute__((aligned(16))) float As[2][BK][LDA];
   __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
   __shared__ int rowoff[BM];
   __shared__ int2 tap_yx[UDET_MAX_TAPS];
@@ -428,7 +511,8 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 2) void conv_igemm_kernel(
   }
 
   // ---- epilogue -------------------------------------------------------------
-  igemm_store<TM, TN, WTM, WTN>(p, acc, rowoff, wm, wn, li, lh, n0, cls * Mtot + m0, Mtot);
+  igemm_store<TM, TN, WTM, WTN>(p, acc, rowoff, wm, wn, li, lh, n0, cls * Mtot + m0, Mtot,
+                                xpose_scratch<sizeof(As), sizeof(Bs)>(&As[0][0][0], &Bs[0][0][0], wave));
   if (p.ksplit > 1 && p.fold) splitk_fold<BM, BN, 256>(p, rowoff, &s_last, t, n0, cls * Mtot + m0, Mtot, blockIdx.y * gridDim.x + bid);
 }
 
@@ -441,8 +525,9 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 2) void conv_igemm_kernel(
 // (conflict-free under the swizzle) and walk K in the permuted order {4g+e : g = 2*kk+half}, which the B fragment
 // reads ([k][n] rows, ds_read_b32) follow.  Same flat-K / parity-class / split-K semantics as conv_igemm_kernel.
 // ---------------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(512, 4) void conv_igemm_dma_kernel(const ConvParams p) {
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NS>
+__global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void conv_igemm_dma_kernel(const ConvParams p) {
+  static_assert(NS >= 2 && NS <= 4, "stages");
   static_assert(WAVES_M * WAVES_N == 4, "4 MFMA waves");
   constexpr int BK = 32;
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
@@ -454,8 +539,8 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_dma_kernel(const ConvParams
   static_assert(B_LD * 256 == BK * B_F4_ROW, "BK*BN/4 must be a multiple of 256");
   typedef __attribute__((address_space(3))) void* lds_ptr;
 
-  __shared__ __attribute__((aligned(16))) float As[2][BM][BK];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
+  __shared__ __attribute__((aligned(16))) float As[NS][BM][BK];
+  __shared__ __attribute__((aligned(16))) float Bs[NS][BK][BN];
   __shared__ int rowoff[BM];
   __shared__ int2 tap_yx[UDET_MAX_TAPS];
   __shared__ int tap_w[UDET_MAX_TAPS];
@@ -610,17 +695,31 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_dma_kernel(const ConvParams
       if (p.kfast) issue_fast(buf);
       else issue_generic(buf);
     };
-    auto landed = [&]() {  // all DMA of this wave has been written to LDS, then meet the MFMA waves
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // NS-deep ring: NS - 1 stages are in flight while the MFMA waves work on one, so a stage has (NS - 1) chunk times to land
+    // (one 128x128 chunk is 1.7 us of MFMA work, about one loaded-memory latency: with a single stage in flight a workgroup
+    // alone on its CU waits at every barrier).  Loads retire in order: waiting for vmcnt <= (stages issued later) * L is
+    // waiting for the stage the MFMA waves need next.
+    constexpr int L = A_LD + B_LD;  // DMA instructions per lane and stage
+    auto landed = [&](int newer) {  // `newer` (uniform): stages issued after the one that has to be in LDS now
+      if (NS > 3 && newer >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * L) : "memory");
+      else if (NS > 2 && newer == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     };
-    if (c_begin < c_end) issue(0);
-    landed();
-    int buf = 0;
+    int issued = c_begin, ibuf = 0;
+    for (int s = 0; s < NS - 1 && issued < c_end; ++s) {
+      issue(ibuf);
+      ibuf = ibuf + 1 == NS ? 0 : ibuf + 1;
+      ++issued;
+    }
+    landed(issued - c_begin - 1);
     for (int c = c_begin; c < c_end; ++c) {
-      if (c + 1 < c_end) issue(buf ^ 1);  // stage c+1 lands while the MFMA waves work on stage c
-      landed();
-      buf ^= 1;
+      if (issued < c_end) {  // its buffer held stage c - 1, which the MFMA waves left at the previous barrier
+        issue(ibuf);
+        ibuf = ibuf + 1 == NS ? 0 : ibuf + 1;
+        ++issued;
+      }
+      landed(issued - c - 2);  // stage c + 1 in LDS (nothing left to wait for after the last one: vmcnt(0) is free)
     }
     return;
   }
@@ -674,10 +773,11 @@ __global__ __launch_bounds__(512, 4) void conv_igemm_dma_kernel(const ConvParams
     for (int c = c_begin; c < c_end; ++c) {
       compute_chunk(buf);
       handover();
-      buf ^= 1;
+      buf = buf + 1 == NS ? 0 : buf + 1;
     }
   }
-  igemm_store<TM, TN, WTM, WTN>(p, acc, rowoff, wm, wn, li, lh, n0, cls * Mtot + m0, Mtot);
+  igemm_store<TM, TN, WTM, WTN>(p, acc, rowoff, wm, wn, li, lh, n0, cls * Mtot + m0, Mtot,
+                                xpose_scratch<sizeof(As), sizeof(Bs)>(&As[0][0][0], &Bs[0][0][0], wave));
   if (p.ksplit > 1 && p.fold) splitk_fold<BM, BN, 256>(p, rowoff, &s_last, t, n0, cls * Mtot + m0, Mtot, blockIdx.y * gridDim.x + bid);
 }
 
@@ -916,7 +1016,8 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_dma4_kernel(const ConvParam
       buf ^= 1;
     }
   }
-  igemm_store<TM, TN, WTM, WTN>(p, acc, rowoff, wm, wn, li, lh, n0, cls * Mtot + m0, Mtot);
+  igemm_store<TM, TN, WTM, WTN>(p, acc, rowoff, wm, wn, li, lh, n0, cls * Mtot + m0, Mtot,
+                                xpose_scratch<sizeof(As), sizeof(Bs)>(&As[0][0][0], &Bs[0][0][0], wave));
   if (p.ksplit > 1 && p.fold) splitk_fold<BM, BN, 256>(p, rowoff, &s_last, t, n0, cls * Mtot + m0, Mtot, blockIdx.y * gridDim.x + bid);
 }
 
@@ -1004,9 +1105,10 @@ int conv_last_config() { return g_last_cfg; }
 void conv_force_config(int bm, int bn, int ks) {
   g_force_bm = bm & 0xffff; g_force_bn = bn; g_force_ks = ks;
   // bit 16: non-specialised, 17: LDS-DMA (wave-specialised), 18: tile kernel, 19: self-staging LDS-DMA (4 waves, BK 16);
-  // bit 20: split-K through the second launch, bit 21: split-K folded into the last-arriving workgroup
+  // bit 20: split-K through the second launch, bit 21: split-K folded into the last-arriving workgroup;
+  // bit 22 / 23: LDS-DMA with a 3 / 4 stage ring
   g_force_fold = (bm >> 20) & 1 ? 0 : ((bm >> 21) & 1 ? 1 : -1);
-  g_force_ws = (bm >> 16) & 1 ? 0 : ((bm >> 17) & 1 ? 2 : ((bm >> 18) & 1 ? 3 : ((bm >> 19) & 1 ? 6 : -1)));
+  g_force_ws = (bm >> 16) & 1 ? 0 : ((bm >> 17) & 1 ? 2 : ((bm >> 18) & 1 ? 3 : ((bm >> 19) & 1 ? 6 : ((bm >> 22) & 1 ? 4 : ((bm >> 23) & 1 ? 5 : -1)))));
 }
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
@@ -1023,7 +1125,12 @@ static int launch_cfg(const ConvParams& p, int ws, hipStream_t stream) {
       return UDET_ERR_UNSUPPORTED;
     }
   }
-  else if (ws == 2) UDET_LAUNCH((conv_igemm_dma_kernel<BM, BN, WAVES_M, WAVES_N>), grid, dim3(512), 0, stream, p);
+  else if (ws == 2) UDET_LAUNCH((conv_igemm_dma_kernel<BM, BN, WAVES_M, WAVES_N, 2>), grid, dim3(512), 0, stream, p);
+  else if (ws == 4) UDET_LAUNCH((conv_igemm_dma_kernel<BM, BN, WAVES_M, WAVES_N, 3>), grid, dim3(512), 0, stream, p);
+  else if (ws == 5) {
+    if constexpr (BM <= 128) UDET_LAUNCH((conv_igemm_dma_kernel<BM, BN, WAVES_M, WAVES_N, 4>), grid, dim3(512), 0, stream, p);
+    else UDET_LAUNCH((conv_igemm_dma_kernel<BM, BN, WAVES_M, WAVES_N, 3>), grid, dim3(512), 0, stream, p);
+  }
   else if (ws) UDET_LAUNCH((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, true>), grid, dim3(512), 0, stream, p);
   else UDET_LAUNCH((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, false>), grid, dim3(256), 0, stream, p);
   UDET_HIP(hipGetLastError());
@@ -1253,7 +1360,7 @@ static ConvCfg tune_cfg(ConvParams& p, hipStream_t stream) {
   if (dma_ok(p)) {  // LDS-DMA staging: re-scan the tiles, the balance between staging and MFMA waves differs
     for (auto& c : cand) {
       ConvCfg d = c;
-      for (int ws : {2, 6}) {  // wave-specialised / self-staging (4 waves, 16-wide stages, 3-4 workgroups per CU)
+      for (int ws : {2, 4, 5, 6}) {  // wave-specialised / self-staging (4 waves, 16-wide stages, 3-4 workgroups per CU)
         if (ws == 6 && !self_staging_tile(d.bm, d.bn)) continue;
         d.ws = ws;
         const float ms = time_cfg(p, d, 3, stream);
@@ -1360,7 +1467,7 @@ int launch_conv(ConvParams& p, hipStream_t stream) {
   if (g_force_ks >= 0) c.ks = g_force_ks > max_ksplit(p) ? max_ksplit(p) : g_force_ks;
   if (g_force_ws >= 0) c.ws = g_force_ws;
   if (g_force_fold >= 0) c.fold = g_force_fold;
-  if ((c.ws == 2 || c.ws == 6) && !dma_ok(p)) c.ws = 1;
+  if ((c.ws == 2 || c.ws == 4 || c.ws == 5 || c.ws == 6) && !dma_ok(p)) c.ws = 1;
   if (c.ws == 6 && !self_staging_tile(c.bm, c.bn)) c.ws = 2;
   if (g_force_ws == 3) { c.ws = 3; c.bm = (g_force_bm == 4) ? 4 : 8; }
   if (c.ws == 3 && !tile_ok(p, c.bm)) { c = heuristic_cfg(p); }

@@ -252,13 +252,16 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams p, cons
           acc[i].v = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b.z, acc[i].v, 0, 0, 0);
           acc[i].v = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b.w, acc[i].v, 0, 0, 0);
         } else {
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            acc[i].v[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2 * i + h].x, b.x, acc[i].v[h], 0, 0, 0);
-            acc[i].v[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2 * i + h].y, b.y, acc[i].v[h], 0, 0, 0);
-            acc[i].v[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2 * i + h].z, b.z, acc[i].v[h], 0, 0, 0);
-            acc[i].v[h] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2 * i + h].w, b.w, acc[i].v[h], 0, 0, 0);
-          }
+          // v_mfma_f32_16x16x4_f32 issues every 32 cycles but a dependent one (same accumulator) only after 40: the two halves'
+          // accumulators alternate, so consecutive MFMAs never depend on each other
+          acc[i].v[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2 * i].x, b.x, acc[i].v[0], 0, 0, 0);
+          acc[i].v[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2 * i + 1].x, b.x, acc[i].v[1], 0, 0, 0);
+          acc[i].v[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2 * i].y, b.y, acc[i].v[0], 0, 0, 0);
+          acc[i].v[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2 * i + 1].y, b.y, acc[i].v[1], 0, 0, 0);
+          acc[i].v[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2 * i].z, b.z, acc[i].v[0], 0, 0, 0);
+          acc[i].v[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2 * i + 1].z, b.z, acc[i].v[1], 0, 0, 0);
+          acc[i].v[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2 * i].w, b.w, acc[i].v[0], 0, 0, 0);
+          acc[i].v[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2 * i + 1].w, b.w, acc[i].v[1], 0, 0, 0);
         }
       }
       // issue order pinned: this step's LDS reads first (they complete under the MFMAs), then the MFMAs
