@@ -7,7 +7,8 @@ extern "C" {
 #endif
 /* force (bm, bn, split-K) for every convolution launch (bm bit 16: non-specialised kernel, bit 17: LDS-DMA staging,
  * bit 18: tile-resident kernel with bm & 0xffff = tile height, bit 19: self-staging LDS-DMA kernel, bit 20: split-K summed by a
- * second launch, bit 21: split-K summed by the last-arriving workgroup); (0,0,-1) restores.  A forced family a launch is not
+ * second launch, bit 21: split-K summed by the last-arriving workgroup, bit 22 / 23: LDS-DMA kernel with a 3 / 4 stage
+ * ring); (0,0,-1) restores.  A forced family a launch is not
  * eligible for falls back to the built-in choice.  Process-global state: never call it from product code. */
 void udet_debug_force_conv(int bm, int bn, int ks);
 /* while on, the first single-op launch of every distinct problem shape times its candidate configurations and caches the winner

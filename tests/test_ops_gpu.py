@@ -167,7 +167,9 @@ FAMILIES = {"plain": (128 + (1 << 16), 32, 1), "wave_spec": (128, 32, 1), "lds_d
             # split-K both ways: bit 21 = slabs summed by the last-arriving workgroup (ticket counter), bit 20 = second launch
             "wave_spec_split4_fold": (128 + (1 << 21), 32, 4), "wave_spec_split4_2pass": (128 + (1 << 20), 32, 4),
             "plain_split2_fold": (128 + (1 << 16) + (1 << 21), 32, 2), "lds_dma_split3_2pass": (128 + (1 << 17) + (1 << 20), 32, 3),
-            "lds_dma_split5_fold_64": (64 + (1 << 17) + (1 << 21), 64, 5), "self_staging_split2_2pass": (64 + (1 << 19) + (1 << 20), 64, 2)}
+            "lds_dma_split5_fold_64": (64 + (1 << 17) + (1 << 21), 64, 5), "self_staging_split2_2pass": (64 + (1 << 19) + (1 << 20), 64, 2),
+            # bit 22 / 23 = LDS-DMA staging with a 3 / 4 stage ring (two / three stages in flight)
+            "lds_dma_ring3": (128 + (1 << 22), 32, 1), "lds_dma_ring4_64_split2": (64 + (1 << 23), 64, 2)}
 THIN_CASES = [
     # n,h,w,cin,cout,k,s
     (1, 32, 64, 16, 16, 3, 1),    # 16-wide MFMA tile kernel
@@ -207,7 +209,7 @@ def force_conv():
 WS_OF = {"plain": 0, "wave_spec": 1, "lds_dma": 2, "lds_dma_split3": 2, "tile8": 3, "tile4": 3, "self_staging": 6,
          "self_staging_128": 6, "self_staging_split2": 6, "self_staging_n32": 6, "self_staging_256x32": 6,
          "wave_spec_split4_fold": 1, "wave_spec_split4_2pass": 1, "plain_split2_fold": 0, "lds_dma_split3_2pass": 2,
-         "lds_dma_split5_fold_64": 2, "self_staging_split2_2pass": 6}
+         "lds_dma_split5_fold_64": 2, "self_staging_split2_2pass": 6, "lds_dma_ring3": 4, "lds_dma_ring4_64_split2": 5}
 
 
 @pytest.mark.parametrize("family", list(FAMILIES))
@@ -247,6 +249,33 @@ def test_conv2d_transpose_kernel_families(ops, force_conv, family):
     y = ops.conv2d_transpose4x4s2(x.cuda(), wt.cuda(), b.cuda()).cpu()
     assert (force_conv.udet_debug_last_conv() & 0xff) == WS_OF[family]
     assert (y - ref).abs().max() < 1e-4 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("family", ["lds_dma", "lds_dma_ring3"])
+@pytest.mark.parametrize("stride", [1, 2])
+def test_conv_tail_split(ops, force_conv, family, stride):
+    """Tail split (ks + 256 r in the forced split count): 288 tiles of 64x64 = one whole round of 256 + 32 tiles cut into 8 K slices
+    each; with stride 2 the backward-data launch has four parity classes and its tail lies inside the last one."""
+    n, h, w, cin, cout, k = 2, 96 * stride, 96, 64, 64, 3
+    if stride == 2:
+        w *= 2
+    x = rnd(n, h, w, cin, seed=41).double().requires_grad_(True)
+    wt = rnd(k, k, cin, cout, seed=42, scale=(2.0 / (k * k * cin)) ** 0.5).double()
+    b = rnd(cout, seed=43, scale=0.1).double()
+    y = _oracle_conv(x, wt, b, stride, 1, "leaky", 0.1, False)
+    lin = O.conv2d_same(x, wt, None, stride, 1)
+    dy = rnd(*y.shape, seed=44).double()
+    gx, = torch.autograd.grad((lin * dy).sum(), [x])
+    bm = 64 + ((1 << 17) if family == "lds_dma" else (1 << 22))
+    force_conv.udet_debug_force_conv(bm, 64, 256)  # r = 1 slot per CU, slices: as many as fill the round
+    got = ops.conv2d(x.detach().float().cuda(), wt.float().cuda(), b.float().cuda(), stride, 1, "leaky", 0.1, False).cpu()
+    last = force_conv.udet_debug_last_conv()
+    assert (last & 0xff) == WS_OF[family] and (last >> 29) & 1 == 1 and (last >> 20) & 0xff >= 2, hex(last)  # up to 256 // 32 slices
+    assert (got - y.detach().float()).abs().max() < 1e-4 * max(1.0, float(y.abs().max()))
+    dx = ops.conv2d_backward_data(dy.float().cuda(), lin.detach().float().cuda(), wt.float().cuda(), (h, w), stride, 1, "none", 0.0).cpu()
+    last = force_conv.udet_debug_last_conv()
+    assert (last & 0xff) == WS_OF[family] and (stride == 2 or (last >> 29) & 1 == 1), hex(last)  # (a 1-tap parity class cannot be split)
+    assert (dx - gx.float()).abs().max() < 2e-4 * max(1.0, float(gx.abs().max()))
 
 
 def test_bad_arguments_raise(ops):

@@ -46,8 +46,8 @@ SHAPES = [
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--cfg", action="append", default=[], help="bm,bn,ks forced configuration (repeatable; bm+65536 selects the non-specialised 256-thread kernel, bm+131072 the LDS-DMA kernel, 262144+{8,4} the tile-resident kernel with that tile height, bm+524288 the self-staging LDS-DMA kernel); "
-                    "the default heuristics always run")
+    ap.add_argument("--cfg", action="append", default=[], help="bm,bn,ks forced configuration (repeatable; bm+65536 selects the non-specialised 256-thread kernel, bm+131072 the LDS-DMA kernel, 262144+{8,4} the tile-resident kernel with that tile height, bm+524288 the self-staging LDS-DMA kernel, bm+4194304 / bm+8388608 the LDS-DMA kernel with a 3 / 4 stage ring); "
+                    "ks + 256 r: tail split for r workgroup slots per CU; the default heuristics always run")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default="")
     args = ap.parse_args()
@@ -83,7 +83,7 @@ def main():
                 if y_ref is None:
                     y_ref = y
                 err = float((y - y_ref).abs().max())
-                tag = "auto" if cfg is None else "x".join(map(str, (cfg[0] & 0xffff,) + cfg[1:])) + ("n" if (cfg[0] >> 16) & 1 else "") + ("d" if (cfg[0] >> 17) & 1 else "") + ("t" if (cfg[0] >> 18) & 1 else "") + ("s" if (cfg[0] >> 19) & 1 else "")
+                tag = "auto" if cfg is None else "x".join(map(str, (cfg[0] & 0xffff, cfg[1], cfg[2] & 255))) + ("T%d" % (cfg[2] >> 8) if cfg[2] > 255 else "") + ("n" if (cfg[0] >> 16) & 1 else "") + ("d" if (cfg[0] >> 17) & 1 else "") + ("t" if (cfg[0] >> 18) & 1 else "") + ("s" if (cfg[0] >> 19) & 1 else "") + ("d3" if (cfg[0] >> 22) & 1 else "") + ("d4" if (cfg[0] >> 23) & 1 else "")
                 line += f" {tag:>11s}: {us_:7.1f}us {gflop / us_ * 1e3:6.1f}TF" + (f" ERR={err:.1e}" if err > 1e-4 else "") + " |"
             except Exception as ex:  # unsupported forced tile
                 line += f" {'x'.join(map(str, cfg))}: n/a |"

@@ -162,7 +162,8 @@ int udet_tune_load(const char* path) {
   while (fgets(line, sizeof(line), f)) {
     unsigned long long key;
     int a, b, c, d, e;
-    if (sscanf(line, "c %llu %d %d %d %d %d", &key, &a, &b, &c, &d, &e) == 6) { conv_tune_put(key, a, b, c, d, e); ++n; }
+    int g = 0, nf = sscanf(line, "c %llu %d %d %d %d %d %d", &key, &a, &b, &c, &d, &e, &g);
+    if (nf == 6 || nf == 7) { conv_tune_put(key, a, b, c, d, e, nf == 7 ? g : 0); ++n; }
     else if (sscanf(line, "w %llu %d", &key, &a) == 2) { wgrad_tune_put(key, a); ++n; }
   }
   fclose(f);

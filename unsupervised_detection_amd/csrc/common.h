@@ -146,6 +146,10 @@ struct ConvParams {
   // tickets: >= UDET_MAX_TICKETS zero-initialised ints private to the launch stream (self-resetting); null disables folding.
   int fold;
   int* tickets;
+  // tail split (LDS-DMA kernel; set by the launcher): x-blocks [0, tail_full) run unsplit, every later x-block is cut into
+  // tail_ks K slices -- the launch's last, partly filled round of workgroups becomes tail_ks times as many short ones.  Slabs hold
+  // the tail rows only: [tail_ks][Mall - tail_prow0][ldp].  tail_ks <= 1: off.
+  int tail_full, tail_ks, tail_prow0;
 };
 #define UDET_MAX_TICKETS 4096
 

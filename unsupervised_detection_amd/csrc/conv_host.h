@@ -17,7 +17,7 @@ bool tune_compare(const float* a, const float* b, size_t n, hipStream_t stream, 
 void wgrad_set_tuning(int on);
 int wgrad_tuned_shapes();
 void conv_tune_dump(FILE* f);
-void conv_tune_put(unsigned long long key, int bm, int bn, int ks, int ws, int fold);
+void conv_tune_put(unsigned long long key, int bm, int bn, int ks, int ws, int fold, int tail);
 void wgrad_tune_dump(FILE* f);
 void wgrad_tune_put(unsigned long long key, int cfg);  // debugging / tuning hook: bm == 0 and ks < 0 restore the heuristics
 bool conv_setup_dgrad(ConvParams& p, int cls, int N, int H, int W, int kh, int kw, int s, int d);

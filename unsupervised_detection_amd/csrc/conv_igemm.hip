@@ -125,9 +125,8 @@ __device__ __forceinline__ void conv_epilogue4(const ConvParams& p, int off, int
                     v.w * act_dfo(ua.w, p.uact, p.ualpha));
   }
 }
-__device__ __forceinline__ bool epilogue4_ok(const ConvParams& p) {
+__device__ __forceinline__ bool epilogue4_out_ok(const ConvParams& p) {  // conv_epilogue4 may be used on this launch's outputs
   auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-  if (p.ksplit > 1) return al(p.partial);  // slab rows are ldp = 4k floats wide
   bool ok = (p.Cout & 3) == 0 && ((p.ldy | p.y_coff) & 3) == 0 && al(p.y);
   if (p.y2) ok = ok && ((p.ldy2 | p.y2_coff) & 3) == 0 && al(p.y2);
   if (p.res) ok = ok && ((p.ldres | p.res_coff) & 3) == 0 && al(p.res);
@@ -154,9 +153,9 @@ __device__ __forceinline__ float* xpose_scratch(float* a, float* b, int wave) {
 // store loop is not unrolled (4 x 2 copies of its body instead of 256).
 template <int TM, int TN, int WTM, int WTN>
 __device__ __forceinline__ void igemm_store(const ConvParams& p, floatx16 (&acc)[TM][TN], const int* rowoff, int wm, int wn, int li,
-                                            int lh, int n0, int prow0, int Mtot, float* xp = nullptr) {
-  const bool slab = p.ksplit > 1;
-  if (xp != nullptr && !(slab && p.fold) && epilogue4_ok(p)) {
+                                            int lh, int n0, int prow0, int Mtot, bool slab, long slab_off, float* xp = nullptr) {
+  // slab: this workgroup holds a K slice; its partial tile goes to p.partial + slab_off + (class row) * ldp
+  if (xp != nullptr && !(slab && p.fold) && (slab ? (reinterpret_cast<uintptr_t>(p.partial) & 15) == 0 : epilogue4_out_ok(p))) {
     const int lane = lh * 32 + li, rr = lane >> 3, c4 = (lane & 7) * 4;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -176,7 +175,7 @@ __device__ __forceinline__ void igemm_store(const ConvParams& p, floatx16 (&acc)
             const float4 v = *reinterpret_cast<const float4*>(&xp[(pass * 8 + rr) * UDET_XP + c4]);
             if (off < 0) continue;
             if (slab) {
-              if (nb < p.ldp) *reinterpret_cast<float4*>(p.partial + ((size_t)blockIdx.z * p.ncls * Mtot + prow0 + row) * p.ldp + nb) = v;
+              if (nb < p.ldp) *reinterpret_cast<float4*>(p.partial + (slab_off + (long)(prow0 + row) * p.ldp + nb)) = v;
             } else if (nb < p.Cout) {
               conv_epilogue4(p, off, nb, v);
             }
@@ -197,9 +196,9 @@ __device__ __forceinline__ void igemm_store(const ConvParams& p, floatx16 (&acc)
       for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * WTN + j * 32 + li;
         const float v = acc[i][j][r];
-        if (p.ksplit > 1) {
+        if (slab) {
           if (n < p.ldp) {
-            float* dst = p.partial + ((size_t)blockIdx.z * p.ncls * Mtot + prow0 + row) * p.ldp + n;
+            float* dst = p.partial + (slab_off + (long)(prow0 + row) * p.ldp + n);
             // folded form: the slab is published write-through (device-scope store, `sc1`): it is in memory when the store is
             // acknowledged, so no L2 write-back fence is needed before the ticket (MI355X_MICROARCH.md "publish-large")
             if (p.fold) __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -511,8 +510,8 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 2) void conv_igemm_kernel(
   }
 
   // ---- epilogue -------------------------------------------------------------
-  igemm_store<TM, TN, WTM, WTN>(p, acc, rowoff, wm, wn, li, lh, n0, cls * Mtot + m0, Mtot,
-                                xpose_scratch<sizeof(As), sizeof(Bs)>(&As[0][0][0], &Bs[0][0][0], wave));
+  igemm_store<TM, TN, WTM, WTN>(p, acc, rowoff, wm, wn, li, lh, n0, cls * Mtot + m0, Mtot, p.ksplit > 1,
+                                (long)blockIdx.z * p.ncls * Mtot * p.ldp, xpose_scratch<sizeof(As), sizeof(Bs)>(&As[0][0][0], &Bs[0][0][0], wave));
   if (p.ksplit > 1 && p.fold) splitk_fold<BM, BN, 256>(p, rowoff, &s_last, t, n0, cls * Mtot + m0, Mtot, blockIdx.y * gridDim.x + bid);
 }
 
@@ -554,9 +553,23 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void conv_igemm_dma_kernel(co
   const int li = lane & 31, lh = lane >> 5;
 
   int bid = blockIdx.x;
+  int kz = blockIdx.z, knz = p.ksplit;  // K slice of this workgroup / slices of its tile
   {
-    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    int nwg = gridDim.x;
+    if (p.tail_ks > 1) {  // tail split: the x-blocks past tail_full are cut into tail_ks slices, the others run whole
+      nwg = p.tail_full;
+      knz = 1;
+      if (bid >= p.tail_full) {
+        const int r = bid - p.tail_full;
+        kz = r % p.tail_ks;
+        bid = p.tail_full + r / p.tail_ks;
+        knz = p.tail_ks;
+      }
+    }
+    if (bid < nwg) {
+      const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+      bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
   }
   const int OHWq = p.OHq * p.OWq;
   const int Mtot = p.N * OHWq;
@@ -588,10 +601,12 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void conv_igemm_dma_kernel(co
   // lanes instead of straddling into the next tap -- so the K cursor is wave-uniform (see the staging waves)
   const int nchunks = p.kfast ? ntc * ((Kc + 31) >> 5) : (ntc * Kc + BK - 1) / BK;
   int c_begin = 0, c_end = nchunks;
-  if (p.ksplit > 1) {
-    c_begin = (int)((long)nchunks * blockIdx.z / p.ksplit);
-    c_end = (int)((long)nchunks * (blockIdx.z + 1) / p.ksplit);
+  if (knz > 1) {
+    c_begin = (int)((long)nchunks * kz / knz);
+    c_end = (int)((long)nchunks * (kz + 1) / knz);
   }
+  // slab of this slice: regular split-K keeps whole-output slabs, the tail split only the rows from tail_prow0 on
+  const long slab_off = p.tail_ks > 1 ? ((long)kz * (p.ncls * Mtot - p.tail_prow0) - p.tail_prow0) * p.ldp : (long)kz * p.ncls * Mtot * p.ldp;
   __syncthreads();
 
   if (role == 1) {
@@ -776,7 +791,7 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void conv_igemm_dma_kernel(co
       buf = buf + 1 == NS ? 0 : buf + 1;
     }
   }
-  igemm_store<TM, TN, WTM, WTN>(p, acc, rowoff, wm, wn, li, lh, n0, cls * Mtot + m0, Mtot,
+  igemm_store<TM, TN, WTM, WTN>(p, acc, rowoff, wm, wn, li, lh, n0, cls * Mtot + m0, Mtot, knz > 1, slab_off,
                                 xpose_scratch<sizeof(As), sizeof(Bs)>(&As[0][0][0], &Bs[0][0][0], wave));
   if (p.ksplit > 1 && p.fold) splitk_fold<BM, BN, 256>(p, rowoff, &s_last, t, n0, cls * Mtot + m0, Mtot, blockIdx.y * gridDim.x + bid);
 }
@@ -1016,8 +1031,8 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_dma4_kernel(const ConvParam
       buf ^= 1;
     }
   }
-  igemm_store<TM, TN, WTM, WTN>(p, acc, rowoff, wm, wn, li, lh, n0, cls * Mtot + m0, Mtot,
-                                xpose_scratch<sizeof(As), sizeof(Bs)>(&As[0][0][0], &Bs[0][0][0], wave));
+  igemm_store<TM, TN, WTM, WTN>(p, acc, rowoff, wm, wn, li, lh, n0, cls * Mtot + m0, Mtot, p.ksplit > 1,
+                                (long)blockIdx.z * p.ncls * Mtot * p.ldp, xpose_scratch<sizeof(As), sizeof(Bs)>(&As[0][0][0], &Bs[0][0][0], wave));
   if (p.ksplit > 1 && p.fold) splitk_fold<BM, BN, 256>(p, rowoff, &s_last, t, n0, cls * Mtot + m0, Mtot, blockIdx.y * gridDim.x + bid);
 }
 
@@ -1066,14 +1081,16 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue4_kernel(const ConvPa
   const int Mtot = p.N * OHWq;
   const int Mall = p.ncls * Mtot;
   const int nq = p.ldp >> 2;  // quads per partial row (ldp = Cout rounded up to 4)
-  const long total = (long)Mall * nq;
-  const size_t slab = (size_t)Mall * p.ldp;
+  const int row0 = p.tail_ks > 1 ? p.tail_prow0 : 0, ksplit = p.tail_ks > 1 ? p.tail_ks : p.ksplit;  // tail split: rows >= tail_prow0 only
+  const long total = (long)(Mall - row0) * nq;
+  const size_t slab = (size_t)(Mall - row0) * p.ldp;
+  const bool vec = epilogue4_out_ok(p);
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-    const int ma = (int)(e / nq), n = (int)(e - (long)ma * nq) * 4;
-    const float* src = p.partial + (size_t)ma * p.ldp + n;
+    const int mr = (int)(e / nq), n = (int)(e - (long)mr * nq) * 4, ma = row0 + mr;
+    const float* src = p.partial + (size_t)mr * p.ldp + n;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     int s = 0;
-    for (; s + 3 < p.ksplit; s += 4) {
+    for (; s + 3 < ksplit; s += 4) {
       const float4 a0 = *reinterpret_cast<const float4*>(src + (size_t)s * slab);
       const float4 a1 = *reinterpret_cast<const float4*>(src + (size_t)(s + 1) * slab);
       const float4 a2 = *reinterpret_cast<const float4*>(src + (size_t)(s + 2) * slab);
@@ -1083,7 +1100,7 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue4_kernel(const ConvPa
       v.x += a2.x; v.y += a2.y; v.z += a2.z; v.w += a2.w;
       v.x += a3.x; v.y += a3.y; v.z += a3.z; v.w += a3.w;
     }
-    for (; s < p.ksplit; ++s) {
+    for (; s < ksplit; ++s) {
       const float4 a0 = *reinterpret_cast<const float4*>(src + (size_t)s * slab);
       v.x += a0.x; v.y += a0.y; v.z += a0.z; v.w += a0.w;
     }
@@ -1092,6 +1109,10 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue4_kernel(const ConvPa
     const int nb = (int)fdiv(m, p.fd_ohw), rem = m - nb * OHWq;
     const int qy = (int)fdiv(rem, p.fd_ow), qx = rem - qy * p.OWq;
     const int off = (nb * p.OH + qy * p.osy + ooy) * p.OW + qx * p.osx + oox;
+    if (vec) {  // (Cout a multiple of 4: whole quads)
+      if (n < p.Cout) conv_epilogue4(p, off, n, v);
+      continue;
+    }
     if (n < p.Cout) conv_epilogue(p, off, n, v.x);
     if (n + 1 < p.Cout) conv_epilogue(p, off, n + 1, v.y);
     if (n + 2 < p.Cout) conv_epilogue(p, off, n + 2, v.z);
@@ -1099,11 +1120,13 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue4_kernel(const ConvPa
   }
 }
 
-static int g_force_bm = 0, g_force_bn = 0, g_force_ks = -1, g_force_ws = -1, g_force_fold = -1;
+static int g_force_bm = 0, g_force_bn = 0, g_force_ks = -1, g_force_ws = -1, g_force_fold = -1, g_force_tail = 0;
 static int g_last_cfg = 0;  // kernel family / tile / split count of the most recent launch_conv (debug query)
 int conv_last_config() { return g_last_cfg; }
 void conv_force_config(int bm, int bn, int ks) {
-  g_force_bm = bm & 0xffff; g_force_bn = bn; g_force_ks = ks;
+  g_force_bm = bm & 0xffff; g_force_bn = bn;
+  g_force_ks = ks < 0 ? ks : (ks & 0xff);
+  g_force_tail = ks < 0 ? 0 : ((ks >> 8) & 0xff);  // ks + 256 r: tail split for r workgroup slots per CU (ks & 255 slices; 0: as many as fill a round)
   // bit 16: non-specialised, 17: LDS-DMA (wave-specialised), 18: tile kernel, 19: self-staging LDS-DMA (4 waves, BK 16);
   // bit 20: split-K through the second launch, bit 21: split-K folded into the last-arriving workgroup;
   // bit 22 / 23: LDS-DMA with a 3 / 4 stage ring
@@ -1112,9 +1135,15 @@ void conv_force_config(int bm, int bn, int ks) {
 }
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
-static int launch_cfg(const ConvParams& p, int ws, hipStream_t stream) {
+static int launch_cfg(ConvParams& p, int ws, hipStream_t stream) {
   const int Mtot = p.N * p.OHq * p.OWq;
   dim3 grid(p.ncls * ((Mtot + BM - 1) / BM), (p.Cout + BN - 1) / BN, p.ksplit > 1 ? p.ksplit : 1);
+  if (p.tail_ks > 1) {  // tail split (run_cfg checked the kernel family, the slab capacity and the alignment)
+    const int mtiles = (Mtot + BM - 1) / BM;
+    p.tail_prow0 = (p.tail_full / mtiles) * Mtot + (p.tail_full % mtiles) * BM;
+    grid.x = p.tail_full + (grid.x - p.tail_full) * p.tail_ks;
+    grid.z = 1;
+  }
   if (ws == 6) {
     if constexpr (BM % 64 == 0 && BN % 64 == 0 && BM <= 128) {
       UDET_LAUNCH((conv_igemm_dma4_kernel<BM, BN, 2, 2>), grid, dim3(256), 0, stream, p);
@@ -1134,7 +1163,11 @@ static int launch_cfg(const ConvParams& p, int ws, hipStream_t stream) {
   else if (ws) UDET_LAUNCH((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, true>), grid, dim3(512), 0, stream, p);
   else UDET_LAUNCH((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, false>), grid, dim3(256), 0, stream, p);
   UDET_HIP(hipGetLastError());
-  if (p.ksplit > 1 && !p.fold) {
+  if (p.tail_ks > 1) {
+    const long nb4l = ((long)(p.ncls * Mtot - p.tail_prow0) * (p.ldp >> 2) + 255) / 256;
+    UDET_LAUNCH(conv_splitk_epilogue4_kernel, dim3((int)(nb4l > 4096 ? 4096 : nb4l)), dim3(256), 0, stream, p);
+    UDET_HIP(hipGetLastError());
+  } else if (p.ksplit > 1 && !p.fold) {
     const long total = (long)p.ncls * Mtot * p.Cout;
     // lanes per element: keep >= ~64k threads busy while the split count allows it
     const int sl = (p.ksplit >= 16 && total * 16 <= 262144) ? 16 : ((p.ksplit >= 4 && total * 4 <= 262144) ? 4 : 1);
@@ -1152,7 +1185,8 @@ static int launch_cfg(const ConvParams& p, int ws, hipStream_t stream) {
 }
 
 // ---- tile / split-K selection ---------------------------------------------------------------
-struct ConvCfg { int bm, bn, ks, ws, fold; };  // fold: split-K summed by the last-arriving workgroup (no second launch)
+struct ConvCfg { int bm, bn, ks, ws, fold, tail; };  // fold: split-K summed by the last-arriving workgroup (no second launch);
+                                                    // tail > 0: x-blocks [0, tail) unsplit, the rest cut into ks slices (ConvParams::tail_full)
 static long cfg_tiles(const ConvParams& p, int bm, int bn) {
   const int Mtot = p.N * p.OHq * p.OWq;
   return (long)p.ncls * ((Mtot + bm - 1) / bm) * ((p.Cout + bn - 1) / bn);
@@ -1181,10 +1215,25 @@ static bool self_staging_tile(int bm, int bn) {  // tiles conv_igemm_dma4_kernel
   return ((bm == 128 || bm == 64) && (bn == 64 || bn == 128)) || (bn == 32 && (bm == 128 || bm == 256));
 }
 static bool dma_ok(const ConvParams& p) { return p.xa == nullptr && p.zero16 != nullptr && !(reinterpret_cast<uintptr_t>(p.zero16) & 15); }
+// tail split for workgroups filling r slots per CU: x-blocks of the whole rounds stay unsplit (*full_x of them), the rest is cut
+// into *ks slices so that it fills one more round.  false: the tile count is a whole number of rounds, or less than one.
+static bool tail_for_rounds(const ConvParams& p, int bm, int bn, int r, int kcap, int* full_x, int* ks) {
+  const int Mtot = p.N * p.OHq * p.OWq, X = p.ncls * ((Mtot + bm - 1) / bm), Y = (p.Cout + bn - 1) / bn;
+  const long S = 256L * r, T = (long)X * Y, fullT = T / S * S;
+  if (fullT == 0 || fullT == T) return false;
+  const int fx = (int)(fullT / Y), rem_x = X - fx;
+  if (fx <= 0 || rem_x <= 0) return false;
+  long k = S / ((long)rem_x * Y);
+  if (k > kcap) k = kcap;
+  if (k < 2) return false;
+  *full_x = fx;
+  *ks = (int)k;
+  return true;
+}
 static ConvCfg heuristic_cfg(const ConvParams& p) {
   // N tile from the channel count; M tile shrunk while the launch would leave CUs without a workgroup
   ConvCfg c;
-  c.ws = 1; c.fold = 0;
+  c.ws = 1; c.fold = 0; c.tail = 0;
   if (p.Cout <= 32) { c.bn = 32; c.bm = 256; if (cfg_tiles(p, 256, 32) < 384) c.bm = 128; }
   else if (p.Cout <= 64) { c.bn = 64; c.bm = 128; if (cfg_tiles(p, 128, 64) < 384) c.bm = 64; }
   else if (p.Cout <= 96) { c.bn = 96; c.bm = 128; }
@@ -1208,9 +1257,17 @@ static int run_cfg(ConvParams& p, const ConvCfg& c, hipStream_t stream) {
   }
   p.ksplit = c.ks > 1 ? c.ks : 1;
   p.fold = 0;
+  p.tail_full = 0; p.tail_ks = 0; p.tail_prow0 = 0;
   if (p.ksplit > 1) {
     p.ldp = (p.Cout + 3) & ~3;
     p.fold = c.fold && p.tickets && cfg_tiles(p, c.bm, c.bn) <= UDET_MAX_TICKETS;
+    const int Mtot = p.N * p.OHq * p.OWq, mtiles = (Mtot + c.bm - 1) / c.bm, xb = p.ncls * mtiles;
+    if (c.tail > 0 && c.tail < xb && (c.ws == 2 || c.ws == 4 || c.ws == 5) && !(reinterpret_cast<uintptr_t>(p.partial) & 15)) {
+      const long prow0 = (long)(c.tail / mtiles) * Mtot + (long)(c.tail % mtiles) * c.bm;
+      if ((size_t)((long)p.ncls * Mtot - prow0) * p.ldp * p.ksplit <= p.partial_cap) {
+        p.tail_full = c.tail; p.tail_ks = p.ksplit; p.ksplit = 1; p.fold = 0;
+      }
+    }
   }
   if (c.bm == 256 && c.bn == 32) return launch_cfg<256, 32, 32, 4, 1>(p, c.ws, stream);
   if (c.bm == 128 && c.bn == 32) return launch_cfg<128, 32, 32, 4, 1>(p, c.ws, stream);
@@ -1231,16 +1288,17 @@ static void tune_scratch_free();
 void conv_set_tuning(int on) { g_tuning = on; if (!on) tune_scratch_free(); }
 int conv_tuned_shapes() { std::lock_guard<std::mutex> l(g_cache_mu); return (int)g_cache.size(); }
 void conv_clear_tuning() { std::lock_guard<std::mutex> l(g_cache_mu); g_cache.clear(); }
-// text form of the cache ("c <problem key> bm bn ks ws fold" per line): lets a second process (a rocprofv3 trace of timed
+// text form of the cache ("c <problem key> bm bn ks ws fold tail" per line): lets a second process (a rocprofv3 trace of timed
 // steps only) run exactly the configurations a tuning run picked
 void conv_tune_dump(FILE* f) {
   std::lock_guard<std::mutex> l(g_cache_mu);
   for (auto& kv : g_cache)
-    fprintf(f, "c %llu %d %d %d %d %d\n", (unsigned long long)kv.first, kv.second.bm, kv.second.bn, kv.second.ks, kv.second.ws, kv.second.fold);
+    fprintf(f, "c %llu %d %d %d %d %d %d\n", (unsigned long long)kv.first, kv.second.bm, kv.second.bn, kv.second.ks, kv.second.ws, kv.second.fold,
+            kv.second.tail);
 }
-void conv_tune_put(unsigned long long key, int bm, int bn, int ks, int ws, int fold) {
+void conv_tune_put(unsigned long long key, int bm, int bn, int ks, int ws, int fold, int tail) {
   std::lock_guard<std::mutex> l(g_cache_mu);
-  g_cache[(uint64_t)key] = ConvCfg{bm, bn, ks, ws, fold};
+  g_cache[(uint64_t)key] = ConvCfg{bm, bn, ks, ws, fold, tail};
 }
 
 // ---- candidate verification -------------------------------------------------------------------------------------------
@@ -1368,6 +1426,27 @@ static ConvCfg tune_cfg(ConvParams& p, hipStream_t stream) {
           const float ms5 = time_cfg(p, d, 5, stream);
           if (ms5 < a * 0.98f) { a = ms5; best = d; }
         }
+        // Tail split of an unsplit candidate: a launch whose workgroups fill r slots per CU for k whole rounds and a fraction of
+        // another runs that last round on part of the chip (576 tiles of 64x64 on 256 CUs: three on 64 CUs, two on the rest).
+        // Cutting only the LAST round's tiles into K slices makes it a full round of short workgroups, at the slab traffic of
+        // those tiles alone.
+        if (d.ks <= 1 && ws != 6 && p.partial && kcap >= 2 && ms < a * 1.3f) {
+          long seen[4] = {0, 0, 0, 0};
+          for (int r = 1; r <= 4; ++r) {
+            int full_x = 0, ks = 0;
+            if (!tail_for_rounds(p, d.bm, d.bn, r, kcap, &full_x, &ks)) continue;
+            const long id = (long)full_x * 1024 + ks;
+            if (id == seen[0] || id == seen[1] || id == seen[2]) continue;
+            seen[r - 1] = id;
+            ConvCfg e = d;
+            e.ks = ks; e.tail = full_x; e.fold = 0;
+            const float mt = time_cfg(p, e, 3, stream);
+            if (mt < a * 0.98f) {
+              const float mt5 = time_cfg(p, e, 5, stream);
+              if (mt5 < a * 0.98f) { a = mt5; best = e; }
+            }
+          }
+        }
       }
     }
     b = a;
@@ -1381,7 +1460,7 @@ static ConvCfg tune_cfg(ConvParams& p, hipStream_t stream) {
       if (ms5 < a * 0.97f) { a = b = ms5; best = d; }
     }
   }
-  if (best.ks > 1 && best.ws != 3) {  // the other way of summing the slabs: last-arriving workgroup <-> second launch
+  if (best.ks > 1 && best.ws != 3 && best.tail == 0) {  // the other way of summing the slabs: last-arriving workgroup <-> second launch
     const ConvCfg w = best;
     for (int ks : {w.ks, w.ks / 2, w.ks / 4}) {  // the folded form sums its slabs in one workgroup: fewer slabs may suit it better
       if (ks < 2) continue;
@@ -1393,7 +1472,7 @@ static ConvCfg tune_cfg(ConvParams& p, hipStream_t stream) {
     }
   }
   // verification against the reference configuration on the tuning data (see above)
-  if (best.bm != h.bm || best.bn != h.bn || best.ks != h.ks || best.ws != h.ws || best.fold != h.fold) {
+  if (best.bm != h.bm || best.bn != h.bn || best.ks != h.ks || best.ws != h.ws || best.fold != h.fold || best.tail != h.tail) {
     const int ld = (p.Cout + 3) & ~3;
     const size_t n = (size_t)p.N * p.OH * p.OW * ld;
     float* r0 = tune_scratch(n, 0);
@@ -1412,16 +1491,17 @@ static ConvCfg tune_cfg(ConvParams& p, hipStream_t stream) {
       ok = rc == UDET_OK && tune_compare(r0, r1, n, stream, &diff, &scale);
     }
     if (!ok) {
-      fprintf(stderr, "[udet tune] REJECTED N=%d %dx%d Kc=%d taps=%d cls=%d Cout=%d: %dx%d ks=%d ws=%d fold=%d differs from the reference "
+      fprintf(stderr, "[udet tune] REJECTED N=%d %dx%d Kc=%d taps=%d cls=%d Cout=%d: %dx%d ks=%d ws=%d fold=%d tail=%d differs from the reference "
               "configuration (max|diff| %.3e, scale %.3e); keeping the heuristic\n", p.N, p.OHq, p.OWq, p.Kc, p.ntaps, p.ncls, p.Cout,
-              best.bm, best.bn, best.ks, best.ws, best.fold, diff, scale);
+              best.bm, best.bn, best.ks, best.ws, best.fold, best.tail, diff, scale);
       conv_tune_note_reject();
       best = h;
     }
   }
   if (getenv("UDET_TUNE_LOG"))
-    fprintf(stderr, "[udet tune] N=%d %dx%d Kc=%d taps=%d cls=%d Cout=%d -> %dx%d ks=%d ws=%d fold=%d  %.1f us (heuristic %dx%d ks=%d)\n", p.N,
-            p.OHq, p.OWq, p.Kc, p.ntaps, p.ncls, p.Cout, best.bm, best.bn, best.ks, best.ws, best.fold, (a < b ? a : b) * 1e3f, h.bm, h.bn, h.ks);
+    fprintf(stderr, "[udet tune] N=%d %dx%d Kc=%d taps=%d cls=%d Cout=%d -> %dx%d ks=%d ws=%d fold=%d tail=%d  %.1f us (heuristic %dx%d ks=%d)\n", p.N,
+            p.OHq, p.OWq, p.Kc, p.ntaps, p.ncls, p.Cout, best.bm, best.bn, best.ks, best.ws, best.fold, best.tail, (a < b ? a : b) * 1e3f, h.bm, h.bn,
+            h.ks);
   return best;
 }
 
@@ -1464,14 +1544,19 @@ int launch_conv(ConvParams& p, hipStream_t stream) {
     }
   }
   if (g_force_bm) { c.bm = g_force_bm; c.bn = g_force_bn; }
-  if (g_force_ks >= 0) c.ks = g_force_ks > max_ksplit(p) ? max_ksplit(p) : g_force_ks;
+  if (g_force_ks >= 0) { c.ks = g_force_ks > max_ksplit(p) ? max_ksplit(p) : g_force_ks; c.tail = 0; }
   if (g_force_ws >= 0) c.ws = g_force_ws;
   if (g_force_fold >= 0) c.fold = g_force_fold;
+  if (g_force_tail > 0) {
+    int fx = 0, k = 0;
+    if (tail_for_rounds(p, c.bm, c.bn, g_force_tail, max_ksplit(p), &fx, &k)) { c.tail = fx; c.ks = c.ks >= 2 ? c.ks : k; c.fold = 0; }
+  }
   if ((c.ws == 2 || c.ws == 4 || c.ws == 5 || c.ws == 6) && !dma_ok(p)) c.ws = 1;
   if (c.ws == 6 && !self_staging_tile(c.bm, c.bn)) c.ws = 2;
   if (g_force_ws == 3) { c.ws = 3; c.bm = (g_force_bm == 4) ? 4 : 8; }
   if (c.ws == 3 && !tile_ok(p, c.bm)) { c = heuristic_cfg(p); }
-  g_last_cfg = (c.ws & 0xff) | ((c.bm & 0xfff) << 8) | ((c.ks & 0xff) << 20) | ((c.ks > 1 && c.fold && c.ws != 3 && p.tickets ? 1 : 0) << 28);
+  g_last_cfg = (c.ws & 0xff) | ((c.bm & 0xfff) << 8) | ((c.ks & 0xff) << 20) | ((c.ks > 1 && c.fold && c.ws != 3 && p.tickets ? 1 : 0) << 28) |
+               ((c.ks > 1 && c.tail > 0 ? 1 : 0) << 29);
   return run_cfg(p, c, stream);
 }
 
