@@ -40,6 +40,9 @@ SHAPES = [
     ("gen.conv16", 4, 192, 384, 32, 16, 3, 1, 1, False),
     ("rec.deconv1", 12, 96, 192, 104, 16, 4, 1, 1, False),
     ("rec.deconv3", 12, 24, 48, 392, 64, 4, 1, 1, False),
+    ("rec.deconv1_dgrad", 12, 96, 192, 16, 98, 4, 1, 1, False),   # short K (16 channels x 16 taps), wide N
+    ("rec.deconv2_dgrad", 12, 48, 96, 32, 194, 4, 1, 1, False),
+    ("gen.conv16_dgrad", 4, 192, 384, 16, 32, 3, 1, 1, False),
     ("rec.aconv41", 12, 12, 24, 128, 128, 3, 1, 1, False),
 ]
 

@@ -119,7 +119,8 @@ struct ConvParams {
   int ncls;
   int cls_tap[5];
   FastDiv fd_ohw, fd_ow;  // filled by launch_conv
-  int kfast;              // LDS-DMA kernels: stages never straddle taps (Kc >= 32, no up-sampled read): wave-uniform K cursor; filled by launch_conv
+  int kfast;              // LDS-DMA kernels: stages never straddle taps (no up-sampled read; bit 0: Kc >= 32, 32-wide stages, bit 1: Kc >= 16,
+                          // 16-wide stages): wave-uniform K cursor; filled by launch_conv
   const float* zero16;    // >= 16 bytes of zeros in device memory (source of halo / tail lanes of the LDS-DMA kernel); may be null
   // epilogue
   int act;

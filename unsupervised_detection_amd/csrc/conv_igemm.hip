@@ -599,7 +599,9 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void conv_igemm_dma_kernel(co
   const int Kc = p.Kc;
   // kfast (Kc >= 32, no up-sampled read): a stage is ONE (channel block, tap) pair -- the last, narrower block is padded with zero
   // lanes instead of straddling into the next tap -- so the K cursor is wave-uniform (see the staging waves)
-  const int nchunks = p.kfast ? ntc * ((Kc + 31) >> 5) : (ntc * Kc + BK - 1) / BK;
+  // kfast bit 2 (Kc in {4, 8, 16}): a stage is 32 / Kc WHOLE taps; the tap of a lane follows from its channel slot (a per-lane constant)
+  const int tps = (p.kfast & 4) ? 32 / Kc : 1;  // taps per stage
+  const int nchunks = (p.kfast & 1) ? ntc * ((Kc + 31) >> 5) : ((p.kfast & 4) ? (ntc + tps - 1) / tps : (ntc * Kc + BK - 1) / BK);
   int c_begin = 0, c_end = nchunks;
   if (knz > 1) {
     c_begin = (int)((long)nchunks * kz / knz);
@@ -634,9 +636,9 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void conv_igemm_dma_kernel(co
     // with data-dependent control flow -- ~1500 instructions per stage for a 128x128 tile, more than the 4096 MFMA cycles of the
     // stage leave room for on a SIMD that also hosts an MFMA wave.  The uniform cursor below needs ~100.
     const KOrder ko = korder(Kc, ntc);
-    KCursor ka = kc_init(ko, p.kfast ? 0 : c_begin * BK + kqs * 4), kb[B_LD];
+    KCursor ka = kc_init(ko, (p.kfast & 5) ? 0 : c_begin * BK + kqs * 4), kb[B_LD];
 #pragma unroll
-    for (int j = 0; j < B_LD; ++j) kb[j] = kc_init(ko, p.kfast ? 0 : c_begin * BK + (t + j * 256) / B_F4_ROW);
+    for (int j = 0; j < B_LD; ++j) kb[j] = kc_init(ko, (p.kfast & 5) ? 0 : c_begin * BK + (t + j * 256) / B_F4_ROW);
     auto issue_generic = [&](int buf) {
       int dy = 0, dx = 0;
       const bool a_ok = kc_valid(ko, ka);
@@ -706,8 +708,40 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void conv_igemm_dma_kernel(co
       }
       if (++s_tap == ntc) { s_tap = 0; ++s_blk; }
     };
+    // Packed taps (Kc < 32): stage s holds taps s * tps .. s * tps + tps - 1; K index k of the stage = (tap k / Kc, channel k % Kc).
+    const int a_sub = (kqs * 4) / Kc, a_ch = (kqs * 4) - a_sub * Kc;  // this lane's A slot
+    int b_sub[B_LD], b_poff[B_LD];
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) {
+      b_sub[j] = b_row[j] / Kc;
+      b_poff[j] = (b_row[j] - b_sub[j] * Kc) * p.ldw + (b_off[j] - b_row[j] * p.ldw);  // (channel row, column) inside the tap's weight block
+    }
+    int s_stage = c_begin;
+    auto issue_pack = [&](int buf) {
+      const int ta = s_stage * tps + a_sub;
+      const bool ta_ok = ta < ntc;
+      const int2 yx = tap_yx[ta_ok ? ta : 0];
+      const int dy = yx.x, dx = yx.y;
+      const int tap_off = (dy * Ws + dx) * p.ldx + a_ch - kqs * 4;  // (a_off carries + kqs * 4)
+#pragma unroll
+      for (int j = 0; j < A_LD; ++j) {
+        const int iy = a_iy0[j] + dy, ix = a_ix0[j] + dx;
+        const bool ok = ta_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const float* src = ok ? p.x + (a_off[j] + tap_off) : zero;
+        __builtin_amdgcn_global_load_lds(src, (lds_ptr)&As[buf][j * 32 + wave * 8][0], 16, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < B_LD; ++j) {
+        const int tb = s_stage * tps + b_sub[j];
+        const bool ok = b_col[j] && tb < ntc;
+        const float* src = ok ? p.wp + ((size_t)tap_w[ok ? tb : 0] * Kc * p.ldw + b_poff[j]) : zero;
+        __builtin_amdgcn_global_load_lds(src, (lds_ptr)(&Bs[buf][0][0] + (j * 256 + wave * 64) * 4), 16, 0, 0);
+      }
+      ++s_stage;
+    };
     auto issue = [&](int buf) {
-      if (p.kfast) issue_fast(buf);
+      if (p.kfast & 1) issue_fast(buf);
+      else if (p.kfast & 4) issue_pack(buf);
       else issue_generic(buf);
     };
     // NS-deep ring: NS - 1 stages are in flight while the MFMA waves work on one, so a stage has (NS - 1) chunk times to land
@@ -862,8 +896,9 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_dma4_kernel(const ConvParam
     rowoff[r] = off;
   }
   const int Kc = p.Kc;
-  // kfast: a stage is one half (16 channels) of ONE (32-channel block, tap) pair -- uniform K cursor, see conv_igemm_dma_kernel
-  const int nchunks = p.kfast ? 2 * ntc * ((Kc + 31) >> 5) : (ntc * Kc + BK - 1) / BK;
+  // kfast (bit 1: Kc >= 16, no up-sampled read): a stage is ONE (16-channel block, tap) pair -- uniform K cursor, see conv_igemm_dma_kernel
+  const bool kfast = (p.kfast & 2) != 0;
+  const int nchunks = kfast ? ntc * ((Kc + 15) >> 4) : (ntc * Kc + BK - 1) / BK;
   int c_begin = 0, c_end = nchunks;
   if (p.ksplit > 1) {
     c_begin = (int)((long)nchunks * blockIdx.z / p.ksplit);
@@ -892,9 +927,9 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_dma4_kernel(const ConvParam
   }
   const float* zero = p.zero16;
   const KOrder ko = korder(Kc, ntc);
-  KCursor ka = kc_init(ko, p.kfast ? 0 : c_begin * BK + kqs * 4), kb[B_LD];
+  KCursor ka = kc_init(ko, kfast ? 0 : c_begin * BK + kqs * 4), kb[B_LD];
 #pragma unroll
-  for (int j = 0; j < B_LD; ++j) kb[j] = kc_init(ko, p.kfast ? 0 : c_begin * BK + (t + j * 256) / B_F4_ROW);
+  for (int j = 0; j < B_LD; ++j) kb[j] = kc_init(ko, kfast ? 0 : c_begin * BK + (t + j * 256) / B_F4_ROW);
   auto issue_generic = [&](int buf) {
     int dy = 0, dx = 0;
     const bool a_ok = kc_valid(ko, ka);
@@ -928,7 +963,7 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_dma4_kernel(const ConvParam
 #pragma unroll
     for (int j = 0; j < B_LD; ++j) kc_advance(ko, kb[j], BK);
   };
-  // uniform cursor: stage s = (block, tap, half) = (s / (2 ntc), (s / 2) % ntc, s & 1), kept in scalars
+  // uniform cursor: stage s = (16-channel block s / ntc, tap s % ntc), kept in scalars
   int a_off[A_LD];
 #pragma unroll
   for (int j = 0; j < A_LD; ++j)
@@ -943,12 +978,11 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_dma4_kernel(const ConvParam
     b_col[j] = n < p.ldw;
   }
   const int ntc_ = ntc > 0 ? ntc : 1;
-  int s_half = __builtin_amdgcn_readfirstlane(c_begin & 1);
-  int s_blk = __builtin_amdgcn_readfirstlane((c_begin >> 1) / ntc_);
-  int s_tap = __builtin_amdgcn_readfirstlane((c_begin >> 1) - s_blk * ntc_);
+  int s_blk = __builtin_amdgcn_readfirstlane(c_begin / ntc_);
+  int s_tap = __builtin_amdgcn_readfirstlane(c_begin - s_blk * ntc_);
   auto issue_fast = [&](int buf) {
     const int2 yx = tap_yx[s_tap];
-    const int dy = yx.x, dx = yx.y, c0 = (s_blk << 5) + (s_half << 4);
+    const int dy = yx.x, dx = yx.y, c0 = s_blk << 4;
     const int tap_off = (dy * Ws + dx) * p.ldx + c0;
     const bool ch_ok = c0 + kqs * 4 < Kc;
 #pragma unroll
@@ -967,13 +1001,10 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_dma4_kernel(const ConvParam
         __builtin_amdgcn_global_load_lds(src, (lds_ptr)(&Bs[buf][0][0] + (j * 256 + wave * 64) * 4), 16, 0, 0);
       }
     }
-    if (++s_half == 2) {
-      s_half = 0;
-      if (++s_tap == ntc) { s_tap = 0; ++s_blk; }
-    }
+    if (++s_tap == ntc) { s_tap = 0; ++s_blk; }
   };
   auto issue = [&](int buf) {
-    if (p.kfast) issue_fast(buf);
+    if (kfast) issue_fast(buf);
     else issue_generic(buf);
   };
   auto meet = [&]() {  // this wave's DMA has landed and its fragment reads are done, then meet the other waves
@@ -1525,7 +1556,10 @@ int launch_conv(ConvParams& p, hipStream_t stream) {
   }
   p.fd_ohw = make_fastdiv((unsigned)(p.OHq * p.OWq));
   p.fd_ow = make_fastdiv((unsigned)p.OWq);
-  p.kfast = p.Kc >= 32 && p.up_shift == 0;
+  // uniform K cursors (no up-sampled read).  bit 0: Kc >= 32, 32-wide stages (wave-specialised kernel); bit 1: Kc >= 16, 16-wide
+  // stages (self-staging kernel); bit 2: Kc in {4, 8, 16}, 32 / Kc whole taps per 32-wide stage (wave-specialised kernel)
+  p.kfast = 0;
+  if (p.up_shift == 0) p.kfast = p.Kc >= 32 ? 3 : ((p.Kc >= 16 ? 2 : 0) | ((p.Kc == 4 || p.Kc == 8 || p.Kc == 16) ? 4 : 0));
   ConvCfg c;
   bool have = false;
   const uint64_t key = conv_key(p);
