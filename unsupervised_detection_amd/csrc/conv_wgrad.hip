@@ -192,8 +192,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, in
 // LDS-DMA variant (dU operand, i.e. no act' on load): 512-thread workgroups, waves 4-7 stage both pixel-major operands
 // with global_load_lds_dwordx4 (they ARE the K-major LDS image: no swizzle needed, fragments stay conflict-free
 // ds_read_b32), halo / tail lanes read a zero block; waves 0-3 run the MFMAs and the bias column sums.
-template <int BM, int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(512, 4) void conv_wgrad_dma_kernel(const WgradParams p, int co_tiles, int nsplit) {
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NS>
+__global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void conv_wgrad_dma_kernel(const WgradParams p, int co_tiles, int nsplit) {
+  static_assert(NS == 2 || NS == 3, "stages");
   constexpr int BKP = 32;
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
   constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -203,8 +204,8 @@ __global__ __launch_bounds__(512, 4) void conv_wgrad_dma_kernel(const WgradParam
   constexpr int B_LD = (B_F4 + 255) / 256;
   static_assert(A_LD * 256 == BKP * A_F4_ROW, "tile");
   typedef __attribute__((address_space(3))) void* lds_ptr;
-  __shared__ __attribute__((aligned(16))) float As[2][BKP][BM];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BKP][BN];
+  __shared__ __attribute__((aligned(16))) float As[NS][BKP][BM];
+  __shared__ __attribute__((aligned(16))) float Bs[NS][BKP][BN];
   __shared__ int2 tap_yx[UDET_MAX_TAPS];
 
   const int tid = threadIdx.x;
@@ -267,17 +268,28 @@ __global__ __launch_bounds__(512, 4) void conv_wgrad_dma_kernel(const WgradParam
         __builtin_amdgcn_global_load_lds(src, (lds_ptr)(&Bs[buf][0][0] + (j * 256 + wave * 64) * 4), 16, 0, 0);
       }
     };
-    auto landed = [&]() {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // NS-deep ring (conv_igemm_dma_kernel): NS - 1 stages in flight; every lane issues A_LD + B_LD DMA instructions per stage
+    static_assert(NS == 2 || B_F4 % 256 == 0, "a ring deeper than 2 counts the DMA instructions per stage");
+    constexpr int L = A_LD + B_LD;
+    auto landed = [&](int newer) {
+      if (NS > 2 && newer >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     };
-    if (c_begin < c_end) issue(0, c_begin);
-    landed();
-    int buf = 0;
+    int issued = c_begin, ibuf = 0;
+    for (int s = 0; s < NS - 1 && issued < c_end; ++s) {
+      issue(ibuf, issued);
+      ibuf = ibuf + 1 == NS ? 0 : ibuf + 1;
+      ++issued;
+    }
+    landed(issued - c_begin - 1);
     for (int c = c_begin; c < c_end; ++c) {
-      if (c + 1 < c_end) issue(buf ^ 1, c + 1);
-      landed();
-      buf ^= 1;
+      if (issued < c_end) {
+        issue(ibuf, issued);
+        ibuf = ibuf + 1 == NS ? 0 : ibuf + 1;
+        ++issued;
+      }
+      landed(issued - c - 2);
     }
     return;
   }
@@ -332,7 +344,7 @@ __global__ __launch_bounds__(512, 4) void conv_wgrad_dma_kernel(const WgradParam
       for (int k = 0; k < BKP; ++k) bsum += Bs[buf][k][t];
     }
     handover();
-    buf ^= 1;
+    buf = buf + 1 == NS ? 0 : buf + 1;
   }
   const int ldn = co_tiles * BN;
   float* dst = p.partial + (size_t)blockIdx.y * p.Mpad * ldn;
@@ -466,7 +478,7 @@ size_t wgrad_partial_floats_needed(int T, int Cin, int Cout) {
   return (size_t)BND_SPLIT * Cout + ldn + mpad * ldn + 64;
 }
 
-static std::unordered_map<uint64_t, int> g_wcache;  // problem shape -> split count | (LDS-DMA variant ? 1<<20 : 0)
+static std::unordered_map<uint64_t, int> g_wcache;  // problem shape -> split count | (LDS-DMA variant: 1 / 2 for a 2- / 3-stage ring) << 20
 static std::mutex g_wcache_mu;
 static int g_wtuning = 0;
 void wgrad_set_tuning(int on) { g_wtuning = on; }
@@ -481,9 +493,10 @@ void wgrad_tune_put(unsigned long long key, int cfg) {
 }
 
 template <int BM, int BN, int WM_, int WN_>
-static void wgrad_launch(const WgradParams& p, int m_tiles, int co_tiles, int nsplit, bool dma, hipStream_t stream) {
+static void wgrad_launch(const WgradParams& p, int m_tiles, int co_tiles, int nsplit, int dma, hipStream_t stream) {  // dma: 0 off, 1 / 2: 2- / 3-stage ring
   dim3 grid(m_tiles * co_tiles, nsplit);
-  if (dma) UDET_LAUNCH((conv_wgrad_dma_kernel<BM, BN, WM_, WN_>), grid, dim3(512), 0, stream, p, co_tiles, nsplit);
+  if (dma == 2) UDET_LAUNCH((conv_wgrad_dma_kernel<BM, BN, WM_, WN_, 3>), grid, dim3(512), 0, stream, p, co_tiles, nsplit);
+  else if (dma) UDET_LAUNCH((conv_wgrad_dma_kernel<BM, BN, WM_, WN_, 2>), grid, dim3(512), 0, stream, p, co_tiles, nsplit);
   else UDET_LAUNCH((conv_wgrad_kernel<BM, BN, WM_, WN_>), grid, dim3(256), 0, stream, p, co_tiles, nsplit);
 }
 
@@ -561,7 +574,7 @@ int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream) {
   const bool dma_ok = p.ya == nullptr && p.zero16 != nullptr && !(reinterpret_cast<uintptr_t>(p.zero16) & 15);
   auto run = [&](int cfg) {
     const int ns = cfg & 0xfffff;
-    const bool dma = dma_ok && (cfg >> 20) != 0;
+    const int dma = dma_ok ? (cfg >> 20) : 0;
     WgradParams q = g;
     q.pbias = base;                                        // [ns][bias groups][ldn]
     q.partial = base + (size_t)ns * bgroups * ldn;        // [ns][Mpad][ldn]
@@ -598,7 +611,7 @@ int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream) {
         const int ns = (int)(256L * k / tiles);
         if (ns >= 1 && std::find(nss.begin(), nss.end(), ns) == nss.end()) nss.push_back(ns);
       }
-      for (int dma = 0; dma <= (dma_ok ? 1 : 0); ++dma)
+      for (int dma = 0; dma <= (dma_ok ? 2 : 0); ++dma)
         for (int ns : nss) {
           if (ns < 1 || ns > cap) continue;
           const int cfg = ns | (dma << 20);
