@@ -468,6 +468,7 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 2) void conv_igemm_kernel(
       __builtin_amdgcn_s_barrier();
     };
     if (role == 1) {
+      __builtin_amdgcn_s_setprio(3);  // staging waves first (see conv_igemm_dma_kernel)
       if (c_begin < c_end) {
         load_chunk();
         store_chunk(0);
@@ -613,6 +614,9 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void conv_igemm_dma_kernel(co
 
   if (role == 1) {
     // ------------------------------------------------ staging waves ------------------------------------------------
+    // issue priority over the MFMA waves of the same SIMD (this and the co-resident workgroups'): a stage's DMA goes out as soon as
+    // its buffer is free instead of waiting for gaps between MFMAs (128x64 tile on the 568-channel layer: 920 -> 750 us)
+    __builtin_amdgcn_s_setprio(3);
     const int kq = lane & 7;                                  // LDS slot written by this lane (lane-linear)
     const int kqs = kq ^ ((wave * 4 + (lane >> 4)) & 7);      // channel group it holds: slot ^ ((row>>1)&7)
     int a_base[A_LD], a_iy0[A_LD], a_ix0[A_LD];

@@ -225,6 +225,7 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void conv_wgrad_dma_kernel(co
   __syncthreads();
 
   if (role == 1) {
+    __builtin_amdgcn_s_setprio(3);  // staging waves issue ahead of the MFMA waves (see conv_igemm_dma_kernel)
     const int ycl = p.ycls ? (m0 / p.Cin4) >> 2 : 0;
     const int a_m4 = t % A_F4_ROW;
     const int a_m = m0 + a_m4 * 4;
