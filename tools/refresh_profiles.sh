@@ -1,0 +1,30 @@
+#!/bin/bash
+# Re-collects every measurement artefact under profiles/ on an MI355X box (one GPU):
+#   gpurun --timeout 1800 -- 'bash tools/refresh_profiles.sh'        then copy gpurun_out/prof/* to profiles/rNN_*
+# 1. the bench line (tuning run: writes the configurations it picked and the per-launch CSV of its measurement pass)
+# 2. rocprofv3 kernel traces of TIMED STEPS ONLY (serial and pipelined), reduced by tools/trace_report.py
+# 3. PMC counters of whole steps in separate passes (tools/pmc_step.py; never combined with the system trace domains)
+# 4. the HBM-bound warp / cost-volume kernels and the MFMA ceiling probe
+set -u
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+O=$R/gpurun_out/prof
+mkdir -p "$O"
+cd "$R"
+UDET_TUNE_LOG=1 UDET_PROF_DUMP=$O/layers.csv python bench.py --tune-cache "$O/tune.txt" > "$O/bench.json" 2> "$O/bench.err"
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/tr_s /tmp/tr_p
+UDET_SERIAL=1 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tr_s -o steps -- \
+    python "$R/bench.py" --tune-cache "$O/tune.txt" --trace-only --no-pipeline --steps 10 --warmup 2 > "$O/trace_serial.log" 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tr_p -o steps -- \
+    python "$R/bench.py" --tune-cache "$O/tune.txt" --trace-only --steps 10 --warmup 2 > "$O/trace_pipelined.log" 2>&1
+cd "$R"
+python tools/trace_report.py /tmp/tr_s --steps 12 --layers "$O/layers.csv" --out "$O/trace_report_serial.json" \
+    --copy-stats "$O/kernel_stats_serial_steps.csv" > /dev/null
+python tools/trace_report.py /tmp/tr_p --steps 12 --layers "$O/layers.csv" --out "$O/trace_report_pipelined.json" \
+    --copy-stats "$O/kernel_stats_pipelined_steps.csv" > /dev/null
+cd /tmp
+python "$R/tools/pmc_step.py" --tune-cache "$O/tune.txt" --out "$O/pmc_step.json" > /dev/null 2> "$O/pmc_step.err"
+cd "$R"
+python tools/cv_bench.py > "$O/cv_bench.txt" 2>&1
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-value -o /tmp/mfma_peak tools/mfma_peak.hip 2> /dev/null && /tmp/mfma_peak > "$O/mfma_peak.txt" 2>&1
+ls -la "$O"
