@@ -137,7 +137,9 @@ def main():
                     "after the headline region; 0 skips that extra measurement")
     ap.add_argument("--ensemble-frames", type=int, default=12, help="frames of the configs[3] ensemble workload timed after the headline "
                     "region (extra field `ensemble`); 0 skips it")
-    ap.add_argument("--pmc-json", default="", help="PMC counters of this build collected with tools/pmc_report.py; fills roofline.traffic")
+    ap.add_argument("--pmc-json", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_step.json"),
+                    help="PMC counters of whole steps collected offline with tools/pmc_step.py (separate rocprofv3 --pmc passes); fills "
+                         "roofline.traffic with the convolution kernels' HBM bytes per step")
     args = ap.parse_args()
     if args.trace_only:
         args.no_cpu_baseline, args.cycles, args.ensemble_frames = True, 0, 0
@@ -321,10 +323,18 @@ def main():
         exe_flops = sum(l[3] for l in layers if l[0] < 3) * 1e9 or alg_flops
         achieved = exe_flops / (conv_ms * 1e-3) / 1e12
         top = max((l for l in layers if l[0] < 3), key=lambda l: l[3], default=None)
-        pmc = {}
+        traffic, traffic_source = None, None
         if args.pmc_json and os.path.exists(args.pmc_json):
             with open(args.pmc_json) as f:
                 pmc = json.load(f)
+            conv = ("conv_igemm", "conv_tile", "conv_wgrad", "wgrad_reduce", "conv_splitk_epilogue", "tap_gather", "bn_dot", "bn_finish")
+            fam = [k for k in pmc.get("kernel_families", []) if any(c in k["kernel"] for c in conv)]
+            if "traffic_bytes_per_launch" in pmc:  # tools/pmc_report.py: one launch
+                traffic = pmc["traffic_bytes_per_launch"]
+            elif fam:  # tools/pmc_step.py: FETCH_SIZE x 2 + WRITE_SIZE of every dispatch, summed over the convolution kernels of one step
+                traffic = int(sum(k["hbm_MB_per_step"] for k in fam) * 1e6)
+            traffic_source = "%s (offline rocprofv3 --pmc passes over serial steps, not re-collected by this run; unit: bytes per step = " \
+                             "per pass of all convolution launches, like `achieved`)" % os.path.relpath(args.pmc_json, os.path.dirname(os.path.abspath(__file__)))
         top_launch = None
         if top is not None:
             top_tf = top[3] / top[2] if top[2] > 0 else 0.0  # GFLOP / ms = TFLOP/s
@@ -343,9 +353,9 @@ def main():
                     "executed_gflop_per_step": round(exe_flops / 1e9, 2), "alg_gflop_per_step": round(alg_flops / 1e9, 2),
                     "achieved_algorithmic": round(alg_flops / (conv_ms * 1e-3) / 1e12, 2),
                     "frac_algorithmic": round(alg_flops / (conv_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
-                    # HBM bytes per launch from PMC counters are collected offline (tools/pmc_report.py, separate rocprofv3 --pmc
-                    # passes, summaries under profiles/); filled here only from a --pmc-json of this build, else null
-                    "traffic": pmc.get("traffic_bytes_per_launch"), "traffic_source": args.pmc_json or None,
+                    # HBM bytes from PMC counters are collected offline (tools/pmc_step.py, separate rocprofv3 --pmc passes, summaries
+                    # under profiles/): the committed collection of this build, or the file given with --pmc-json; null without one
+                    "traffic": traffic, "traffic_source": traffic_source,
                     "launch_groups_per_step": int(conv_groups), "avg_group_ms": round(conv_ms / max(conv_groups, 1), 4),
                     "conv_ms_per_step_serial": round(conv_ms, 3),
                     # the same launch groups bracketed by hipEventRecord before / after (adds event packets + dispatch gaps)
