@@ -1,5 +1,5 @@
 // Ceiling probe for the fp32 MFMA pipe of one MI355X (what the implicit-GEMM main loops can reach at best):
-//   hipcc --offload-arch=gfx950 -O3 -o gpurun_exp/mfma_peak tools/mfma_peak.hip && gpurun_exp/mfma_peak
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_peak tools/mfma_peak.hip && /tmp/mfma_peak      (profiles/rNN_mfma_peak.txt)
 // Every variant issues the same number of v_mfma_f32_32x32x2_f32 per wave on four independent accumulators (the
 // 64x64 wave tile of the 128x128 kernels) and differs in what surrounds them:
 //   mode 0  MFMAs only
@@ -7,16 +7,17 @@
 //             group ahead
 //   mode 2  + one s_barrier per 64 MFMAs (the stage handover) among the workgroup's waves
 //   mode 3  mode 2 with 4 extra idle waves per workgroup that only take part in the barrier (the staging waves' slot)
-//   mode 4  mode 3, and those waves fetch the next 32 KB stage with global_load_lds_dwordx4 (one stage in flight, vmcnt(0) before
-//           the barrier -- the protocol of conv_igemm_dma_kernel): every 8 lanes read one 128-byte line, lines `stride` bytes
-//           apart, each workgroup cycling through its own `region` bytes of a global buffer
+//   mode 4  mode 3, and those waves fetch the next stage (NJ x 4 KB) with global_load_lds_dwordx4 -- one stage in flight and vmcnt(0)
+//           before the barrier (the protocol of conv_igemm_dma_kernel), or two in flight with a 3-buffer ring: every 8 lanes read one
+//           128-byte line, lines `stride` bytes apart, each workgroup cycling through its own `region` bytes (a power of two of
+//           lines) of a global buffer.  The address arithmetic is a handful of VALU operations on purpose: with a 64-bit modulo per
+//           load the same probe loses a third of its MFMA rate (VALU work of a staging wave is paid by the MFMA wave of its SIMD).
 // Reported: TFLOP/s over the whole chip at `wgs_per_cu` resident workgroups per CU.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
-__device__ __forceinline__ int j_unused() { return 0; }
 
 template <int MODE, int NJ = 8, int NS = 2>
 __global__ __launch_bounds__(512) void probe(float* out, int stages, const float* src = nullptr, long region = 0, int stride = 128) {
@@ -28,7 +29,6 @@ __global__ __launch_bounds__(512) void probe(float* out, int stages, const float
     (&Bs[0][0][0])[i] = 0.5f;
   }
   __syncthreads();
-  if (MODE == 5 && false) return;
   if (tid >= 256) {  // mode 3: barrier-only waves; mode 4: staging waves
     if (MODE == 4) {
       typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -36,7 +36,7 @@ __global__ __launch_bounds__(512) void probe(float* out, int stages, const float
       const char* base = reinterpret_cast<const char*>(src) + (long)blockIdx.x * region;
       unsigned cur = 0;  // line index inside the region
       const unsigned mask = (unsigned)(region / stride) - 1;  // (power of two) lines of the region
-      const unsigned lane_off = (l & 7) * 16, lane_line = (j_unused(), (unsigned)(l >> 3));
+      const unsigned lane_off = (l & 7) * 16, lane_line = (unsigned)(l >> 3);
       int buf = 1;
       auto issue = [&]() {
 #pragma unroll
