@@ -223,17 +223,19 @@ int launch_cost_volume(const float* c1, const float* wr, float* out, int ldo, in
 // xcds < 8: only workgroups whose hardware slot falls on the first `xcds` XCDs work (the others exit): the small pyramid
 // levels then stay inside one or two L2s instead of every XCD fetching the whole level for a handful of tiles.
 // ---------------------------------------------------------------------------
-template <int T>
-__global__ __launch_bounds__(256) void warp_cost_volume_kernel(const float* __restrict__ c1, const float* __restrict__ c2,
+template <int T, int QS>
+__global__ __launch_bounds__(256, QS == 4 ? 4 : 2) void warp_cost_volume_kernel(const float* __restrict__ c1, const float* __restrict__ c2,
                                                                const float* __restrict__ flow, int ldf, int f_coff, float flow_scale,
                                                                float* __restrict__ out, int ldo, int corr_coff, int c1_coff,
                                                                float* __restrict__ warped_dbg, int N, int H, int W, int C, int xcds) {
   constexpr int HALO = T + 2 * CV_R, NHP = HALO * HALO, NP = T * T, NG = 256 / NP, ND = (81 + NG - 1) / NG;
-  constexpr int HL = (NHP * 8 + 255) / 256;  // float4 halo items per thread and slice
-  constexpr int TL = (NP * 8 + 255) / 256;   // float4 c1 items per thread and slice
+  constexpr int CS = QS * 4 + 4;             // LDS pixel stride: a slice of QS channel quads + 4 pad floats (conflict-free ds_read_b128)
+  constexpr int QSH = QS == 8 ? 3 : 2;       // log2(QS)
+  constexpr int HL = (NHP * QS + 255) / 256;  // float4 halo items per thread and slice
+  constexpr int TL = (NP * QS + 255) / 256;   // float4 c1 items per thread and slice
   constexpr int GB = 2;                      // gather batch: items per thread whose four corner loads are in flight together
-  __shared__ __attribute__((aligned(16))) float sw[(NHP * CV_CS > NP * 81 ? NHP * CV_CS : NP * 81)];
-  __shared__ __attribute__((aligned(16))) float s1[NP * CV_CS];
+  __shared__ __attribute__((aligned(16))) float sw[(NHP * CS > NP * 81 ? NHP * CS : NP * 81)];
+  __shared__ __attribute__((aligned(16))) float s1[NP * CS];
   __shared__ int h_off[NHP];       // element offset of the top-left corner in c2 (-1: halo pixel outside the image)
   __shared__ float2 h_a[NHP];      // (alpha_y, alpha_x)
   const int t = threadIdx.x;
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(256) void warp_cost_volume_kernel(const float* __re
   int toff[TL];  // c1 tile pixel offsets (-1 outside)
 #pragma unroll
   for (int u = 0; u < TL; ++u) {
-    const int e = t + u * 256, tp = e >> 3;
+    const int e = t + u * 256, tp = e >> QSH;
     const int yy = y0 + tp / T, xx = x0 + tp % T;
     toff[u] = (tp < NP && yy < H && xx < W) ? ((n * H + yy) * W + xx) : -1;
   }
@@ -288,25 +290,25 @@ __global__ __launch_bounds__(256) void warp_cost_volume_kernel(const float* __re
   for (int j = 0; j < ND; ++j) {
     acc[j] = 0.f;
     const int d = g + NG * j, dy = d / 9, dx = d - dy * 9;
-    woff[j] = ((py + dy) * HALO + px + dx) * CV_CS;
+    woff[j] = ((py + dy) * HALO + px + dx) * CS;
   }
-  const int c4 = t & 7;
+  const int c4 = t & (QS - 1);
   const long rowC = (long)W * C;
   __syncthreads();
 
-  for (int cb = 0; cb < C; cb += 32) {
-    const bool cok = c4 * 4 < min(32, C - cb);
+  for (int cb = 0; cb < C; cb += QS * 4) {
+    const bool cok = c4 * 4 < min(QS * 4, C - cb);
     // c1 tile: LDS + the slab's c1 segment
 #pragma unroll
     for (int u = 0; u < TL; ++u) {
       const int e = t + u * 256;
-      if (e < NP * 8) {
+      if (e < NP * QS) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (cok && toff[u] >= 0) {
           v = *reinterpret_cast<const float4*>(c1 + (long)toff[u] * C + cb + c4 * 4);
           if (c1_coff >= 0) *reinterpret_cast<float4*>(out + (long)toff[u] * ldo + c1_coff + cb + c4 * 4) = v;
         }
-        *reinterpret_cast<float4*>(&s1[(e >> 3) * CV_CS + c4 * 4]) = v;
+        *reinterpret_cast<float4*>(&s1[(e >> QSH) * CS + c4 * 4]) = v;
       }
     }
     // warped halo: four corner gathers per (halo pixel, channel quad), in batches of GB items (4*GB loads in flight)
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(256) void warp_cost_volume_kernel(const float* __re
 #pragma unroll
       for (int k = 0; k < GB; ++k) {
         const int e = t + (ub + k) * 256;
-        hp[k] = e >> 3;
+        hp[k] = e >> QSH;
         tl[k] = tr[k] = bl[k] = br[k] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (ub + k < HL && hp[k] < NHP) {
           const int o = h_off[hp[k]];
@@ -343,7 +345,7 @@ __global__ __launch_bounds__(256) void warp_cost_volume_kernel(const float* __re
             o.z = lerp_rn(a.x, lerp_rn(a.y, tl[k].z, tr[k].z), lerp_rn(a.y, bl[k].z, br[k].z));
             o.w = lerp_rn(a.x, lerp_rn(a.y, tl[k].w, tr[k].w), lerp_rn(a.y, bl[k].w, br[k].w));
           }
-          *reinterpret_cast<float4*>(&sw[hp[k] * CV_CS + c4 * 4]) = o;
+          *reinterpret_cast<float4*>(&sw[hp[k] * CS + c4 * 4]) = o;
           if (warped_dbg && cok) {  // test hook: the tile's own (centre) pixels of the warped tensor
             const int hy = hp[k] / HALO, hx = hp[k] - hy * HALO;
             const int yy = y0 + hy - CV_R, xx = x0 + hx - CV_R;
@@ -358,8 +360,8 @@ __global__ __launch_bounds__(256) void warp_cost_volume_kernel(const float* __re
     // kept 8 a quads + all unrolled b loads alive: 196 VGPRs, 2 waves per SIMD).  Every accumulator still sees its channels in
     // the order q = 0..7, (x, y, z, w): bit-identical to cost_volume_kernel.
 #pragma unroll 1
-    for (int q = 0; q < 8; ++q) {
-      const float4 a = *reinterpret_cast<const float4*>(&s1[p * CV_CS + q * 4]);
+    for (int q = 0; q < QS; ++q) {
+      const float4 a = *reinterpret_cast<const float4*>(&s1[p * CS + q * 4]);
 #pragma unroll
       for (int j = 0; j < ND; ++j) {
         if (g + NG * j < 81) {
@@ -413,11 +415,18 @@ int launch_warp_cost_volume(const float* c1, const float* c2, const float* flow,
   const int xcds = tiles <= 32 ? 1 : (tiles <= 64 ? 2 : (tiles <= 128 ? 4 : 8));
   const int per = (tiles + xcds - 1) / xcds;
   const dim3 grid(per * 8);
+  // 8x8 tiles stage 16-channel slices (29 KB of LDS: four workgroups per CU -- the 960 tiles of level 2 are one round, with
+  // 32-channel slices they were 1.25 rounds of three); the small levels' 4x4 tiles keep 32 channels per barrier pair
+  static const int qs_env = getenv("UDET_CV_QS") ? atoi(getenv("UDET_CV_QS")) : 0;
+  const int qs = qs_env ? qs_env : (T == 8 ? 4 : 8);
   if (T == 4)
-    UDET_LAUNCH(warp_cost_volume_kernel<4>, grid, dim3(256), 0, stream, c1, c2, flow, ldf, f_coff, flow_scale, out, ldo, corr_coff,
+    UDET_LAUNCH((warp_cost_volume_kernel<4, 8>), grid, dim3(256), 0, stream, c1, c2, flow, ldf, f_coff, flow_scale, out, ldo, corr_coff,
+                       c1_coff, warped_dbg, N, H, W, C, xcds);
+  else if (qs == 4)
+    UDET_LAUNCH((warp_cost_volume_kernel<8, 4>), grid, dim3(256), 0, stream, c1, c2, flow, ldf, f_coff, flow_scale, out, ldo, corr_coff,
                        c1_coff, warped_dbg, N, H, W, C, xcds);
   else
-    UDET_LAUNCH(warp_cost_volume_kernel<8>, grid, dim3(256), 0, stream, c1, c2, flow, ldf, f_coff, flow_scale, out, ldo, corr_coff,
+    UDET_LAUNCH((warp_cost_volume_kernel<8, 8>), grid, dim3(256), 0, stream, c1, c2, flow, ldf, f_coff, flow_scale, out, ldo, corr_coff,
                        c1_coff, warped_dbg, N, H, W, C, xcds);
   UDET_HIP(hipGetLastError());
   return UDET_OK;
