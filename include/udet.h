@@ -177,6 +177,10 @@ typedef struct {
   float lr, beta1, beta2, adam_eps; /* 1e-4, flag beta1=0.9, 0.999, 1e-8 (adversarial_learner.py:216) */
   float clip;                /* 0.2  (adversarial_learner.py:227,233) */
   unsigned long long noise_seed;    /* stream of the escape-noise branch (loss_utils.py:7-10,19-26) */
+  int conv_fp16;             /* 0 (default): fp32 MFMA, the reference's arithmetic.  1: BASELINE.json configs[4] -- the convolution
+                              * GEMMs (forward, backward-data, backward-filter) multiply in fp16 with fp32 accumulation
+                              * (v_mfma_f32_32x32x8_f16; gradient operands scaled by 4096 against underflow); tensors, losses,
+                              * reductions and the optimizer stay fp32.  Not a reference capability: parity tolerance 2e-2. */
 } udet_config;
 
 int udet_plan_create(const udet_config* cfg, udet_plan** out);

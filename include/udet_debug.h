@@ -11,6 +11,9 @@ extern "C" {
  * ring); (0,0,-1) restores.  A forced family a launch is not
  * eligible for falls back to the built-in choice.  Process-global state: never call it from product code. */
 void udet_debug_force_conv(int bm, int bn, int ks);
+/* fp16 multiplication (fp32 accumulation) in the single-operator convolution entry points; plans take it from
+ * udet_config.conv_fp16.  Process-global state: tests only. */
+void udet_debug_conv_fp16(int on);
 /* while on, the first single-op launch of every distinct problem shape times its candidate configurations and caches the winner
  * (what udet_autotune does for a plan); tools/conv_bench.py / wgrad_bench.py use it to measure the tuned kernels stand-alone */
 void udet_debug_set_tuning(int on);

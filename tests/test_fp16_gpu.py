@@ -1,0 +1,136 @@
+"""BASELINE.json configs[4] ("fp16 convs with fp32 loss accumulation"): udet_config.conv_fp16 makes the convolution GEMMs
+multiply in fp16 (v_mfma_f32_32x32x8_f16, fp32 accumulation, gradient operands scaled by 4096) while tensors, losses,
+reductions and the optimizer stay fp32.  Not a reference capability (no fp16 anywhere), so the bar is the fp32
+oracle at a RELAXED tolerance: 2e-2 of the tensor's scale (fp16 has a 2^-11 relative rounding step; a K = 600 x 9 dot
+product of such operands stays well inside that), and the default fp32 path must be untouched."""
+import ctypes
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import oracle_torch as O  # noqa: E402
+
+TOL = 2e-2
+GRAD_TOL = 5e-2  # parameter gradients pass through up to ~30 fp16 GEMMs (forward and backward chains)
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) - 0.5) * 2 * scale
+
+
+@pytest.fixture
+def fp16_ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from unsupervised_detection_amd import ops
+    from unsupervised_detection_amd._ffi import lib
+    lib.udet_debug_conv_fp16.restype = None
+    lib.udet_debug_conv_fp16.argtypes = [ctypes.c_int]
+    lib.udet_debug_last_conv.restype = ctypes.c_int
+    lib.udet_debug_conv_fp16(1)
+    yield ops, lib
+    lib.udet_debug_conv_fp16(0)
+
+
+def rel(a, ref):
+    return float((a - ref).abs().max()) / max(1e-6, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("case", [(2, 32, 64, 64, 64, 3, 1), (1, 32, 64, 104, 16, 4, 1), (2, 24, 40, 200, 96, 3, 1), (1, 32, 64, 32, 64, 3, 2),
+                                  (1, 48, 64, 16, 32, 5, 2)])
+def test_single_operators_in_fp16(fp16_ops, case):
+    """forward, backward-data and backward-filter of one layer: fp16 multiplication really runs (an LDS-DMA family) and stays within
+    2e-2 of the float64 oracle; the same call in fp32 mode is 20x closer."""
+    ops, lib = fp16_ops
+    n, h, w, cin, cout, k, s = case
+    x = rnd(n, h, w, cin, seed=1).double().requires_grad_(True)
+    wt = (rnd(k, k, cin, cout, seed=2, scale=(2.0 / (k * k * cin)) ** 0.5)).double().requires_grad_(True)
+    b = rnd(cout, seed=3, scale=0.1).double()
+    lin = O.conv2d_same(x, wt, None, s, 1)
+    y = torch.nn.functional.leaky_relu(lin + b, 0.1)
+    dy = rnd(*lin.shape, seed=4, scale=1e-3).double()  # gradient-sized values: fp16 would flush them without the 4096 scale
+    gx, gw = torch.autograd.grad((lin * dy).sum(), [x, wt])
+    xf, wf, bf, dyf = x.detach().float().cuda(), wt.detach().float().cuda(), b.float().cuda(), dy.float().cuda()
+    got = ops.conv2d(xf, wf, bf, s, 1, "leaky", 0.1, False).cpu()
+    assert (lib.udet_debug_last_conv() & 0xff) in (2, 4, 5, 6)
+    e16 = rel(got, y.detach().float())
+    assert e16 < TOL
+    dx = ops.conv2d_backward_data(dyf, lin.detach().float().cuda(), wf, (h, w), s, 1, "none", 0.0).cpu()
+    assert rel(dx, gx.float()) < TOL
+    dw, db = ops.conv2d_backward_filter(xf, dyf, lin.detach().float().cuda(), (k, k), s, 1, "none", 0.0)
+    assert rel(dw.cpu(), gw.float()) < TOL
+    assert rel(db.cpu(), dy.sum((0, 1, 2)).float()) < 1e-4  # the bias gradient is an fp32 column sum
+    lib.udet_debug_conv_fp16(0)
+    e32 = rel(ops.conv2d(xf, wf, bf, s, 1, "leaky", 0.1, False).cpu(), y.detach().float())
+    assert e32 < 1e-4 and e32 * 5 < max(e16, 1e-6)  # the fp16 path really computed something else than the fp32 one
+
+
+class Cfg(O.Flags):
+    img_height, img_width, batch_size = 64, 128, 2
+
+
+def _perturbed(specs, seed):
+    p = O.init_params(specs, seed)
+    g = torch.Generator().manual_seed(seed)
+    for k in p:
+        if k.endswith(("bias", "biases", "beta")):
+            p[k] = torch.randn(p[k].shape, generator=g) * 0.05
+        if k.endswith("gamma"):
+            p[k] = 1 + torch.randn(p[k].shape, generator=g) * 0.1
+    return p
+
+
+def test_step_plan_in_fp16():
+    """The whole step with conv_fp16 = 1 (B = 2, SegTrackV2 pairs are resized to the same 384x640 -> 192x384 as DAVIS; here a small
+    plan): PWC flow, mask, predictions, losses and every parameter gradient against the fp32 oracle at the relaxed tolerance."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from unsupervised_detection_amd import weights as W
+    from unsupervised_detection_amd.engine import Engine, EngineConfig
+    eng = Engine(EngineConfig(batch_size=2, in_height=128, in_width=192, img_height=64, img_width=128, conv_fp16=True))
+    pp, pg, pr = _perturbed(O.pwc_param_specs(), 11), _perturbed(O.generator_param_specs(), 12), _perturbed(O.recover_param_specs(), 13)
+    flat = {"pwc": W.from_dict(pp, W.NET_PWC).cuda(), "gen": W.from_dict(pg, W.NET_GEN).cuda(), "rec": W.from_dict(pr, W.NET_REC).cuda()}
+    eng.pack_pwc(flat["pwc"])
+    eng.pack_trainable(flat["gen"], flat["rec"])
+    g = torch.Generator().manual_seed(5)
+    base = torch.rand(2, 128 + 8, 192 + 8, 3, generator=g)
+    img1 = torch.nn.functional.avg_pool2d(base.permute(0, 3, 1, 2), 5, 1, 2).permute(0, 2, 3, 1).contiguous()
+    img2 = (img1[:, 2:130, 3:195] + 0.01 * torch.randn(2, 128, 192, 3, generator=g)).contiguous() - 0.5
+    img1 = img1[:, 4:132, 4:196].contiguous() - 0.5
+    flow = eng.pwc_forward(img1.cuda(), img2.cuda()).cpu()
+    ref, _ = O.pwc_forward(pp, img1, img2)
+    assert rel(flow, ref) < TOL
+    # generator / recover on given inputs
+    gi = torch.Generator().manual_seed(21)
+    image = torch.rand(2, 64, 128, 3, generator=gi) - 0.5
+    fl = torch.randn(2, 64, 128, 2, generator=gi) * 0.1
+    fl = torch.nn.functional.avg_pool2d(fl.permute(0, 3, 1, 2), 7, 1, 3).permute(0, 2, 3, 1).contiguous() * 3
+    eng.forward_from_flow(image.cuda(), fl.cuda(), 3)
+    pgd = {k: v.double().requires_grad_(True) for k, v in pg.items()}
+    prd = {k: v.double().requires_grad_(True) for k, v in pr.items()}
+    out = O.forward_from_flow(pgd, prd, image.double(), fl.double(), Cfg)
+    assert float((eng.buffer("mask").cpu() - out["mask"].float()).abs().max()) < TOL
+    pred = eng.buffer("pred").cpu()
+    refp = torch.cat([out["pred"], out["pred_c"], out["pred_img"]], 0).float()
+    assert rel(pred, refp) < TOL
+    L = eng.losses()
+    for k in L:
+        assert abs(L[k] - float(out[k])) < TOL * max(1.0, abs(float(out[k]))), (k, L[k], float(out[k]))
+    g_gen = torch.zeros(W.param_total(W.NET_GEN), device="cuda")
+    g_rec = torch.zeros(W.param_total(W.NET_REC), device="cuda")
+    eng.backward(3, flat["gen"], flat["rec"], g_gen, g_rec)
+    gg = O.grads_of(out["generator"], pgd)
+    gr = O.grads_of(out["recover"], prd)
+    for net, got, refg in ((W.NET_GEN, g_gen.cpu(), gg), (W.NET_REC, g_rec.cpu(), gr)):
+        d = W.as_dict(got, net)
+        scale = max(float(v.abs().max()) for v in refg.values())
+        worst = 0.0
+        for k, v in refg.items():
+            err = float((d[k].double() - v).abs().max())
+            worst = max(worst, err / max(float(v.abs().max()), 1e-2 * scale))
+            assert err < GRAD_TOL * max(float(v.abs().max()), 1e-2 * scale), (k, err, float(v.abs().max()))
+        print("fp16 step plan: worst parameter-gradient error of net %d, relative to the tensor's scale: %.2e" % (net, worst))
+    assert torch.isfinite(g_gen).all() and torch.isfinite(g_rec).all()

@@ -21,6 +21,7 @@ int udet_plan_create(const udet_config* c, udet_plan** out) {
   k.flow_normalizer = c->flow_normalizer; k.cbn = c->cbn; k.epsilon = c->epsilon;
   k.lr = c->lr; k.beta1 = c->beta1; k.beta2 = c->beta2; k.adam_eps = c->adam_eps; k.clip = c->clip;
   k.noise_seed = c->noise_seed;
+  k.conv_fp16 = c->conv_fp16 ? 1 : 0;
   Plan* P = plan_build(k);
   if (!P) return UDET_ERR_SHAPE;
   *out = new udet_plan{P};

@@ -151,6 +151,11 @@ struct ConvParams {
   // tail_ks K slices -- the launch's last, partly filled round of workgroups becomes tail_ks times as many short ones.  Slabs hold
   // the tail rows only: [tail_ks][Mall - tail_prow0][ldp].  tail_ks <= 1: off.
   int tail_full, tail_ks, tail_prow0;
+  // f16 != 0 (udet_config.conv_fp16): the LDS-DMA kernels convert their fragments to fp16 (round to nearest even) and multiply with
+  // v_mfma_f32_32x32x8_f16, accumulating in fp32; tensors stay fp32 in memory.  The x operand is scaled by f16_xscale on conversion
+  // and the accumulators by 1 / f16_xscale before the epilogue: gradients (backward-data) use 4096 against fp16 underflow.
+  int f16;
+  float f16_xscale;
 };
 #define UDET_MAX_TICKETS 4096
 
@@ -204,6 +209,10 @@ struct WgradParams {
   float* dgamma;
   float* dbeta;
   float bn_c;
+  // f16 != 0: the LDS-DMA kernel multiplies in fp16 (v_mfma_f32_32x32x8_f16, fp32 accumulation); the gradient operand dU is scaled by
+  // f16_yscale on conversion (fp16 underflow) and the partial sums by its inverse before they are stored
+  int f16;
+  float f16_yscale;
 };
 int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream);
 int launch_bn_finalize(float* dw, int T, int Cin, int Cout, const float* w, const float* b, const float* gamma, float bn_c, float* pd,

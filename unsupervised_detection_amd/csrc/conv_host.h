@@ -5,6 +5,8 @@ void same_pad(int in, int k, int s, int d, int* before, int* out);
 void conv_setup_fwd(ConvParams& p, int N, int H, int W, int kh, int kw, int s, int d);
 int conv_dgrad_classes(int s, int H, int W);
 void conv_force_config(int bm, int bn, int ks);
+void conv_debug_f16(int on);  // fp16 multiplication in the single-operator launches (plans carry udet_config.conv_fp16)
+int conv_debug_f16_on();
 int conv_last_config();
 void conv_set_tuning(int on);   // autotuner: while on, unseen problem shapes are timed and the best configuration cached
 int conv_tuned_shapes();

@@ -28,6 +28,7 @@
 namespace udet {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef _Float16 halfx4 __attribute__((ext_vector_type(4)));
 
 // Flat-K cursor.  K runs channel-block-major: for every block of CB = min(Kc,32) input channels all taps of the launch,
 // then the next channel block (the last block may be narrower).  A workgroup therefore re-visits its ~3 input rows
@@ -525,7 +526,7 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 2) void conv_igemm_kernel(
 // (conflict-free under the swizzle) and walk K in the permuted order {4g+e : g = 2*kk+half}, which the B fragment
 // reads ([k][n] rows, ds_read_b32) follow.  Same flat-K / parity-class / split-K semantics as conv_igemm_kernel.
 // ---------------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NS>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NS, bool F16 = false>
 __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void conv_igemm_dma_kernel(const ConvParams p) {
   static_assert(NS >= 2 && NS <= 4, "stages");
   static_assert(WAVES_M * WAVES_N == 4, "4 MFMA waves");
@@ -786,6 +787,7 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void conv_igemm_dma_kernel(co
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   const int swz = (li >> 1) & 7;  // (row>>1)&7 of every row this lane reads (wave / sub-tile offsets are multiples of 16)
+  const float xscale = F16 ? p.f16_xscale : 1.f;
   auto handover = [&]() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -807,17 +809,32 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void conv_igemm_dma_kernel(co
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       if (kk + 1 < 4) frag((kk + 1) & 1, kk + 1);
+      if constexpr (F16) {  // the lane half's four consecutive K values of a fragment are one fp16 operand of the K = 8 MFMA
+        halfx4 ah[TM], bh[TN];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
+        for (int i = 0; i < TM; ++i)
+          ah[i] = halfx4{(_Float16)(a[kk & 1][i].x * xscale), (_Float16)(a[kk & 1][i].y * xscale), (_Float16)(a[kk & 1][i].z * xscale),
+                         (_Float16)(a[kk & 1][i].w * xscale)};
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          const float av = e == 0 ? a[kk & 1][i].x : (e == 1 ? a[kk & 1][i].y : (e == 2 ? a[kk & 1][i].z : a[kk & 1][i].w));
+        for (int j = 0; j < TN; ++j)
+          bh[j] = halfx4{(_Float16)b[kk & 1][0][j], (_Float16)b[kk & 1][1][j], (_Float16)b[kk & 1][2][j], (_Float16)b[kk & 1][3][j]};
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[kk & 1][e][j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x8f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const float av = e == 0 ? a[kk & 1][i].x : (e == 1 ? a[kk & 1][i].y : (e == 2 ? a[kk & 1][i].z : a[kk & 1][i].w));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[kk & 1][e][j], acc[i][j], 0, 0, 0);
+          }
         }
       }
       if (kk + 1 < 4) __builtin_amdgcn_sched_group_barrier(0x100, TM + 4 * TN, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);
+      if constexpr (!F16) __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);
     }
   };
   handover();
@@ -828,6 +845,15 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void conv_igemm_dma_kernel(co
       handover();
       buf = buf + 1 == NS ? 0 : buf + 1;
     }
+  }
+  if (F16 && xscale != 1.f) {
+    const float inv = 1.f / xscale;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv;
   }
   igemm_store<TM, TN, WTM, WTN>(p, acc, rowoff, wm, wn, li, lh, n0, cls * Mtot + m0, Mtot, knz > 1, slab_off,
                                 xpose_scratch<sizeof(As), sizeof(Bs)>(&As[0][0][0], &Bs[0][0][0], wave));
@@ -843,7 +869,7 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void conv_igemm_dma_kernel(co
 // keeps the pipe 44 % busy, two co-resident ones 57 %.
 // A stage: row-major [BM][16] (64-byte rows, 4 slots of 16 B), slot XOR-swizzled by (row>>1)&3 on the source side; B: [16][BN].
 // ---------------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WAVES_M, int WAVES_N>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool F16 = false>
 __global__ __launch_bounds__(256, 3) void conv_igemm_dma4_kernel(const ConvParams p) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
   constexpr int BK = 16;
@@ -1025,6 +1051,7 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_dma4_kernel(const ConvParam
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   const int swz = (li >> 1) & 3;  // (row>>1)&3 of every row this lane reads (wave / sub-tile offsets are multiples of 32)
+  const float xscale = F16 ? p.f16_xscale : 1.f;
   auto compute_chunk = [&](int buf) {
     float4 a[2][TM];
     float b[2][4][TN];
@@ -1041,17 +1068,32 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_dma4_kernel(const ConvParam
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
       if (kk + 1 < 2) frag((kk + 1) & 1, kk + 1);
+      if constexpr (F16) {  // the lane half's four consecutive K values of a fragment are one fp16 operand of the K = 8 MFMA
+        halfx4 ah[TM], bh[TN];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
+        for (int i = 0; i < TM; ++i)
+          ah[i] = halfx4{(_Float16)(a[kk & 1][i].x * xscale), (_Float16)(a[kk & 1][i].y * xscale), (_Float16)(a[kk & 1][i].z * xscale),
+                         (_Float16)(a[kk & 1][i].w * xscale)};
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          const float av = e == 0 ? a[kk & 1][i].x : (e == 1 ? a[kk & 1][i].y : (e == 2 ? a[kk & 1][i].z : a[kk & 1][i].w));
+        for (int j = 0; j < TN; ++j)
+          bh[j] = halfx4{(_Float16)b[kk & 1][0][j], (_Float16)b[kk & 1][1][j], (_Float16)b[kk & 1][2][j], (_Float16)b[kk & 1][3][j]};
 #pragma unroll
-          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[kk & 1][e][j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x8f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const float av = e == 0 ? a[kk & 1][i].x : (e == 1 ? a[kk & 1][i].y : (e == 2 ? a[kk & 1][i].z : a[kk & 1][i].w));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[kk & 1][e][j], acc[i][j], 0, 0, 0);
+          }
         }
       }
       if (kk + 1 < 2) __builtin_amdgcn_sched_group_barrier(0x100, TM + 4 * TN, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);
+      if constexpr (!F16) __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);
     }
   };
 
@@ -1065,6 +1107,15 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_dma4_kernel(const ConvParam
       meet();
       buf ^= 1;
     }
+  }
+  if (F16 && xscale != 1.f) {
+    const float inv = 1.f / xscale;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv;
   }
   igemm_store<TM, TN, WTM, WTN>(p, acc, rowoff, wm, wn, li, lh, n0, cls * Mtot + m0, Mtot, p.ksplit > 1,
                                 (long)blockIdx.z * p.ncls * Mtot * p.ldp, xpose_scratch<sizeof(As), sizeof(Bs)>(&As[0][0][0], &Bs[0][0][0], wave));
@@ -1181,14 +1232,18 @@ static int launch_cfg(ConvParams& p, int ws, hipStream_t stream) {
   }
   if (ws == 6) {
     if constexpr (BM % 64 == 0 && BN % 64 == 0 && BM <= 128) {
-      UDET_LAUNCH((conv_igemm_dma4_kernel<BM, BN, 2, 2>), grid, dim3(256), 0, stream, p);
+      if (p.f16) UDET_LAUNCH((conv_igemm_dma4_kernel<BM, BN, 2, 2, true>), grid, dim3(256), 0, stream, p);
+      else UDET_LAUNCH((conv_igemm_dma4_kernel<BM, BN, 2, 2>), grid, dim3(256), 0, stream, p);
     } else if constexpr (BN == 32 && BM % 128 == 0) {
-      UDET_LAUNCH((conv_igemm_dma4_kernel<BM, BN, 4, 1>), grid, dim3(256), 0, stream, p);
+      if (p.f16) UDET_LAUNCH((conv_igemm_dma4_kernel<BM, BN, 4, 1, true>), grid, dim3(256), 0, stream, p);
+      else UDET_LAUNCH((conv_igemm_dma4_kernel<BM, BN, 4, 1>), grid, dim3(256), 0, stream, p);
     } else {
       set_error("conv: no self-staging kernel for tile %dx%d", BM, BN);
       return UDET_ERR_UNSUPPORTED;
     }
   }
+  else if (ws == 2 && p.f16) UDET_LAUNCH((conv_igemm_dma_kernel<BM, BN, WAVES_M, WAVES_N, 2, true>), grid, dim3(512), 0, stream, p);
+  else if ((ws == 4 || ws == 5) && p.f16) UDET_LAUNCH((conv_igemm_dma_kernel<BM, BN, WAVES_M, WAVES_N, 3, true>), grid, dim3(512), 0, stream, p);
   else if (ws == 2) UDET_LAUNCH((conv_igemm_dma_kernel<BM, BN, WAVES_M, WAVES_N, 2>), grid, dim3(512), 0, stream, p);
   else if (ws == 4) UDET_LAUNCH((conv_igemm_dma_kernel<BM, BN, WAVES_M, WAVES_N, 3>), grid, dim3(512), 0, stream, p);
   else if (ws == 5) {
@@ -1282,6 +1337,7 @@ static ConvCfg heuristic_cfg(const ConvParams& p) {
   }
   c.fold = 0;  // measured (r2a): the release / acquire of the folded form costs more than the second launch on almost every shape;
                // the tuner still tries it for its winner
+  if (p.f16 && dma_ok(p)) c.ws = 2;  // fp16 multiplication exists in the LDS-DMA families only
   return c;
 }
 static int run_cfg(ConvParams& p, const ConvCfg& c, hipStream_t stream) {
@@ -1392,7 +1448,7 @@ bool tune_compare(const float* a, const float* b, size_t n, hipStream_t stream, 
 
 static uint64_t conv_key(const ConvParams& p) {
   const int f[] = {p.N, p.H, p.W, p.up_shift, p.Kc, p.Cout, p.ntaps, p.ncls, p.OHq, p.OWq, p.isy, p.osy, p.xa ? 1 : 0,
-                   p.ldx, p.ldy, p.accumulate, p.res ? 1 : 0, p.y2 ? 1 : 0, p.partial ? 1 : 0, p.cls_tap[1], p.uo ? 1 : 0};
+                   p.ldx, p.ldy, p.accumulate, p.res ? 1 : 0, p.y2 ? 1 : 0, p.partial ? 1 : 0, p.cls_tap[1], p.uo ? 1 : 0, p.f16 ? 1 : 0};
   uint64_t h = 1469598103934665603ull;
   for (int v : f) { h ^= (uint64_t)(uint32_t)v; h *= 1099511628211ull; }
   return h;
@@ -1450,6 +1506,8 @@ static ConvCfg tune_cfg(ConvParams& p, hipStream_t stream) {
   alt.ws = 0;
   float a = time_cfg(p, best, 5, stream), b = time_cfg(p, alt, 5, stream);
   if (b < a * 0.97f) { best = alt; a = b; }
+  const bool f16 = p.f16 && dma_ok(p);  // only LDS-DMA configurations multiply in fp16: every candidate must, or results differ per shape
+  if (f16) { best = h; a = b = 1e30f; }
   if (dma_ok(p)) {  // LDS-DMA staging: re-scan the tiles, the balance between staging and MFMA waves differs
     for (auto& c : cand) {
       ConvCfg d = c;
@@ -1487,7 +1545,7 @@ static ConvCfg tune_cfg(ConvParams& p, hipStream_t stream) {
     b = a;
   }
   for (int th : {8, 4}) {  // thin layers: tile-resident direct convolution
-    if (!tile_ok(p, th)) continue;
+    if (!tile_ok(p, th) || f16) continue;
     const ConvCfg d = {th, 32, 1, 3, 0};
     const float ms = time_cfg(p, d, 3, stream);
     if (ms < a * 0.97f) {
@@ -1540,7 +1598,12 @@ static ConvCfg tune_cfg(ConvParams& p, hipStream_t stream) {
   return best;
 }
 
+static int g_debug_f16 = 0;  // test hook: fp16 multiplication for the single-operator entry points too
+void conv_debug_f16(int on) { g_debug_f16 = on; }
+int conv_debug_f16_on() { return g_debug_f16; }
 int launch_conv(ConvParams& p, hipStream_t stream) {
+  if (g_debug_f16) p.f16 = 1;
+  if (p.f16 && !(p.f16_xscale > 0.f)) p.f16_xscale = 1.f;
   if (p.Kc % 4 != 0 || p.ldx % 4 != 0 || p.x_coff % 4 != 0 || p.ldw % 4 != 0) {
     set_error("conv: Kc=%d ldx=%d x_coff=%d ldw=%d violate the 4-float alignment contract", p.Kc, p.ldx, p.x_coff, p.ldw);
     return UDET_ERR_ALIGN;

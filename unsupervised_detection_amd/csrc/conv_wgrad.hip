@@ -16,6 +16,7 @@
 namespace udet {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef _Float16 halfx4 __attribute__((ext_vector_type(4)));
 
 // One GEMM per layer:  M = (tap, input channel) flattened (m = tap*Cin4 + ci, Cin4 = Cin rounded up to 4),
 // N = output channels, K = output pixels, split across workgroups (blockIdx.y).  A 128-row M tile of a 7x7 conv
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, in
 // LDS-DMA variant (dU operand, i.e. no act' on load): 512-thread workgroups, waves 4-7 stage both pixel-major operands
 // with global_load_lds_dwordx4 (they ARE the K-major LDS image: no swizzle needed, fragments stay conflict-free
 // ds_read_b32), halo / tail lanes read a zero block; waves 0-3 run the MFMAs and the bias column sums.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NS>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NS, bool F16 = false>
 __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void conv_wgrad_dma_kernel(const WgradParams p, int co_tiles, int nsplit) {
   static_assert(NS == 2 || NS == 3, "stages");
   constexpr int BKP = 32;
@@ -306,6 +307,8 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void conv_wgrad_dma_kernel(co
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   float bsum = 0.f;
+  const float yscale = F16 ? p.f16_yscale : 1.f;  // on the gradient operand: B, or A in the swapped view
+  const float ascale = p.swapped ? yscale : 1.f, bscale = p.swapped ? 1.f : yscale;
   auto handover = [&]() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -314,7 +317,33 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void conv_wgrad_dma_kernel(co
   handover();
   int buf = 0;
   for (int c = c_begin; c < c_end; ++c) {
-    {
+    if constexpr (F16) {  // K = 8 pixels per MFMA: this lane half's four consecutive pixels of a column are one fp16 operand
+      halfx4 a[2][TM], b[2][TN];
+      auto frag = [&](int s, int kk) {
+        const int k0 = kk * 8 + lh * 4;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int m = wm * WTM + i * 32 + li;
+          a[s][i] = halfx4{(_Float16)(As[buf][k0][m] * ascale), (_Float16)(As[buf][k0 + 1][m] * ascale), (_Float16)(As[buf][k0 + 2][m] * ascale),
+                           (_Float16)(As[buf][k0 + 3][m] * ascale)};
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int n = wn * WTN + j * 32 + li;
+          b[s][j] = halfx4{(_Float16)(Bs[buf][k0][n] * bscale), (_Float16)(Bs[buf][k0 + 1][n] * bscale), (_Float16)(Bs[buf][k0 + 2][n] * bscale),
+                           (_Float16)(Bs[buf][k0 + 3][n] * bscale)};
+        }
+      };
+      frag(0, 0);
+#pragma unroll
+      for (int kk = 0; kk < BKP / 8; ++kk) {
+        if (kk + 1 < BKP / 8) frag((kk + 1) & 1, kk + 1);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x8f16(a[kk & 1][i], b[kk & 1][j], acc[i][j], 0, 0, 0);
+      }
+    } else {
       float a[2][TM], b[2][TN];
       auto frag = [&](int s, int kk) {
 #pragma unroll
@@ -346,6 +375,15 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void conv_wgrad_dma_kernel(co
     }
     handover();
     buf = buf + 1 == NS ? 0 : buf + 1;
+  }
+  if (F16 && yscale != 1.f) {
+    const float inv = 1.f / yscale;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv;
   }
   const int ldn = co_tiles * BN;
   float* dst = p.partial + (size_t)blockIdx.y * p.Mpad * ldn;
@@ -496,13 +534,16 @@ void wgrad_tune_put(unsigned long long key, int cfg) {
 template <int BM, int BN, int WM_, int WN_>
 static void wgrad_launch(const WgradParams& p, int m_tiles, int co_tiles, int nsplit, int dma, hipStream_t stream) {  // dma: 0 off, 1 / 2: 2- / 3-stage ring
   dim3 grid(m_tiles * co_tiles, nsplit);
-  if (dma == 2) UDET_LAUNCH((conv_wgrad_dma_kernel<BM, BN, WM_, WN_, 3>), grid, dim3(512), 0, stream, p, co_tiles, nsplit);
+  if (dma && p.f16) UDET_LAUNCH((conv_wgrad_dma_kernel<BM, BN, WM_, WN_, 2, true>), grid, dim3(512), 0, stream, p, co_tiles, nsplit);
+  else if (dma == 2) UDET_LAUNCH((conv_wgrad_dma_kernel<BM, BN, WM_, WN_, 3>), grid, dim3(512), 0, stream, p, co_tiles, nsplit);
   else if (dma) UDET_LAUNCH((conv_wgrad_dma_kernel<BM, BN, WM_, WN_, 2>), grid, dim3(512), 0, stream, p, co_tiles, nsplit);
   else UDET_LAUNCH((conv_wgrad_kernel<BM, BN, WM_, WN_>), grid, dim3(256), 0, stream, p, co_tiles, nsplit);
 }
 
 // p.taps must list the (non-culled) taps with widx = ky*kw+kx; T = kh*kw.
 int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream) {
+  if (conv_debug_f16_on()) p.f16 = 1;
+  if (p.f16 && !(p.f16_yscale > 0.f)) p.f16_yscale = 1.f;
   if (p.ldx % 4 || p.x_coff % 4 || p.ldy % 4 || p.y_coff % 4) {
     set_error("wgrad: ldx=%d x_coff=%d ldy=%d y_coff=%d must be multiples of 4", p.ldx, p.x_coff, p.ldy, p.y_coff);
     return UDET_ERR_ALIGN;
@@ -569,6 +610,7 @@ int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream) {
   int nsplit = (int)((768 + tiles - 1) / tiles);
   if (nsplit > cap) nsplit = cap;
   if (nsplit < 1) nsplit = 1;
+  if (p.f16 && p.ya == nullptr && p.zero16 != nullptr && !(reinterpret_cast<uintptr_t>(p.zero16) & 15)) nsplit |= 1 << 20;  // fp16 lives in the LDS-DMA kernel
   const size_t wsz = (size_t)T * p.Cin * p.Cout;
   if (p.ntaps < T) UDET_HIP(hipMemsetAsync(p.dw, 0, wsz * sizeof(float), stream));  // culled taps have zero gradient
   const long total = (long)(Mreal + 1) * g.Cout;
@@ -591,7 +633,7 @@ int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream) {
   };
   // autotuned split count (see conv_igemm.hip): kernel + reduction timed together
   {
-    const int f[] = {p.N, p.H, p.W, p.up_shift, p.Cin, p.Cout, p.ntaps, p.OH, p.OW, p.isy, p.ya ? 1 : 0, p.ldx, p.ldy, cap, dma_ok ? 1 : 0, g.swapped, p.ycls};
+    const int f[] = {p.N, p.H, p.W, p.up_shift, p.Cin, p.Cout, p.ntaps, p.OH, p.OW, p.isy, p.ya ? 1 : 0, p.ldx, p.ldy, cap, dma_ok ? 1 : 0, g.swapped, p.ycls, p.f16 ? 1 : 0};
     uint64_t key = 1469598103934665603ull;
     for (int v : f) { key ^= (uint64_t)(uint32_t)v; key *= 1099511628211ull; }
     bool have = false;
@@ -607,12 +649,13 @@ int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream) {
       float best_ms = 1e30f;
       int best = h;
       // candidates: powers of two around the heuristic + the split counts that fill whole rounds of the 256 CUs
-      std::vector<int> nss = {h / 8, h / 4, h / 2, h, h * 2, h * 4};
+      const int hc = h & 0xfffff;  // (the heuristic carries the staging variant in bit 20 in fp16 mode)
+      std::vector<int> nss = {hc / 8, hc / 4, hc / 2, hc, hc * 2, hc * 4};
       for (int k : {1, 2, 3, 4, 6, 8}) {
         const int ns = (int)(256L * k / tiles);
         if (ns >= 1 && std::find(nss.begin(), nss.end(), ns) == nss.end()) nss.push_back(ns);
       }
-      for (int dma = 0; dma <= (dma_ok ? 2 : 0); ++dma)
+      for (int dma = (p.f16 && dma_ok) ? 1 : 0; dma <= (dma_ok ? (p.f16 ? 1 : 2) : 0); ++dma)
         for (int ns : nss) {
           if (ns < 1 || ns > cap) continue;
           const int cfg = ns | (dma << 20);
@@ -648,7 +691,7 @@ int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream) {
       }
       if (getenv("UDET_TUNE_LOG"))
         fprintf(stderr, "[udet tune] wgrad N=%d %dx%d Cin=%d Cout=%d taps=%d -> nsplit=%d dma=%d (heuristic %d) %.1f us\n", p.N, p.OH,
-                p.OW, p.Cin, p.Cout, p.ntaps, nsplit & 0xfffff, nsplit >> 20, h, best_ms / 3 * 1e3f);
+                p.OW, p.Cin, p.Cout, p.ntaps, nsplit & 0xfffff, nsplit >> 20, h & 0xfffff, best_ms / 3 * 1e3f);
       std::lock_guard<std::mutex> l(g_wcache_mu);
       g_wcache[key] = nsplit;
     }

@@ -66,6 +66,7 @@ struct Config {
   float flow_normalizer, cbn, epsilon;
   float lr, beta1, beta2, adam_eps, clip;
   unsigned long long noise_seed;
+  int conv_fp16 = 0;  // convolution GEMMs multiply in fp16 (fp32 accumulation)
 };
 
 struct Plan {

@@ -123,11 +123,15 @@ static void setup_up_dgrad(ConvParams& p, int N, int H, int W) {
     }
 }
 
+// fp16 mode: gradient operands are multiplied by this power of two before the fp16 conversion (and the fp32 accumulators divided by it)
+#define UDET_F16_GRAD_SCALE 4096.f
 static void fill_common(Plan* P, ConvParams& p, float* ws, int slot) {
   p.partial = ws + P->scratch_off[slot];
   p.partial_cap = P->scratch_floats;
   p.zero16 = ws + P->small_off + 60000;  // never written after udet_plan_init's memset
   p.tickets = reinterpret_cast<int*>(ws + P->ticket_off) + (size_t)slot * UDET_MAX_TICKETS;
+  p.f16 = P->cfg.conv_fp16;
+  p.f16_xscale = 1.f;  // (backward-data launches: UDET_F16_GRAD_SCALE, their x operand is a gradient)
 }
 
 static int run_fwd(Plan* P, const Layer& L, int N, float* ws, const Lane& ln, size_t x_extra = 0, size_t y_extra = 0) {
@@ -223,6 +227,7 @@ static int run_dgrad(Plan* P, const Layer& L, int N, int dy, bool dy_is_du, int 
       p.uact = em.act; p.ualpha = em.alpha; p.u_c0 = em.c0; p.u_c1 = em.c1;
     }
     fill_common(P, p, ws, ln.slot);
+    p.f16_xscale = UDET_F16_GRAD_SCALE;  // the x operand is a gradient
     UDET_TRY(launch_conv(p, s));
   }
   prof_end(P, s);
@@ -252,6 +257,8 @@ static int run_wgrad(Plan* P, const Layer& L, int N, int dy, bool dy_is_du, cons
   q.partial = ws + P->wgrad_off[ln.slot];
   q.zero16 = ws + P->small_off + 60000;
   q.partial_floats = P->wgrad_floats;
+  q.f16 = P->cfg.conv_fp16;
+  q.f16_yscale = UDET_F16_GRAD_SCALE;
   if (L.g_idx >= 0) {
     q.w = w_flat + np.p[L.w_idx].offset;
     q.b = w_flat + np.p[L.b_idx].offset;

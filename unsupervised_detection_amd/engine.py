@@ -14,7 +14,7 @@ from .weights import NET_GEN, NET_REC  # noqa: F401  (re-exported: the net ids u
 class _Cfg(ctypes.Structure):
     _fields_ = [("batch", c_i), ("in_h", c_i), ("in_w", c_i), ("img_h", c_i), ("img_w", c_i), ("flow_normalizer", c_f),
                 ("cbn", c_f), ("epsilon", c_f), ("lr", c_f), ("beta1", c_f), ("beta2", c_f), ("adam_eps", c_f), ("clip", c_f),
-                ("noise_seed", ctypes.c_ulonglong)]
+                ("noise_seed", ctypes.c_ulonglong), ("conv_fp16", c_i)]
 
 
 lib.udet_plan_create.restype = c_i
@@ -76,6 +76,7 @@ class EngineConfig:
     adam_eps: float = 1e-8
     clip: float = 0.2
     noise_seed: int = 8964
+    conv_fp16: bool = False  # BASELINE.json configs[4]: fp16 multiplication (fp32 accumulation) in the convolution GEMMs
 
 
 def _ptr(t):
@@ -93,7 +94,7 @@ class Engine:
         self.cfg = cfg
         self.device = torch.device(device)
         c = _Cfg(cfg.batch_size, cfg.in_height, cfg.in_width, cfg.img_height, cfg.img_width, cfg.flow_normalizer, cfg.cbn,
-                 cfg.epsilon, cfg.lr, cfg.beta1, cfg.beta2, cfg.adam_eps, cfg.clip, cfg.noise_seed)
+                 cfg.epsilon, cfg.lr, cfg.beta1, cfg.beta2, cfg.adam_eps, cfg.clip, cfg.noise_seed, 1 if cfg.conv_fp16 else 0)
         h = c_p()
         check(lib.udet_plan_create(ctypes.byref(c), ctypes.byref(h)))
         self._h = h
