@@ -17,6 +17,8 @@ _DEFS = [
     # not a reference flag: explicit opt-in to synthetic DAVIS-shaped pairs / seeded random weights when no dataset or checkpoint
     # is given (the reference raises IOError in those cases, adversarial_learner.py:66-67,339-343; so does this port without it)
     ("synthetic", bool, False),
+    # not a reference flag: BASELINE.json configs[4] -- fp16 multiplication (fp32 accumulation) in the convolution GEMMs
+    ("conv_fp16", bool, False),
 ]
 
 

@@ -33,7 +33,7 @@ def _engine_config(config, batch=None, in_hw=(384, 640)):
     g = lambda k, d: getattr(config, k, d)
     return EngineConfig(batch_size=batch or g("batch_size", 16), in_height=in_hw[0], in_width=in_hw[1],
                         img_height=g("img_height", 192), img_width=g("img_width", 384), flow_normalizer=g("flow_normalizer", 80.0),
-                        cbn=g("cbn", 0.5), epsilon=g("epsilon", 75.0), beta1=g("beta1", 0.9))
+                        cbn=g("cbn", 0.5), epsilon=g("epsilon", 75.0), beta1=g("beta1", 0.9), conv_fp16=bool(g("conv_fp16", False)))
 
 
 def _latest_checkpoint(checkpoint_dir):
