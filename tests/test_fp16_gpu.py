@@ -39,6 +39,26 @@ def rel(a, ref):
     return float((a - ref).abs().max()) / max(1e-6, float(ref.abs().max()))
 
 
+def test_tile_resident_kernel_in_fp16(fp16_ops):
+    """The tile-resident family (32- and 16-wide MFMA tiles) with fp16 multiplication, forced."""
+    ops, lib = fp16_ops
+    lib.udet_debug_force_conv.restype = None
+    lib.udet_debug_force_conv.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    try:
+        for (n, h, w, cin, cout, k), th in (((1, 32, 64, 32, 32, 3), 8), ((1, 32, 64, 104, 16, 4), 4), ((2, 16, 64, 16, 16, 3), 8)):
+            x = rnd(n, h, w, cin, seed=31)
+            wt = rnd(k, k, cin, cout, seed=32, scale=(2.0 / (k * k * cin)) ** 0.5)
+            b = rnd(cout, seed=33, scale=0.1)
+            ref = torch.nn.functional.leaky_relu(O.conv2d_same(x.double(), wt.double(), b.double(), 1, 1), 0.1).float()
+            lib.udet_debug_force_conv((1 << 18) + th, 0, 1)
+            got = ops.conv2d(x.cuda(), wt.cuda(), b.cuda(), 1, 1, "leaky", 0.1, False).cpu()
+            assert (lib.udet_debug_last_conv() & 0xff) == 3
+            e = rel(got, ref)
+            assert 1e-5 < e < TOL, e  # fp16-sized error: neither the fp32 path nor garbage
+    finally:
+        lib.udet_debug_force_conv(0, 0, -1)
+
+
 @pytest.mark.parametrize("case", [(2, 32, 64, 64, 64, 3, 1), (1, 32, 64, 104, 16, 4, 1), (2, 24, 40, 200, 96, 3, 1), (1, 32, 64, 32, 64, 3, 2),
                                   (1, 48, 64, 16, 32, 5, 2)])
 def test_single_operators_in_fp16(fp16_ops, case):
@@ -55,7 +75,7 @@ def test_single_operators_in_fp16(fp16_ops, case):
     gx, gw = torch.autograd.grad((lin * dy).sum(), [x, wt])
     xf, wf, bf, dyf = x.detach().float().cuda(), wt.detach().float().cuda(), b.float().cuda(), dy.float().cuda()
     got = ops.conv2d(xf, wf, bf, s, 1, "leaky", 0.1, False).cpu()
-    assert (lib.udet_debug_last_conv() & 0xff) in (2, 4, 5, 6)
+    assert (lib.udet_debug_last_conv() & 0xff) in (2, 3, 4, 5, 6)  # an fp16-capable family: LDS-DMA or tile-resident
     e16 = rel(got, y.detach().float())
     assert e16 < TOL
     dx = ops.conv2d_backward_data(dyf, lin.detach().float().cuda(), wf, (h, w), s, 1, "none", 0.0).cpu()

@@ -1545,7 +1545,7 @@ static ConvCfg tune_cfg(ConvParams& p, hipStream_t stream) {
     b = a;
   }
   for (int th : {8, 4}) {  // thin layers: tile-resident direct convolution
-    if (!tile_ok(p, th) || f16) continue;
+    if (!tile_ok(p, th)) continue;  // (multiplies in fp16 too when asked to)
     const ConvCfg d = {th, 32, 1, 3, 0};
     const float ms = time_cfg(p, d, 3, stream);
     if (ms < a * 0.97f) {

@@ -17,6 +17,7 @@
 namespace udet {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef _Float16 halfx4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void tile_epilogue(const ConvParams& p, int off, int n, float v) {
   if (p.bias) v += p.bias[n];
@@ -57,7 +58,7 @@ template <int NW> struct TileAcc;
 template <> struct TileAcc<32> { floatx16 v; };
 template <> struct TileAcc<16> { floatx4 v[2]; };
 
-template <int TH, int NW, int TILE_MT, int TILE_MW>
+template <int TH, int NW, int TILE_MT, int TILE_MW, bool F16 = false>
 __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams p, const TileGeoms gs) {
   constexpr int TW = 32;
   constexpr int TM = TH / 4;     // tile rows per wave
@@ -117,6 +118,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams p, cons
 #pragma unroll
   for (int i = 0; i < TM; ++i) abase[i] = ((wave * TM + i) * p.isy) * g.PW + col * p.isx;
   const int ahalf = 16 * p.isx;
+  const float xscale = F16 ? p.f16_xscale : 1.f;
 
   // Global -> registers -> LDS in two steps: `fetch` issues every load of a channel pass back to back (one memory latency per
   // pass instead of one per loop trip) and `commit` writes them to LDS.  The next pass is fetched right before this pass's
@@ -244,6 +246,23 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams p, cons
           }
         }
       }
+      if constexpr (F16) {  // a lane group's quad (4 channels of a tap) is one fp16 operand of the K = 8 / K = 16 MFMA
+        const halfx4 bh = halfx4{(_Float16)b.x, (_Float16)b.y, (_Float16)b.z, (_Float16)b.w};
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          if constexpr (NW == 32) {
+            const halfx4 ah = halfx4{(_Float16)(a[i].x * xscale), (_Float16)(a[i].y * xscale), (_Float16)(a[i].z * xscale), (_Float16)(a[i].w * xscale)};
+            acc[i].v = __builtin_amdgcn_mfma_f32_32x32x8f16(ah, bh, acc[i].v, 0, 0, 0);
+          } else {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const float4 av = a[2 * i + h];
+              const halfx4 ah = halfx4{(_Float16)(av.x * xscale), (_Float16)(av.y * xscale), (_Float16)(av.z * xscale), (_Float16)(av.w * xscale)};
+              acc[i].v[h] = __builtin_amdgcn_mfma_f32_16x16x16f16(ah, bh, acc[i].v[h], 0, 0, 0);
+            }
+          }
+        }
+      } else
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         if constexpr (NW == 32) {
@@ -266,7 +285,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams p, cons
       }
       // issue order pinned: this step's LDS reads first (they complete under the MFMAs), then the MFMAs
       __builtin_amdgcn_sched_group_barrier(0x100, NA + 2, 0);
-      __builtin_amdgcn_sched_group_barrier(0x008, 4 * NA, 0);
+      if constexpr (!F16) __builtin_amdgcn_sched_group_barrier(0x008, 4 * NA, 0);
       b = bn;
 #pragma unroll
       for (int i = 0; i < NA; ++i) a[i] = an[i];
@@ -274,6 +293,21 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams p, cons
     }
   }
 
+  if (F16 && xscale != 1.f) {
+    const float inv = 1.f / xscale;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      if constexpr (NW == 32) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i].v[r] *= inv;
+      } else {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i].v[h][r] *= inv;
+      }
+    }
+  }
   // ---- 4. epilogue --------------------------------------------------------------------------------------------------
   const int nn = n0 + col;
   if (nn >= p.Cout) return;
@@ -371,7 +405,24 @@ int launch_conv_tile(const ConvParams& p, int th, hipStream_t stream) {
   const int ncls = p.ncls > 1 ? p.ncls : 1;
   const bool n16 = p.Cout <= 16;
   dim3 grid(tiles, n16 ? 1 : (p.Cout + 31) / 32, ncls);
-  UDET_LAUNCH(K[th == 4][n16][big], grid, dim3(256), lds, stream, p, g);
+  if (p.f16) {
+    static const Kern K16[2][2][2] = {
+        {{conv_tile_kernel<8, 32, TILE_MT_SMALL, TILE_MW_SMALL, true>, conv_tile_kernel<8, 32, TILE_MT_BIG, TILE_MW_BIG, true>},
+         {conv_tile_kernel<8, 16, TILE_MT_SMALL, TILE_MW_SMALL, true>, conv_tile_kernel<8, 16, TILE_MT_BIG, TILE_MW_BIG, true>}},
+        {{conv_tile_kernel<4, 32, TILE_MT_SMALL, TILE_MW_SMALL, true>, conv_tile_kernel<4, 32, TILE_MT_BIG, TILE_MW_BIG, true>},
+         {conv_tile_kernel<4, 16, TILE_MT_SMALL, TILE_MW_SMALL, true>, conv_tile_kernel<4, 16, TILE_MT_BIG, TILE_MW_BIG, true>}}};
+    static bool attr16 = false;
+    if (!attr16) {
+      for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b)
+          for (int c = 0; c < 2; ++c)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(K16[a][b][c]), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+      attr16 = true;
+    }
+    UDET_LAUNCH(K16[th == 4][n16][big], grid, dim3(256), lds, stream, p, g);
+  } else {
+    UDET_LAUNCH(K[th == 4][n16][big], grid, dim3(256), lds, stream, p, g);
+  }
   UDET_HIP(hipGetLastError());
   return UDET_OK;
 }
