@@ -1295,10 +1295,11 @@ static int max_ksplit(const ConvParams& p) {  // capacity / minimum-work bound o
   return ks < 1 ? 1 : ks;
 }
 struct TileGeoms;
-size_t conv_tile_lds_bytes(const ConvParams& p, int th, TileGeoms* gout, bool* big);
-int launch_conv_tile(const ConvParams& p, int th, hipStream_t stream);
-static bool tile_ok(const ConvParams& p, int th) {
-  const size_t b = conv_tile_lds_bytes(p, th, nullptr, nullptr);
+size_t conv_tile_lds_bytes(const ConvParams& p, int th, int cbmax, TileGeoms* gout, bool* big);
+int launch_conv_tile(const ConvParams& p, int th, int cbmax, hipStream_t stream);
+static bool tile_ok(const ConvParams& p, int th, int cb = 32) {
+  if (cb == 16 && p.Kc <= 16) return false;  // (the same launch as cb = 32)
+  const size_t b = conv_tile_lds_bytes(p, th, cb, nullptr, nullptr);
   return b > 0 && b <= 96 * 1024 && p.Kc <= 256 && p.Cout <= 64;
 }
 static bool self_staging_tile(int bm, int bn) {  // tiles conv_igemm_dma4_kernel is instantiated for
@@ -1344,7 +1345,7 @@ static int run_cfg(ConvParams& p, const ConvCfg& c, hipStream_t stream) {
   if (c.ws == 3) {  // tile-resident direct convolution (conv_tile.hip); bm carries the tile height
     p.ksplit = 1;
     p.fold = 0;
-    return launch_conv_tile(p, c.bm, stream);
+    return launch_conv_tile(p, c.bm, c.bn == 16 ? 16 : 32, stream);  // bn carries the channels per pass
   }
   p.ksplit = c.ks > 1 ? c.ks : 1;
   p.fold = 0;
@@ -1544,9 +1545,10 @@ static ConvCfg tune_cfg(ConvParams& p, hipStream_t stream) {
     }
     b = a;
   }
-  for (int th : {8, 4}) {  // thin layers: tile-resident direct convolution
-    if (!tile_ok(p, th)) continue;  // (multiplies in fp16 too when asked to)
-    const ConvCfg d = {th, 32, 1, 3, 0};
+  for (int thcb : {8 * 64 + 32, 4 * 64 + 32, 8 * 64 + 16, 4 * 64 + 16}) {  // thin layers: tile-resident direct convolution (multiplies in fp16 too when asked to)
+    const int th = thcb >> 6, cb = thcb & 63;  // tile height x channels resident per pass
+    if (!tile_ok(p, th, cb)) continue;
+    const ConvCfg d = {th, cb, 1, 3, 0};
     const float ms = time_cfg(p, d, 3, stream);
     if (ms < a * 0.97f) {
       const float ms5 = time_cfg(p, d, 5, stream);
@@ -1654,8 +1656,8 @@ int launch_conv(ConvParams& p, hipStream_t stream) {
   }
   if ((c.ws == 2 || c.ws == 4 || c.ws == 5 || c.ws == 6) && !dma_ok(p)) c.ws = 1;
   if (c.ws == 6 && !self_staging_tile(c.bm, c.bn)) c.ws = 2;
-  if (g_force_ws == 3) { c.ws = 3; c.bm = (g_force_bm == 4) ? 4 : 8; }
-  if (c.ws == 3 && !tile_ok(p, c.bm)) { c = heuristic_cfg(p); }
+  if (g_force_ws == 3) { c.ws = 3; c.bm = (g_force_bm == 4) ? 4 : 8; c.bn = g_force_bn == 16 ? 16 : 32; }
+  if (c.ws == 3 && !tile_ok(p, c.bm, c.bn == 16 ? 16 : 32)) { c = heuristic_cfg(p); }
   g_last_cfg = (c.ws & 0xff) | ((c.bm & 0xfff) << 8) | ((c.ks & 0xff) << 20) | ((c.ks > 1 && c.fold && c.ws != 3 && p.tickets ? 1 : 0) << 28) |
                ((c.ks > 1 && c.tail > 0 ? 1 : 0) << 29);
   return run_cfg(p, c, stream);

@@ -36,6 +36,7 @@ struct TileGeom {
 };
 struct TileGeoms {
   TileGeom g[4];  // per output-parity class
+  int cb;         // channels resident per pass: 32, or 16 (half the LDS: one or two more workgroups per CU, twice the passes)
 };
 
 // NW = 32: v_mfma_f32_32x32x2_f32 (two lane halves share a K step); NW = 16: v_mfma_f32_16x16x4_f32 for <= 16 output channels
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams p, cons
   const int ooy = p.ncls > 1 ? (cls >> 1) : p.ooy, oox = p.ncls > 1 ? (cls & 1) : p.oox;
   const int PIX = g.PH * g.PW;
   const int PIXP = PIX | 1;                       // odd: the b128 stores of one pixel's channel quads spread over all banks
-  const int CB = p.Kc < 32 ? p.Kc : 32;           // channels resident per pass (deep layers walk Kc in blocks of 32)
+  const int CB = p.Kc < gs.cb ? p.Kc : gs.cb;     // channels resident per pass (deep layers walk Kc in blocks of 32 or 16)
   const int CQB = CB >> 2;
   float4* T4 = smem4;                             // [CQB][PIXP]
   float4* W4 = smem4 + (size_t)CQB * PIXP;        // [ntc*CQB + NG][NW]   (rows past the last quad: zeros)
@@ -348,12 +349,14 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams p, cons
 }
 
 // LDS bytes of the tile kernel for this launch at tile height th (0: not eligible); the maximum over the parity classes
-size_t conv_tile_lds_bytes(const ConvParams& p, int th, TileGeoms* gout, bool* big) {
+size_t conv_tile_lds_bytes(const ConvParams& p, int th, int cbmax, TileGeoms* gout, bool* big) {
   if (big) *big = false;
   if (p.ntaps < 1 || p.xa != nullptr || p.Kc % 4 != 0 || p.isy != p.isx || p.isy < 1 || p.isy > 2) return 0;
   const int ncls = p.ncls > 1 ? p.ncls : 1;
   if (ncls > 4) return 0;
-  const size_t cb = p.Kc < 32 ? p.Kc : 32;  // channels resident per pass
+  if (cbmax != 32 && cbmax != 16) return 0;
+  if (gout) gout->cb = cbmax;
+  const size_t cb = p.Kc < cbmax ? p.Kc : cbmax;  // channels resident per pass
   size_t worst = 0;
   for (int c = 0; c < ncls; ++c) {
     const int t0 = ncls > 1 ? p.cls_tap[c] : 0, t1 = ncls > 1 ? p.cls_tap[c + 1] : p.ntaps;
@@ -379,10 +382,10 @@ size_t conv_tile_lds_bytes(const ConvParams& p, int th, TileGeoms* gout, bool* b
   return worst;
 }
 
-int launch_conv_tile(const ConvParams& p, int th, hipStream_t stream) {
+int launch_conv_tile(const ConvParams& p, int th, int cbmax, hipStream_t stream) {
   TileGeoms g;
   bool big = false;
-  const size_t lds = conv_tile_lds_bytes(p, th, &g, &big);
+  const size_t lds = conv_tile_lds_bytes(p, th, cbmax, &g, &big);
   if (lds == 0 || lds > 96 * 1024 || (th != 8 && th != 4)) {
     set_error("conv_tile: launch not eligible");
     return UDET_ERR_UNSUPPORTED;
