@@ -416,17 +416,12 @@ int launch_warp_cost_volume(const float* c1, const float* c2, const float* flow,
   const int per = (tiles + xcds - 1) / xcds;
   const dim3 grid(per * 8);
   // 8x8 tiles stage 16-channel slices (29 KB of LDS: four workgroups per CU -- the 960 tiles of level 2 are one round, with
-  // 32-channel slices they were 1.25 rounds of three); the small levels' 4x4 tiles keep 32 channels per barrier pair
-  static const int qs_env = getenv("UDET_CV_QS") ? atoi(getenv("UDET_CV_QS")) : 0;
-  const int qs = qs_env ? qs_env : (T == 8 ? 4 : 8);
+  // 32-channel slices they were 1.25 rounds of three: 33 -> 28 us); the small levels' 4x4 tiles keep 32 channels per barrier pair
   if (T == 4)
     UDET_LAUNCH((warp_cost_volume_kernel<4, 8>), grid, dim3(256), 0, stream, c1, c2, flow, ldf, f_coff, flow_scale, out, ldo, corr_coff,
                        c1_coff, warped_dbg, N, H, W, C, xcds);
-  else if (qs == 4)
-    UDET_LAUNCH((warp_cost_volume_kernel<8, 4>), grid, dim3(256), 0, stream, c1, c2, flow, ldf, f_coff, flow_scale, out, ldo, corr_coff,
-                       c1_coff, warped_dbg, N, H, W, C, xcds);
   else
-    UDET_LAUNCH((warp_cost_volume_kernel<8, 8>), grid, dim3(256), 0, stream, c1, c2, flow, ldf, f_coff, flow_scale, out, ldo, corr_coff,
+    UDET_LAUNCH((warp_cost_volume_kernel<8, 4>), grid, dim3(256), 0, stream, c1, c2, flow, ldf, f_coff, flow_scale, out, ldo, corr_coff,
                        c1_coff, warped_dbg, N, H, W, C, xcds);
   UDET_HIP(hipGetLastError());
   return UDET_OK;
