@@ -20,6 +20,30 @@ def test_library_exports_every_declared_symbol():
     assert _ffi.lib.udet_version() >= 100
 
 
+def test_tune_cache_file_round_trip(tmp_path):
+    """udet_tune_save / udet_tune_load (host only): the text form of the autotuner's choices.  A line carries
+    `c <key> bm bn ks ws fold tail`; files of earlier builds (no tail column) still load; anything else is rejected."""
+    from unsupervised_detection_amd import _ffi
+    lib = _ffi.lib
+    lib.udet_tune_load.restype = ctypes.c_int
+    lib.udet_tune_save.restype = ctypes.c_int
+    lib.udet_tuned_shapes.restype = ctypes.c_int
+    f = tmp_path / "tune.txt"
+    f.write_text("udet-tune 1\nc 1111 64 64 4 2 0 256\nc 2222 128 128 1 4 0\nw 3333 1048604\nnot a line\n")
+    before = lib.udet_tuned_shapes()
+    assert lib.udet_tune_load(str(f).encode()) == 3
+    assert lib.udet_tuned_shapes() == before + 3
+    g = tmp_path / "out.txt"
+    assert lib.udet_tune_save(str(g).encode()) == 0
+    lines = g.read_text().splitlines()
+    assert lines[0] == "udet-tune 1"
+    assert "c 1111 64 64 4 2 0 256" in lines and "c 2222 128 128 1 4 0 0" in lines and "w 3333 1048604" in lines
+    bad = tmp_path / "bad.txt"
+    bad.write_text("something else\n")
+    assert lib.udet_tune_load(str(bad).encode()) < 0
+    assert lib.udet_tune_load(str(tmp_path / "missing.txt").encode()) < 0
+
+
 def test_param_tables_match_oracle():
     from oracle import oracle_torch as O
     from unsupervised_detection_amd import weights as W
