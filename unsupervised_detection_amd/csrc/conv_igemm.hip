@@ -1466,7 +1466,18 @@ static float time_cfg(ConvParams& p, const ConvCfg& c, int reps, hipStream_t str
   (void)hipEventElapsedTime(&ms, e0, e1);
   return ms / reps;
 }
+static ConvCfg tune_cfg_impl(ConvParams& p, hipStream_t stream);
 static ConvCfg tune_cfg(ConvParams& p, hipStream_t stream) {
+  // candidates are launched hundreds of times: an accumulating launch would grow its output with every repetition and the layers
+  // behind it would be tuned (and verified) on ever larger data -- beyond the fp16 range in fp16 mode.  Timed as plain stores (one
+  // read of the output less per element).
+  const int acc = p.accumulate;
+  p.accumulate = 0;
+  const ConvCfg c = tune_cfg_impl(p, stream);
+  p.accumulate = acc;
+  return c;
+}
+static ConvCfg tune_cfg_impl(ConvParams& p, hipStream_t stream) {
   const ConvCfg h = heuristic_cfg(p);
   std::vector<ConvCfg> cand;
   static const int TILES[6][2] = {{256, 32}, {128, 32}, {128, 64}, {64, 64}, {128, 96}, {128, 128}};
@@ -1606,6 +1617,10 @@ int conv_debug_f16_on() { return g_debug_f16; }
 int launch_conv(ConvParams& p, hipStream_t stream) {
   if (g_debug_f16) p.f16 = 1;
   if (p.f16 && !(p.f16_xscale > 0.f)) p.f16_xscale = 1.f;
+  // the tuning pass repeats every launch hundreds of times on random data, accumulating launches included: its "gradients" are far
+  // larger than real ones and would overflow fp16 under the 4096 scale (every candidate NaN, every shape rejected); the scale does
+  // not change a launch's duration
+  if (p.f16 && g_tuning) p.f16_xscale = 1.f;
   if (p.Kc % 4 != 0 || p.ldx % 4 != 0 || p.x_coff % 4 != 0 || p.ldw % 4 != 0) {
     set_error("conv: Kc=%d ldx=%d x_coff=%d ldw=%d violate the 4-float alignment contract", p.Kc, p.ldx, p.x_coff, p.ldw);
     return UDET_ERR_ALIGN;

@@ -544,6 +544,7 @@ static void wgrad_launch(const WgradParams& p, int m_tiles, int co_tiles, int ns
 int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream) {
   if (conv_debug_f16_on()) p.f16 = 1;
   if (p.f16 && !(p.f16_yscale > 0.f)) p.f16_yscale = 1.f;
+  if (p.f16 && g_wtuning) p.f16_yscale = 1.f;  // (tuning data: see launch_conv)
   if (p.ldx % 4 || p.x_coff % 4 || p.ldy % 4 || p.y_coff % 4) {
     set_error("wgrad: ldx=%d x_coff=%d ldy=%d y_coff=%d must be multiples of 4", p.ldx, p.x_coff, p.ldy, p.y_coff);
     return UDET_ERR_ALIGN;
