@@ -60,6 +60,30 @@ def test_inference_dict_contract(gpu, monkeypatch):
     assert out["outs"]["pred_masks"][0.9].shape == (64, 128, 1) and out["outs"]["img_1s"][1.0].shape == (64, 128, 3)
 
 
+def test_augmented_inference_pipelines_the_flow_of_the_next_pair(gpu, monkeypatch):
+    """inference() of the augmented graph prefetches PWC-Net for the NEXT pair while this pair's generator runs: same masks as the
+    plain forward of every pair, one result per pair, StopIteration exactly at the end of the data."""
+    from unsupervised_detection_amd import learner as Lr
+    monkeypatch.setattr(Lr, "_engine_config", lambda config, batch=None, in_hw=(128, 192): Lr.EngineConfig(
+        batch_size=batch or config.batch_size, in_height=128, in_width=192, img_height=config.img_height, img_width=config.img_width))
+    lr = Lr.AdversarialLearner()
+    lr.setup_inference(_cfg(data_source=_Src(1, 3)), aug_test=True)
+    outs = [lr.inference(None) for _ in range(3)]
+    with pytest.raises(StopIteration):
+        lr.inference(None)
+    with pytest.raises(StopIteration):
+        lr.inference(None)
+    assert [o["img_fname"] for o in outs] == [b"f0", b"f1", b"f2"]
+    e = lr.engine
+    for o, b in zip(outs, _Src(1, 3)):
+        i1 = torch.cat([lr._central_crop_resize(b["img1"], c) for c in lr.test_crops], 0)
+        i2 = torch.cat([lr._central_crop_resize(b["img2"], c) for c in lr.test_crops], 0)
+        e.forward(i1, i2, 0)
+        ref = e.buffer("mask").cpu().numpy()
+        for k, c in enumerate(lr.test_crops):
+            assert np.array_equal(o["outs"]["pred_masks"][c], ref[k])  # the same kernels on the same data
+
+
 class _SrcGt(_Src):
     """reader-style batches: annotation at the reader's resolution (here 128x192), image size of the graphs 64x128"""
 

@@ -314,15 +314,30 @@ class AdversarialLearner(object):
     def inference(self, sess=None):
         """Outputs a dictionary with the results of the required operations (:606-623).  `sess` is accepted and
         ignored.  Raises StopIteration at the end of the data (the reference raises tf.errors.OutOfRangeError)."""
-        batch = next(self.test_iterator)
         e = self.engine
         if self.aug_test:
+            # The frozen PWC-Net of the NEXT pair runs on the plan's prefetch lanes beside this pair's generator pass and the
+            # device -> host copies of its results (one pair of look-ahead on the iterator; same results as forward()).
+            def staged(b):
+                if b["img1"].shape[0] != 1:
+                    raise ValueError("the augmented test graph takes one frame pair per step (adversarial_learner.py:547)")
+                c1 = torch.cat([self._central_crop_resize(b["img1"], crop) for crop in self.test_crops], 0)
+                c2 = torch.cat([self._central_crop_resize(b["img2"], crop) for crop in self.test_crops], 0)
+                e.prefetch_flow(c1, c2)
+                return b
+            ahead = getattr(self, "_ahead", None)
+            if ahead is None:
+                if getattr(self, "_exhausted", False):
+                    raise StopIteration
+                ahead = staged(next(self.test_iterator))
+            batch = ahead
+            e.prefetch_consume()
+            try:
+                self._ahead = staged(next(self.test_iterator))
+            except StopIteration:
+                self._ahead, self._exhausted = None, True
+            e.forward_in_place(0)
             outs = {"pred_masks": {}, "gt_masks": {}, "img_1s": {}}
-            if batch["img1"].shape[0] != 1:
-                raise ValueError("the augmented test graph takes one frame pair per step (adversarial_learner.py:547)")
-            i1 = torch.cat([self._central_crop_resize(batch["img1"], crop) for crop in self.test_crops], 0)
-            i2 = torch.cat([self._central_crop_resize(batch["img2"], crop) for crop in self.test_crops], 0)
-            e.forward(i1, i2, 0)
             masks, images = e.buffer("mask").cpu().numpy(), e.buffer("image").cpu().numpy()
             gt = batch.get("gt_mask")  # seg_1s[crop]: central_cropping of the annotation (bilinear, :348), then nearest
             for k, crop in enumerate(self.test_crops):
@@ -331,6 +346,7 @@ class AdversarialLearner(object):
                 outs["gt_masks"][crop] = None if gt is None else \
                     self._resize_gt(self._central_crop_resize(gt, crop))[0].cpu().numpy()
             return {"outs": outs, "img_fname": batch["fname"][0]}
+        batch = next(self.test_iterator)
         batch, n = pad_batch(batch, e.cfg.batch_size)  # short last batch of a one-pass reader: only its valid rows are returned
         e.forward(batch["img1"], batch["img2"], 1)
         gt = self._resize_gt(batch.get("gt_mask"))
