@@ -282,6 +282,7 @@ class AdversarialLearner(object):
         4-crop graph (batch 1, generator only, :525-592)."""
         self.config = config
         self.aug_test = aug_test
+        self._ahead, self._exhausted = None, False  # inference() looks one batch ahead (PWC flow prefetch)
         # the augmented graph feeds ONE frame pair (batch 1, :547) through four central crops: here the crops are the batch of
         # one plan, so a frame costs one PWC-Net + generator pass at batch 4 instead of four passes at batch 1 (every op of
         # the path is per sample, so the masks are the same numbers)
@@ -346,9 +347,22 @@ class AdversarialLearner(object):
                 outs["gt_masks"][crop] = None if gt is None else \
                     self._resize_gt(self._central_crop_resize(gt, crop))[0].cpu().numpy()
             return {"outs": outs, "img_fname": batch["fname"][0]}
-        batch = next(self.test_iterator)
-        batch, n = pad_batch(batch, e.cfg.batch_size)  # short last batch of a one-pass reader: only its valid rows are returned
-        e.forward(batch["img1"], batch["img2"], 1)
+        def staged_batch(b):  # (same one-pair look-ahead as above)
+            b, nvalid = pad_batch(b, e.cfg.batch_size)  # short last batch of a one-pass reader: only its valid rows are returned
+            e.prefetch_flow(b["img1"], b["img2"])
+            return b, nvalid
+        ahead = getattr(self, "_ahead", None)
+        if ahead is None:
+            if getattr(self, "_exhausted", False):
+                raise StopIteration
+            ahead = staged_batch(next(self.test_iterator))
+        batch, n = ahead
+        e.prefetch_consume()
+        try:
+            self._ahead = staged_batch(next(self.test_iterator))
+        except StopIteration:
+            self._ahead, self._exhausted = None, True
+        e.forward_in_place(1)
         gt = self._resize_gt(batch.get("gt_mask"))
         return {"gen_masks": e.buffer("mask")[:n].cpu().numpy(), "pred_flow": e.buffer("pred")[:n].cpu().numpy(),
                 "input_image": e.buffer("image")[:n].cpu().numpy(), "gt_flow": e.buffer("flow")[:n].cpu().numpy(),
