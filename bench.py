@@ -190,16 +190,21 @@ def main():
     eng = Engine(EngineConfig(batch_size=args.batch, conv_fp16=args.fp16_convs), device=f"cuda:{local_rank}")
     loaded = 0
     if args.tune_cache and os.path.exists(args.tune_cache):
-        loaded = int(lib.udet_tune_load(args.tune_cache.encode()))
+        loaded = max(0, int(lib.udet_tune_load(args.tune_cache.encode())))  # < 0: a file of another build -> tune again
     st = TrainState(eng, seed=8964, autotune=not (args.no_autotune or loaded > 0))  # identical weights on every rank; kernels autotuned once
     if args.tune_cache and not loaded and not args.no_autotune and rank == 0:
         lib.udet_tune_save(args.tune_cache.encode())
     w0 = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:  # the oracle leg starts from the same weights
         w0 = tuple(W.as_dict(t.cpu().clone(), n) for t, n in ((st.w_pwc, W.NET_PWC), (st.w_gen, W.NET_GEN), (st.w_rec, W.NET_REC)))
-    f1, f2 = data.synthetic_davis_pairs(args.batch, 8964 + rank)  # distinct data per rank (weak scaling)
-    img1 = data.preprocess_image(torch.from_numpy(f1).cuda())
-    img2 = data.preprocess_image(torch.from_numpy(f2).cuda())
+    # NPAIRS distinct resident batches per rank, visited round-robin (distinct data per rank: weak scaling); batch 0 is the one
+    # the parity check and the CPU-oracle leg use
+    NPAIRS = 4
+    batches = []
+    for i in range(NPAIRS):
+        f1, f2 = data.synthetic_davis_pairs(args.batch, 8964 + rank + 1000 * i)
+        batches.append((data.preprocess_image(torch.from_numpy(f1).cuda()), data.preprocess_image(torch.from_numpy(f2).cuda())))
+    img1, img2 = batches[0]
 
     # every launch of the step goes to one explicitly created stream (not the legacy null stream, whose implicit
     # synchronisation with blocking streams would serialise the plan's side streams on some runtimes)
@@ -227,20 +232,35 @@ def main():
     # cross-step pipelining (trainer.train_step): every step enqueues the frozen PWC-Net's flow of the NEXT pair beside
     # its own backward pass.  The pipeline is primed before the timed region (>= 1 warm-up step or an explicit prefetch),
     # so the K timed steps contain exactly K PWC forwards, K generator/recover forwards, K x both backward, K x 2 applies.
-    nxt = None if args.no_pipeline else (img1, img2)
-    if nxt is not None and args.warmup == 0:
+    pipelined = not args.no_pipeline
+    nxt = (img1, img2) if pipelined else None  # (the later, single-batch measurements keep re-using batch 0)
+    kstep = [0]  # running step index: step k trains on batches[k % NPAIRS] and prefetches batches[(k + 1) % NPAIRS]
+
+    def run_step(which=BOTH, group=None):
+        a, b = batches[kstep[0] % NPAIRS]
+        n = batches[(kstep[0] + 1) % NPAIRS] if pipelined else None
+        kstep[0] += 1
+        train_step(st, a, b, which, group=group, next_pair=n)
+    if pipelined and args.warmup == 0:
         eng.prefetch_flow(img1, img2)
         st._prefetched = (img1, img2)
     stage("plan built, weights packed, autotuned")
     for _ in range(args.warmup):
-        train_step(st, img1, img2, BOTH, next_pair=nxt)
+        run_step()
     barrier()
     stage("warm-up done")
+    # per-step completion events on the stream every launch of the step is issued from (the plan's side streams are joined to
+    # it before the optimizer applies): step k's duration = event k - event k-1 -> the distribution behind the mean
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        train_step(st, img1, img2, BOTH, next_pair=nxt)
+    marks[0].record()
+    for k in range(args.steps):
+        run_step()
+        marks[k + 1].record()
     barrier()
     dt = time.perf_counter() - t0
+    step_ms = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
+    pct = lambda q: step_ms[min(len(step_ms) - 1, int(round(q * (len(step_ms) - 1))))] if step_ms else None
     tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -261,6 +281,23 @@ def main():
         ar = torch.tensor([(time.perf_counter() - t0) / 10 * 1e3], device="cuda", dtype=torch.float64)
         dist.all_reduce(ar, op=dist.ReduceOp.MAX)
         allreduce_ms = round(float(ar.item()), 4)
+    # how much of that the step hides: the same K steps WITHOUT the exchange (group=False; the replicas drift apart from here on,
+    # nothing below depends on them agreeing).  exposed = what the exchange adds to a step; hidden = the rest of its stand-alone time
+    exchange = None
+    if world > 1:
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            run_step(group=False)
+        barrier()
+        nx = torch.tensor([(time.perf_counter() - t0) / args.steps * 1e3], device="cuda", dtype=torch.float64)
+        dist.all_reduce(nx, op=dist.ReduceOp.MAX)
+        ms_noex = float(nx.item())
+        exposed = max(0.0, ms - ms_noex)
+        exchange = {"ms_per_step_without_exchange": round(ms_noex, 3), "exchange_exposed_ms": round(exposed, 4),
+                    "overlap_hidden_ms": round(max(0.0, allreduce_ms - exposed), 4),
+                    "how": "recover gradients reduced on a communication stream behind udet_stream_wait_grads (under the rest of the "
+                           "generator-loss pass), generator gradients after the backward; hidden = allreduce_ms - exposed"}
 
     # the reference's own schedule (adversarial_learner.py:383-398 with iter_gen=3 / iter_rec=1): a 4-step cycle
     # = 16 pairs, 4 forwards, 1 recover-loss backward, 3 generator-loss backwards.  Reported beside the headline number.
@@ -269,12 +306,12 @@ def main():
         from unsupervised_detection_amd.engine import GEN, REC
         order = (REC, GEN, GEN, GEN)
         for w in order:  # one untimed cycle: the single-backward paths' first launches
-            train_step(st, img1, img2, w, next_pair=nxt)
+            run_step(w)
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.cycles):
             for w in order:
-                train_step(st, img1, img2, w, next_pair=nxt)
+                run_step(w)
         barrier()
         dc = torch.tensor([time.perf_counter() - t0], device="cuda", dtype=torch.float64)
         if world > 1:
@@ -292,7 +329,7 @@ def main():
         if rank == 0:
             print(json.dumps({"metric": "frame-pairs/sec per adversarial step, DAVIS 480p batch4, 1/2/4/8 GPU", "value": round(pairs_per_s, 3),
                               "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-                              "trace_only": True, "tuned_configurations_loaded": loaded}), flush=True)
+                              "ms_per_step_median": round(pct(0.5), 3), "trace_only": True, "tuned_configurations_loaded": loaded}), flush=True)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -316,6 +353,7 @@ def main():
         os.remove(dump)
     os.environ["UDET_PROF_DUMP"] = dump
     stage("reference schedule done; profiling pass")
+    st._prefetched = None
     prof = eng.profile(lambda: train_step(st, img1, img2, BOTH))
     stage("profiling pass done")
     os.environ.pop("UDET_PROF_DUMP", None)
@@ -362,6 +400,10 @@ def main():
                               "kernel execution time rocprofv3 --kernel-trace reports)",
                     "achieved": round(achieved, 2), "peak": peak_tf, "unit": "TFLOP/s",
                     "frac": round(achieved / peak_tf, 4),
+                    # the same executed GFLOP over the TIMED step (kernels of several lanes overlap there): what fraction of the
+                    # chip's matrix peak the headline region itself sustains
+                    "frac_step": round(exe_flops / (ms * 1e-3) / 1e12 / peak_tf, 4),
+                    "frac_step_algorithmic": round(alg_flops / (ms * 1e-3) / 1e12 / peak_tf, 4),
                     "numerator": "executed GFLOP of the launches (recover encoder A once instead of three times; the generator's NN x2 + 3x3 "
                                  "layers as four 2x2 convolutions: 16 of 36 tap products) -- `achieved_algorithmic` / `frac_algorithmic` divide "
                                  "the reference graph's 871.78 GFLOP by the same time",
@@ -393,7 +435,12 @@ def main():
         out = {
             "metric": "frame-pairs/sec per adversarial step, DAVIS 480p batch4, 1/2/4/8 GPU",
             "value": round(pairs_per_s, 3), "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms, 3),
+            # SURVEY 8d protocol: per-step times from HIP events on the launch stream over the same K timed steps
+            "ms_per_step_median": round(pct(0.5), 3), "ms_per_step_p95": round(pct(0.95), 3), "ms_per_step_min": round(step_ms[0], 3),
+            "ms_per_step_max": round(step_ms[-1], 3), "value_at_median": round(args.batch * world / (pct(0.5) * 1e-3), 3),
+            "resident_batches": NPAIRS,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16 x f16 -> f32 in the convolution MFMAs (fp32 tensors, losses, reductions, optimizer)" if args.fp16_convs else "f32",
             "data": "synthetic (DAVIS-480p-shaped pairs, reader preprocessing applied before timing; random-init weights)",
             "config": {"workload": ("BASELINE.json configs[4]: SegTrackV2-shaped pairs -> 384x640 (PWC) -> 192x384, batch %d/GPU, fp16 convs with "
@@ -410,7 +457,7 @@ def main():
                           "tune_rejected": int(lib.udet_tune_rejected()), "pipelined": nxt is not None,
                           "note": "step = forward(prefetched PWC flow) + PWC flow of the next pair beside both backward passes "
                                   "+ 2 applies; every timed step contains all of that work exactly once"},
-            "allreduce_ms": allreduce_ms,
+            "allreduce_ms": allreduce_ms, "gradient_exchange": exchange,
             "reference_schedule": ref_cycle,
             "ensemble": ensemble,
             "losses": {k: round(v, 5) for k, v in losses.items()},

@@ -26,6 +26,7 @@ extern "C" {
 #define UDET_ERR_HIP (-3)
 #define UDET_ERR_UNSUPPORTED (-4)
 #define UDET_ERR_ARG (-5)
+#define UDET_ERR_OVERFLOW (-6) /* conv_fp16 mode: an optimizer update was dropped because its gradients were not finite */
 
 #define UDET_ACT_NONE 0
 #define UDET_ACT_LEAKY 1
@@ -180,7 +181,12 @@ typedef struct {
   int conv_fp16;             /* 0 (default): fp32 MFMA, the reference's arithmetic.  1: BASELINE.json configs[4] -- the convolution
                               * GEMMs (forward, backward-data, backward-filter) multiply in fp16 with fp32 accumulation
                               * (v_mfma_f32_32x32x8_f16; gradient operands scaled by 4096 against underflow); tensors, losses,
-                              * reductions and the optimizer stay fp32.  Not a reference capability: parity tolerance 2e-2. */
+                              * reductions and the optimizer stay fp32.  Not a reference capability: parity tolerance 2e-2.
+                              * Overflow guard: a gradient operand beyond 16 (65504 / 4096) becomes inf in fp16 and reaches the
+                              * flat gradient buffer as inf / NaN; udet_apply counts the non-finite gradient values on the
+                              * device and DROPS the update when there are any (weights / Adam slots untouched); the next call
+                              * on the plan that finds the count returns UDET_ERR_OVERFLOW once (udet_fp16_overflow_count
+                              * synchronises and returns the number of dropped updates). */
 } udet_config;
 
 int udet_plan_create(const udet_config* cfg, udet_plan** out);
@@ -248,6 +254,9 @@ int udet_grad_absmean(udet_plan* plan, int net, const float* g, float* out2, voi
 /* the rest of train_op (loss_utils.py:19-32): clip +-0.2 / escape noise (generator only), Adam apply with the
  * shared beta-power accumulators; g is overwritten with the clipped gradient. */
 int udet_apply(udet_plan* plan, int net, float* w, float* g, float* m, float* v, void* workspace, void* stream);
+/* conv_fp16 plans: synchronises the pending overflow reports and returns how many optimizer updates were dropped so far because
+ * their gradients held non-finite values (0 for fp32 plans); never an error by itself */
+long udet_fp16_overflow_count(udet_plan* plan);
 long udet_get_adam_step(const udet_plan* plan);
 void udet_set_adam_step(udet_plan* plan, long t);
 /* pack + forward + backward + apply for `which` on one GPU (no gradient exchange) */
@@ -268,9 +277,13 @@ int udet_autotune(udet_plan* plan, const float* w_gen, const float* w_rec, float
 int udet_tuned_shapes(void);
 /* The tuned configurations as a text file (keys are hashes of the problem shapes): a later process loads them instead of
  * tuning again, e.g. a rocprofv3 trace that should contain timed steps only.  udet_tune_load returns the number of entries
- * read (>= 0) or an error code; entries are trusted (they were verified when they were tuned). */
+ * read (>= 0) or an error code.  The header line carries the build's tuning ABI: a file of another build is rejected.  Loaded
+ * entries are not trusted blindly: at launch time a cached configuration is used only if its tile / kernel family is
+ * instantiated, its split count is clamped to the launch's capacity, and anything else falls back to the built-in choice. */
 int udet_tune_save(const char* path);
 int udet_tune_load(const char* path);
+/* autotuner winners rejected because their output differed from the built-in configuration's (0 on a healthy build) */
+int udet_tune_rejected(void);
 /* Measurement aid (bench.py): between begin/end every convolution / warp-cost-volume launch group is timed on the launch
  * stream.  out[cat*5 + {0..4}] = {groups, kernel ms, algorithmic FLOPs, algorithmic bytes, bracket ms} for cat 0 conv fwd,
  * 1 conv dgrad, 2 conv wgrad, 3 (unused), 4 warp + cost volume.  "kernel ms" sums the kernels' own start -> stop times (event
@@ -278,6 +291,17 @@ int udet_tune_load(const char* path);
  * each group, which additionally contains the event packets and dispatch gaps. */
 int udet_profile_begin(udet_plan* plan);
 int udet_profile_end(udet_plan* plan, double* out, int ncat, void* stream);
+
+/* Concurrency switch.  A plan runs independent chains of a step on its own side streams, forked from / joined to the caller's
+ * stream with events.  on = 0 collapses every lane onto the caller's stream: the plain program order, results
+ * bit-identical (tests/test_autotune_gpu.py), used for serial kernel traces.  Takes effect from the next call on the plan.
+ *
+ * Environment variables the library reads -- all diagnostic, none on a launch path, none changes a result:
+ *   UDET_SERIAL=1      read once by udet_plan_create: the plan starts with udet_plan_set_concurrent(plan, 0);
+ *   UDET_TUNE_LOG=1    read by the autotuner (udet_autotune): one stderr line per tuned problem shape;
+ *   UDET_PROF_DUMP=F   read by udet_profile_end: appends one CSV line per launch group of the measurement pass to F.
+ * Kernel-selection forcing for tests lives in a separate library (include/udet_debug.h, libudet_debug.so). */
+int udet_plan_set_concurrent(udet_plan* plan, int on);
 
 #ifdef __cplusplus
 }

@@ -1,5 +1,6 @@
-/* Test-only hooks of libudet.so (NOT part of the drop-in surface in udet.h): used by tools/conv_bench.py and the
- * kernel-family tests to pin one convolution kernel family / tile / split-K mode and to ask which one ran. */
+/* Test-only hooks (NOT part of the drop-in surface in udet.h, NOT exported by libudet.so): they live in libudet_debug.so, a
+ * small library that links against libudet.so; tools/conv_bench.py and the kernel-family tests load it
+ * (unsupervised_detection_amd/_devel.py) to pin one convolution kernel family / tile / split-K mode and to ask which one ran. */
 #ifndef UDET_DEBUG_H
 #define UDET_DEBUG_H
 #ifdef __cplusplus
@@ -20,8 +21,6 @@ void udet_debug_set_tuning(int on);
 /* what the most recent convolution launch actually ran: family (0 plain, 1 wave-specialised, 2 LDS-DMA, 3 tile-resident,
  * 6 self-staging LDS-DMA) | tile rows << 8 | split count << 20 | folded split-K << 28 */
 int udet_debug_last_conv(void);
-/* autotuner winners rejected because their output differed from the reference configuration's (0 on a healthy build) */
-int udet_tune_rejected(void);
 #ifdef __cplusplus
 }
 #endif

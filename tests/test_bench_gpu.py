@@ -28,3 +28,9 @@ def test_two_ranks_complete_and_report_once():
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and out["config"]["global_batch"] == 8
     assert out["value"] > 0 and out["roofline"]["frac"] > 0 and out["reference_schedule"]["cycles"] == 1
     assert out["allreduce_ms"] is not None and out["allreduce_ms"] > 0 and out["parity_check"] is None
+    # the exchange runs the same stream / event choreography as an RCCL run (trainer._exchange_gradients) and reports what the
+    # overlap hides; per-step distribution and the timed-region roofline fraction are part of the line
+    ex = out["gradient_exchange"]
+    assert ex is not None and ex["ms_per_step_without_exchange"] > 0 and ex["overlap_hidden_ms"] >= 0
+    assert out["ms_per_step_median"] > 0 and out["ms_per_step_p95"] >= out["ms_per_step_median"] and out["resident_batches"] >= 4
+    assert out["roofline"]["frac_step"] > 0

@@ -206,3 +206,43 @@ def test_augmented_test_graph_at_full_resolution(env):
     e4.forward(c1, c2, 0)
     torch.cuda.synchronize()
     assert float((e4.buffer("mask").cpu() - torch.cat(masks_b1, 0)).abs().max()) < 1e-4
+
+
+def test_stream_wait_grads_hands_over_the_recover_gradients_early(env):
+    """udet_stream_wait_grads (trainer._exchange_gradients): with which = 3 a communication stream that waits only for
+    the RECOVER gradients' completion event may read g_rec while the longer generator-loss pass is still running.  One process,
+    no collective: a side stream waits on the event and clones g_rec;
+      (a) the clone equals g_rec after a full synchronisation (the event really marks the final buffer),
+      (b) the side stream's work is done BEFORE the whole backward is (timestamps on the two streams): the overlap window the
+          RCCL exchange uses exists at the benchmark's shape,
+      (c) waiting for the generator event instead yields the final g_gen."""
+    eng, W, lib, flat = env["eng"], env["W"], env["lib"], env["flat"]
+    from unsupervised_detection_amd._ffi import check
+    eng.forward(env["img1"].cuda(), env["img2"].cuda(), 3)
+    g_gen, g_rec = torch.zeros_like(flat["gen"]), torch.zeros_like(flat["rec"])
+    side_r, side_g = torch.cuda.Stream(), torch.cuda.Stream()
+    for _ in range(2):  # (the first round also warms the allocator of the side streams)
+        g_gen.zero_()
+        g_rec.zero_()
+        torch.cuda.synchronize()
+        t0, t_main, t_side = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        t0.record()
+        eng.backward(3, flat["gen"], flat["rec"], g_gen, g_rec)
+        t_main.record()  # the caller's stream has joined BOTH passes here
+        check(lib.udet_stream_wait_grads(eng._h, W.NET_REC, side_r.cuda_stream))
+        with torch.cuda.stream(side_r):
+            early = g_rec.clone()
+            t_side.record(side_r)
+        check(lib.udet_stream_wait_grads(eng._h, W.NET_GEN, side_g.cuda_stream))
+        with torch.cuda.stream(side_g):
+            gen_copy = g_gen.clone()
+        torch.cuda.synchronize()
+    assert float(g_rec.abs().max()) > 0 and torch.equal(early, g_rec)
+    assert torch.equal(gen_copy, g_gen)
+    ms_side, ms_main = t0.elapsed_time(t_side), t0.elapsed_time(t_main)
+    print("recover gradients final (and cloned) after %.2f ms, whole backward after %.2f ms" % (ms_side, ms_main))
+    assert ms_side < ms_main, (ms_side, ms_main)
+    _check_grads(W, W.NET_REC, early, env["ref"]["grads"]["rec"])
+    # an unknown net / no backward yet is an argument error, not a hang
+    with pytest.raises(ValueError):
+        check(lib.udet_stream_wait_grads(eng._h, 0, side_r.cuda_stream))

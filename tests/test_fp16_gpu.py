@@ -13,7 +13,9 @@ pytestmark = pytest.mark.gpu
 from oracle import oracle_torch as O  # noqa: E402
 
 TOL = 2e-2
-GRAD_TOL = 5e-2  # parameter gradients pass through up to ~30 fp16 GEMMs (forward and backward chains)
+# Parameter gradients pass through up to ~30 fp16 GEMMs (forward and backward chains).  Per-network bounds tied to what this
+# plan measures (worst tensor, relative to its scale): generator 3.0e-2 (17 layers + the recover net behind it), recover 1.2e-2.
+GRAD_TOL = {1: 4e-2, 2: 2e-2}
 
 
 def rnd(*shape, seed=0, scale=1.0):
@@ -26,10 +28,7 @@ def fp16_ops():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from unsupervised_detection_amd import ops
-    from unsupervised_detection_amd._ffi import lib
-    lib.udet_debug_conv_fp16.restype = None
-    lib.udet_debug_conv_fp16.argtypes = [ctypes.c_int]
-    lib.udet_debug_last_conv.restype = ctypes.c_int
+    from unsupervised_detection_amd._devel import dbg as lib  # libudet_debug.so: the test-only hooks
     lib.udet_debug_conv_fp16(1)
     yield ops, lib
     lib.udet_debug_conv_fp16(0)
@@ -42,8 +41,6 @@ def rel(a, ref):
 def test_tile_resident_kernel_in_fp16(fp16_ops):
     """The tile-resident family (32- and 16-wide MFMA tiles) with fp16 multiplication, forced."""
     ops, lib = fp16_ops
-    lib.udet_debug_force_conv.restype = None
-    lib.udet_debug_force_conv.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
     try:
         for (n, h, w, cin, cout, k), th in (((1, 32, 64, 32, 32, 3), 8), ((1, 32, 64, 104, 16, 4), 4), ((2, 16, 64, 16, 16, 3), 8)):
             x = rnd(n, h, w, cin, seed=31)
@@ -151,6 +148,47 @@ def test_step_plan_in_fp16():
         for k, v in refg.items():
             err = float((d[k].double() - v).abs().max())
             worst = max(worst, err / max(float(v.abs().max()), 1e-2 * scale))
-            assert err < GRAD_TOL * max(float(v.abs().max()), 1e-2 * scale), (k, err, float(v.abs().max()))
+            assert err < GRAD_TOL[net] * max(float(v.abs().max()), 1e-2 * scale), (k, err, float(v.abs().max()))
         print("fp16 step plan: worst parameter-gradient error of net %d, relative to the tensor's scale: %.2e" % (net, worst))
     assert torch.isfinite(g_gen).all() and torch.isfinite(g_rec).all()
+
+
+def test_fp16_overflow_is_detected_and_the_update_dropped():
+    """The static 4096 gradient scale assumes |dU| < 16 (65504 / 4096).  Weights blown up so that the gradients leave that range
+    must not corrupt the model silently: the optimizer update is dropped on the device (weights / Adam slots untouched), the
+    next call on the plan raises, and the counter says how many updates were dropped.  A healthy step reports nothing."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from unsupervised_detection_amd import weights as W
+    from unsupervised_detection_amd.engine import BOTH, Engine, EngineConfig
+    eng = Engine(EngineConfig(batch_size=1, in_height=128, in_width=192, img_height=64, img_width=128, conv_fp16=True))
+    pp, pg, pr = _perturbed(O.pwc_param_specs(), 11), _perturbed(O.generator_param_specs(), 12), _perturbed(O.recover_param_specs(), 13)
+    w = {n: W.from_dict(p, n).cuda() for n, p in ((W.NET_PWC, pp), (W.NET_GEN, pg), (W.NET_REC, pr))}
+    eng.pack_pwc(w[W.NET_PWC])
+    g = torch.Generator().manual_seed(3)
+    i1 = (torch.rand(1, 128, 192, 3, generator=g) - 0.5).cuda()
+    i2 = (torch.rand(1, 128, 192, 3, generator=g) - 0.5).cuda()
+    bufs = {n: [torch.zeros_like(w[n]) for _ in range(3)] for n in (W.NET_GEN, W.NET_REC)}
+
+    def step():
+        eng.train_step(BOTH, i1, i2, w[W.NET_GEN], w[W.NET_REC], bufs[W.NET_GEN][0], bufs[W.NET_REC][0], bufs[W.NET_GEN][1],
+                       bufs[W.NET_GEN][2], bufs[W.NET_REC][1], bufs[W.NET_REC][2])
+    step()
+    torch.cuda.synchronize()
+    assert eng.fp16_overflow_count() == 0  # a healthy step: nothing dropped, finite gradients
+    assert torch.isfinite(bufs[W.NET_REC][0]).all() and torch.isfinite(bufs[W.NET_GEN][0]).all()
+    # blow the recover decoder up: activations (and with them dU) far beyond 16
+    tab = {n: (o, int(torch.tensor(s).prod())) for n, s, o in W.param_table(W.NET_REC)}
+    for name in ("FlownetS/deconv2/weights", "FlownetS/deconv1/weights", "FlownetS/flow1/weights"):
+        o, c = tab[name]
+        w[W.NET_REC][o:o + c] *= 3.0e3
+    before = w[W.NET_REC].clone()
+    m_before = bufs[W.NET_REC][1].clone()
+    step()
+    torch.cuda.synchronize()
+    assert not torch.isfinite(bufs[W.NET_REC][0]).all()          # the overflow reached the flat gradient buffer ...
+    assert torch.equal(w[W.NET_REC], before) and torch.equal(bufs[W.NET_REC][1], m_before)  # ... and the update was dropped
+    with pytest.raises(OverflowError):                           # the next call on the plan reports it (once)
+        eng.forward(i1, i2, 3)
+    assert eng.fp16_overflow_count() >= 1
+    eng.forward(i1, i2, 3)                                       # reported once: the plan keeps working

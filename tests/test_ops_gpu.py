@@ -196,12 +196,7 @@ def _tile_fits(th, cin, cout, k, s):
 
 @pytest.fixture
 def force_conv():
-    import ctypes
-    from unsupervised_detection_amd._ffi import lib
-    lib.udet_debug_force_conv.restype = None
-    lib.udet_debug_force_conv.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
-    lib.udet_debug_last_conv.restype = ctypes.c_int
-    lib.udet_debug_last_conv.argtypes = []
+    from unsupervised_detection_amd._devel import dbg as lib  # libudet_debug.so: the test-only hooks
     yield lib
     lib.udet_debug_force_conv(0, 0, -1)
 

@@ -11,36 +11,56 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_exports_every_declared_symbol():
     from unsupervised_detection_amd import _ffi
-    hdr = open(os.path.join(ROOT, "include", "udet.h")).read() + open(os.path.join(ROOT, "include", "udet_debug.h")).read()
-    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    names = set(re.findall(r"\b(udet_[a-z0-9_]+)\s*\(", hdr))
+    def declared(header):
+        hdr = open(os.path.join(ROOT, "include", header)).read()
+        hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+        return set(re.findall(r"\b(udet_[a-z0-9_]+)\s*\(", hdr))
+    names = declared("udet.h")
     assert len(names) >= 25
     for n in sorted(names):
         assert hasattr(_ffi.lib, n), f"libudet.so does not export {n}"
     assert _ffi.lib.udet_version() >= 100
+    # the test-only hooks are NOT in the product library: they live in libudet_debug.so (include/udet_debug.h)
+    from unsupervised_detection_amd import _devel
+    hooks = declared("udet_debug.h")
+    assert len(hooks) >= 4
+    for n in sorted(hooks):
+        assert hasattr(_devel.dbg, n), f"libudet_debug.so does not export {n}"
+        assert not hasattr(_ffi.lib, n), f"libudet.so must not export the test hook {n}"
 
 
 def test_tune_cache_file_round_trip(tmp_path):
     """udet_tune_save / udet_tune_load (host only): the text form of the autotuner's choices.  A line carries
-    `c <key> bm bn ks ws fold tail`; files of earlier builds (no tail column) still load; anything else is rejected."""
+    `c <key> bm bn ks ws fold tail`; the header names the build's tuning ABI and a file of another build (or anything else) is
+    rejected (a stale file must not feed configurations to a different kernel set)."""
     from unsupervised_detection_amd import _ffi
     lib = _ffi.lib
     lib.udet_tune_load.restype = ctypes.c_int
     lib.udet_tune_save.restype = ctypes.c_int
     lib.udet_tuned_shapes.restype = ctypes.c_int
     f = tmp_path / "tune.txt"
-    f.write_text("udet-tune 1\nc 1111 64 64 4 2 0 256\nc 2222 128 128 1 4 0\nw 3333 1048604\nnot a line\n")
+    g0 = tmp_path / "hdr.txt"
+    assert lib.udet_tune_save(str(g0).encode()) == 0
+    header = g0.read_text().splitlines()[0]
+    assert header.startswith("udet-tune 2 abi ")
+    f.write_text(header + "\nc 1111 64 64 4 2 0 256\nc 2222 128 128 1 4 0\nw 3333 1048604\nnot a line\n")
     before = lib.udet_tuned_shapes()
     assert lib.udet_tune_load(str(f).encode()) == 3
     assert lib.udet_tuned_shapes() == before + 3
     g = tmp_path / "out.txt"
     assert lib.udet_tune_save(str(g).encode()) == 0
     lines = g.read_text().splitlines()
-    assert lines[0] == "udet-tune 1"
+    assert lines[0] == header
     assert "c 1111 64 64 4 2 0 256" in lines and "c 2222 128 128 1 4 0 0" in lines and "w 3333 1048604" in lines
     bad = tmp_path / "bad.txt"
     bad.write_text("something else\n")
     assert lib.udet_tune_load(str(bad).encode()) < 0
+    old = tmp_path / "old.txt"
+    old.write_text("udet-tune 1\nc 1111 64 64 4 2 0 256\n")  # a file of an earlier build
+    assert lib.udet_tune_load(str(old).encode()) < 0
+    other = tmp_path / "other.txt"
+    other.write_text("udet-tune 2 abi 999999\nc 1111 64 64 4 2 0 256\n")
+    assert lib.udet_tune_load(str(other).encode()) < 0
     assert lib.udet_tune_load(str(tmp_path / "missing.txt").encode()) < 0
 
 

@@ -12,10 +12,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from unsupervised_detection_amd import ops  # noqa: E402
-from unsupervised_detection_amd._ffi import lib  # noqa: E402
-
-lib.udet_debug_force_conv.restype = None
-lib.udet_debug_force_conv.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
+from unsupervised_detection_amd._devel import dbg as lib  # noqa: E402  (libudet_debug.so: the test-only hooks)
 
 # name, n, h, w, cin, cout, k, stride, dil, up
 SHAPES = [

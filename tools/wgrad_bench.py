@@ -35,8 +35,8 @@ def main():
     a = ap.parse_args()
     g = torch.Generator().manual_seed(0)
     if os.environ.get("UDET_WGRAD_TUNE", "1") == "1":
-        lib.udet_debug_set_tuning.restype = None
-        lib.udet_debug_set_tuning(1)
+        from unsupervised_detection_amd._devel import dbg
+        dbg.udet_debug_set_tuning(1)
     for name, n, h, w, cin, cout, k, s in SHAPES:
         if a.only and a.only not in name:
             continue

@@ -1,0 +1,22 @@
+"""Loader of libudet_debug.so (include/udet_debug.h): TEST-ONLY hooks that pin a convolution kernel family / tile / split-K
+mode and report which one ran.  Used by tests/ and tools/ only -- nothing on the product path imports this module; the
+hooks are not exported by libudet.so."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+from ._ffi import lib as _lib  # libudet.so first: the debug library resolves its internal symbols against it  # noqa: F401
+
+_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libudet_debug.so")
+if not os.path.exists(_PATH):
+    raise RuntimeError(f"{_PATH} is missing: build it with `make -C unsupervised_detection_amd/csrc`")
+dbg = ctypes.CDLL(_PATH, mode=ctypes.RTLD_GLOBAL)
+dbg.udet_debug_force_conv.restype = None
+dbg.udet_debug_force_conv.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
+dbg.udet_debug_last_conv.restype = ctypes.c_int
+dbg.udet_debug_last_conv.argtypes = []
+dbg.udet_debug_conv_fp16.restype = None
+dbg.udet_debug_conv_fp16.argtypes = [ctypes.c_int]
+dbg.udet_debug_set_tuning.restype = None
+dbg.udet_debug_set_tuning.argtypes = [ctypes.c_int]

@@ -76,4 +76,6 @@ def check(status: int):
         msg = lib.udet_last_error().decode("utf-8", "replace")
         if status in (-1, -2, -5):
             raise ValueError(f"libudet error {status}: {msg}")
+        if status == -6:
+            raise OverflowError(f"libudet error {status}: {msg}")
         raise UdetError(f"libudet error {status}: {msg}")

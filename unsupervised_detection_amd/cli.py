@@ -28,9 +28,12 @@ def _sources(flags, mode):
     if not (root and os.path.isfile(os.path.join(root, "ImageSets", "480p", "val.txt"))):
         raise IOError("Partition file not found under --root_dir {!r} (DAVIS2016 layout: ImageSets/480p/val.txt)".format(root))
     import torch.distributed as dist
-    rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    ddp = dist.is_available() and dist.is_initialized()
+    rank, world = (dist.get_rank(), dist.get_world_size()) if ddp else (0, 1)
+    # data-parallel training: one shuffle shared by the ranks, each takes its own rows of every global batch (disjoint pairs;
+    # an epoch = the pair table once = num_samples_train / (batch_size * world) steps, see AdversarialLearner.train)
     rd = data.Davis2016Reader(root, max_temporal_len=flags.max_temporal_len, min_temporal_len=flags.min_temporal_len,
-                              num_threads=flags.num_threads, seed=8964 + rank)  # every rank draws its own pairs
+                              num_threads=flags.num_threads, seed=8964, shard=(rank, world))
     if mode == "train":
         flags.data_source = rd.image_inputs(batch_size=flags.batch_size, partition=flags.train_partition, train_crop=flags.train_crop)
 

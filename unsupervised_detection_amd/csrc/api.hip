@@ -4,7 +4,6 @@
 #include <string.h>
 
 #include "../../include/udet.h"
-#include "../../include/udet_debug.h"
 #include "common.h"
 #include "conv_host.h"
 #include "elementwise.h"
@@ -56,13 +55,6 @@ using namespace udet;
 extern "C" {
 
 int udet_version(void) { return 101; }
-int udet_debug_last_conv(void) { return conv_last_config(); }
-void udet_debug_force_conv(int bm, int bn, int ks) { conv_force_config(bm, bn, ks); }
-void udet_debug_conv_fp16(int on) { conv_debug_f16(on); }
-void udet_debug_set_tuning(int on) {
-  conv_set_tuning(on);
-  wgrad_set_tuning(on);
-}
 const char* udet_last_error(void) { return g_err; }
 
 int udet_warp(const float* image, const float* flow, float flow_scale, float* out, int n, int h, int w, int c,

@@ -50,6 +50,18 @@ int udet_buffer_info(const udet_plan* h, int i, const char** name, size_t* offse
   dims[0] = b.n; dims[1] = b.h; dims[2] = b.w; dims[3] = b.ld;
   return UDET_OK;
 }
+int udet_plan_set_concurrent(udet_plan* h, int on) {
+  if (!h) { set_error("plan_set_concurrent: null plan"); return UDET_ERR_ARG; }
+  if (on)
+    for (auto st : h->p->side)
+      if (!st) { set_error("plan_set_concurrent: the plan has no side streams"); return UDET_ERR_UNSUPPORTED; }
+  h->p->concurrent = on != 0;
+  return UDET_OK;
+}
+long udet_fp16_overflow_count(udet_plan* h) {
+  (void)plan_check_overflow(h->p, true);  // (the error text stays in udet_last_error; the count is the answer here)
+  return h->p->ovf_skipped;
+}
 long udet_get_adam_step(const udet_plan* h) { return h->p->adam_t; }
 void udet_set_adam_step(udet_plan* h, long t) { h->p->adam_t = t; }
 
@@ -63,6 +75,7 @@ int udet_pwc_forward(udet_plan* h, const float* img1, const float* img2, void* w
   return plan_pwc_forward(h->p, img1, img2, (float*)ws, (hipStream_t)stream);
 }
 int udet_forward_from_flow(udet_plan* h, int ncalls, void* ws, void* stream) {
+  UDET_TRY(plan_check_overflow(h->p, false));  // conv_fp16: report an update the previous step had to drop
   if (ncalls < 0 || ncalls > 3) { set_error("forward: ncalls must be 0..3"); return UDET_ERR_ARG; }
   return plan_forward(h->p, nullptr, nullptr, ncalls, (float*)ws, (hipStream_t)stream);
 }
@@ -80,6 +93,7 @@ int udet_recover_forward(udet_plan* h, int n, void* ws, void* stream) {
   return plan_recover_forward(h->p, n, (float*)ws, (hipStream_t)stream, true);
 }
 int udet_forward(udet_plan* h, const float* img1, const float* img2, int ncalls, void* ws, void* stream) {
+  UDET_TRY(plan_check_overflow(h->p, false));  // conv_fp16: report an update the previous step had to drop
   if (ncalls < 0 || ncalls > 3) { set_error("forward: ncalls must be 0..3"); return UDET_ERR_ARG; }
   if (!img1 || !img2) { set_error("forward: null image pointer"); return UDET_ERR_ARG; }
   return plan_forward(h->p, img1, img2, ncalls, (float*)ws, (hipStream_t)stream);
@@ -92,11 +106,13 @@ int udet_prefetch_consume(udet_plan* h, void* ws, void* stream) {
   return plan_prefetch_consume(h->p, (float*)ws, (hipStream_t)stream);
 }
 int udet_forward_prefetched(udet_plan* h, int ncalls, void* ws, void* stream) {
+  UDET_TRY(plan_check_overflow(h->p, false));  // conv_fp16: report an update the previous step had to drop
   if (ncalls < 0 || ncalls > 3) { set_error("forward: ncalls must be 0..3"); return UDET_ERR_ARG; }
   return plan_forward(h->p, nullptr, nullptr, ncalls, (float*)ws, (hipStream_t)stream, true);
 }
 int udet_backward(udet_plan* h, int which, const float* w_gen, const float* w_rec, float* g_gen, float* g_rec, void* ws,
                   void* stream) {
+  UDET_TRY(plan_check_overflow(h->p, false));  // conv_fp16: report an update the previous step had to drop
   if (which < 1 || which > 3) { set_error("backward: which must be 1 (generator), 2 (recover) or 3 (both)"); return UDET_ERR_ARG; }
   return plan_backward(h->p, which, w_gen, w_rec, g_gen, g_rec, (float*)ws, (hipStream_t)stream);
 }
@@ -144,7 +160,7 @@ int udet_tuned_shapes(void) { return conv_tuned_shapes() + wgrad_tuned_shapes();
 int udet_tune_save(const char* path) {
   FILE* f = path ? fopen(path, "w") : nullptr;
   if (!f) { set_error("tune_save: cannot open %s", path ? path : "(null)"); return UDET_ERR_ARG; }
-  fprintf(f, "udet-tune 1\n");
+  fprintf(f, "udet-tune 2 abi %d\n", UDET_TUNE_ABI);
   conv_tune_dump(f);
   wgrad_tune_dump(f);
   fclose(f);
@@ -154,10 +170,11 @@ int udet_tune_load(const char* path) {
   FILE* f = path ? fopen(path, "r") : nullptr;
   if (!f) { set_error("tune_load: cannot open %s", path ? path : "(null)"); return UDET_ERR_ARG; }
   char line[256];
-  int n = 0, ver = 0;
-  if (!fgets(line, sizeof(line), f) || sscanf(line, "udet-tune %d", &ver) != 1 || ver != 1) {
+  int n = 0, ver = 0, abi = -1;
+  // the header names the build's tuning ABI: keys and configuration codes of another build mean something else
+  if (!fgets(line, sizeof(line), f) || sscanf(line, "udet-tune %d abi %d", &ver, &abi) != 2 || ver != 2 || abi != UDET_TUNE_ABI) {
     fclose(f);
-    set_error("tune_load: %s is not a udet-tune 1 file", path);
+    set_error("tune_load: %s is not a udet-tune 2 file of this build (abi %d)", path, UDET_TUNE_ABI);
     return UDET_ERR_ARG;
   }
   while (fgets(line, sizeof(line), f)) {

@@ -21,6 +21,8 @@ int wgrad_tuned_shapes();
 void conv_tune_dump(FILE* f);
 void conv_tune_put(unsigned long long key, int bm, int bn, int ks, int ws, int fold, int tail);
 void wgrad_tune_dump(FILE* f);
+// bumped whenever a kernel family, a tile set or a problem key changes: tuning files of another build are rejected (udet_tune_load)
+#define UDET_TUNE_ABI 3
 void wgrad_tune_put(unsigned long long key, int cfg);  // debugging / tuning hook: bm == 0 and ks < 0 restore the heuristics
 bool conv_setup_dgrad(ConvParams& p, int cls, int N, int H, int W, int kh, int kw, int s, int d);
 int launch_pack_weights(const float* src, float* dst, int T, int R, int C, int Kc, int ldw, int k_split, int k_gap,

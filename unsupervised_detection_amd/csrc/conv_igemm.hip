@@ -1652,6 +1652,23 @@ int launch_conv(ConvParams& p, hipStream_t stream) {
     auto it = g_cache.find(key);
     if (it != g_cache.end()) { c = it->second; have = true; }
   }
+  if (have) {
+    // a cached entry may come from a file (udet_tune_load): never trust it beyond what the launcher would choose itself --
+    // only instantiated tiles / families, the split count inside this launch's capacity, folding only where tickets exist
+    static const int TILES[6][2] = {{256, 32}, {128, 32}, {128, 64}, {64, 64}, {128, 96}, {128, 128}};
+    bool tile = false;
+    for (auto& t : TILES) tile = tile || (c.bm == t[0] && c.bn == t[1]);
+    if (c.ws == 3) tile = (c.bm == 4 || c.bm == 8) && (c.bn == 16 || c.bn == 32);
+    if (!tile || c.ws < 0 || c.ws > 6) {
+      c = heuristic_cfg(p);
+    } else {
+      const int cap = max_ksplit(p);
+      if (c.ks < 1) c.ks = 1;
+      if (c.ks > cap) { c.ks = cap; c.tail = 0; }
+      c.fold = c.fold ? 1 : 0;
+      if (c.tail < 0) c.tail = 0;
+    }
+  }
   if (!have) {
     if (g_tuning) {
       c = tune_cfg(p, stream);

@@ -570,7 +570,7 @@ int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream) {
     // (centre tap x output channels) must not straddle an M tile: 128 % co4 == 0.
     const bool narrow = p.Cout <= 4 ? p.Cin >= 16 : (p.Cout <= 16 && 128 % co4 == 0 && cheaper);
     const bool swap = narrow && p.isy == 1 && p.isx == 1 && p.up_shift == 0 && p.H == p.OH && p.W == p.OW &&
-                      p.ya == nullptr && centre >= 0 && !getenv("UDET_NO_WSWAP");
+                      p.ya == nullptr && centre >= 0;
     if (swap) {
       g.x = p.dy; g.ldx = p.ldy; g.x_coff = p.y_coff; g.Cin = p.Cout;
       g.dy = p.x; g.ldy = p.ldx; g.y_coff = p.x_coff; g.Cout = p.Cin;

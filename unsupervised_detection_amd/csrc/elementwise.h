@@ -26,7 +26,8 @@ int launch_mask_bwd(const float* dmask, const float* dfin, const float* f, const
 int launch_grad_absmean(const float* g, const long* seg_off, const long* seg_len, int nvars, float* vmean, float thresh,
                         float* out, hipStream_t s);
 int launch_adam(float* w, float* g, float* m, float* v, long n, float lr_t, float b1, float b2, float eps, float clip,
-                const float* flag, uint64_t seed, uint64_t step, hipStream_t s, int mode = 0);
+                const float* flag, uint64_t seed, uint64_t step, hipStream_t s, int mode = 0, const int* skip = nullptr);
+int launch_nonfinite_count(const float* g, long n, int* out, hipStream_t s);
 int launch_flow_normalize(const float* f, double* part, float* out, int B, long HW, hipStream_t s);
 int launch_charbonnier(const float* gt, const float* pred, const float* mask, int mc, int B, long HW, float cbn, float* part,
                        float* out, hipStream_t s);

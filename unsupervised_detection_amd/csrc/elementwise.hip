@@ -754,9 +754,11 @@ __device__ __host__ __forceinline__ float udet_uniform01(uint64_t seed, uint64_t
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ w, float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long n, float lr_t, float b1, float b2, float eps,
                                                    float clip, const float* __restrict__ flag, uint64_t seed,
-                                                   uint64_t step, int mode) {
+                                                   uint64_t step, int mode, const int* __restrict__ skip) {
   // mode 0: clip / noise + Adam (the step's fused form); 1: clip / noise only (train_op's clipped_grad_and_vars);
   // 2: Adam only on the gradient as it is (optimizer.apply_gradients)
+  // skip (fp16 mode): number of non-finite gradient values counted by nonfinite_count_kernel -- the whole update is dropped
+  if (skip && *skip != 0) return;
   const bool noise = flag && flag[1] != 0.f;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     float gi = g[i];
@@ -822,9 +824,28 @@ int launch_mask_stats(const float* pred, const float* gt, int N, int H, int W, f
   return UDET_OK;
 }
 int launch_adam(float* w, float* g, float* m, float* v, long n, float lr_t, float b1, float b2, float eps, float clip,
-                const float* flag, uint64_t seed, uint64_t step, hipStream_t s, int mode) {
+                const float* flag, uint64_t seed, uint64_t step, hipStream_t s, int mode, const int* skip) {
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, s, w, g, m, v, n, lr_t, b1, b2, eps, clip, flag, seed,
-                     step, mode);
+                     step, mode, skip);
+  UDET_HIP(hipGetLastError());
+  return UDET_OK;
+}
+// fp16 mode: gradient operands are scaled by 4096 before the fp16 conversion, so |dU| > 16 becomes inf there and reaches the flat
+// gradient buffer as inf / NaN (nothing on the way maps a non-finite value back to a finite one; the clip of the optimizer would).
+// out[0] = number of non-finite values of g[0, n), out[1] += the same (running total of the plan)
+__global__ __launch_bounds__(256) void nonfinite_count_kernel(const float* __restrict__ g, long n, int* __restrict__ out) {
+  int c = 0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) c += !(fabsf(g[i]) <= 3.402823466e38f);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+  if ((threadIdx.x & 63) == 0 && c) {
+    atomicAdd(out, c);
+    atomicAdd(out + 1, c);
+  }
+}
+int launch_nonfinite_count(const float* g, long n, int* out, hipStream_t s) {
+  UDET_HIP(hipMemsetAsync(out, 0, sizeof(int), s));
+  hipLaunchKernelGGL(nonfinite_count_kernel, dim3(grid_for(n, 1024)), dim3(256), 0, s, g, n, out);
   UDET_HIP(hipGetLastError());
   return UDET_OK;
 }

@@ -108,6 +108,14 @@ struct Plan {
   bool profiling = false;
   std::vector<ProfRec*> prof;
   long adam_t = 0;               // number of optimizer applies so far (shared beta powers)
+  // fp16 mode (cfg.conv_fp16): overflow guard of the static 4096 gradient scale.  plan_apply counts the non-finite values of the
+  // flat gradient buffer on the device; the optimizer kernel drops the update when there are any (the weights are never touched
+  // by inf / NaN), the count travels to pinned host memory behind an event and the NEXT call on the plan reports it
+  // (UDET_ERR_OVERFLOW once per skipped update; udet_fp16_overflow_count is the synchronous query)
+  int* ovf_host = nullptr;       // [2 nets][2]: {count of the last apply, running total}
+  hipEvent_t ovf_ev[3] = {nullptr, nullptr, nullptr};
+  bool ovf_pending[3] = {false, false, false};
+  long ovf_skipped = 0;          // optimizer updates dropped so far
   bool pwc_packed = false;
   int add_buf(const std::string& name, int n, int h, int w, int ld);
   const Buf& buf(int id) const { return bufs[id]; }
@@ -134,6 +142,8 @@ int plan_losses(Plan* P, float* ws, hipStream_t s);
 // which: 1 generator loss -> MaskNet, 2 recover loss -> FlownetS, 3 both (the two passes run concurrently)
 int plan_backward(Plan* P, int which, const float* w_gen, const float* w_rec, float* g_gen, float* g_rec, float* ws, hipStream_t s);
 int plan_apply(Plan* P, int net, float* w, float* g, float* m, float* v, float* ws, hipStream_t s);
+// fp16 mode: reports (once) an optimizer update that was dropped because its gradients were not finite; wait: synchronise first
+int plan_check_overflow(Plan* P, bool wait);
 enum { PROF_CONV_FWD = 0, PROF_CONV_DGRAD = 1, PROF_CONV_WGRAD = 2, PROF_WARP = 3, PROF_CORR = 4, PROF_NCAT = 5 };
 void prof_begin(Plan* P, int cat, double flops, double bytes, hipStream_t s, const char* name = "");
 void prof_end(Plan* P, hipStream_t s);

@@ -177,6 +177,9 @@ Plan::~Plan() {
   for (auto* r : prof) delete r;
   for (auto& ev : grad_ev)
     if (ev) (void)hipEventDestroy(ev);
+  for (auto& ev : ovf_ev)
+    if (ev) (void)hipEventDestroy(ev);
+  if (ovf_host) (void)hipHostFree(ovf_host);
 }
 
 Plan* plan_build(const Config& cfg) {
@@ -441,7 +444,7 @@ Plan* plan_build(const Config& cfg) {
     for (auto& L : v) {
       const bool head = L.cout == 2 && L.cin >= 32 && L.kh * L.kw * L.cout <= 64 && L.dil == 1 && !L.up && L.res < 0 && L.y2 < 0 &&
                         ((L.transposed && L.kh == 4) || (!L.transposed && L.stride == 1));
-      if (!head || getenv("UDET_NO_COL2IM")) continue;
+      if (!head) continue;
       L.col2im = true;
       L.ldz = round_up(L.kh * L.kw * L.cout, 32);
       L.zbuf = P->add_buf("z." + L.name, N, L.H, L.W, L.ldz);
@@ -497,22 +500,13 @@ Plan* plan_build(const Config& cfg) {
     off = align64(off + 4 * nl * (sizeof(PackJob) / sizeof(float)) + 64);
   }
   P->arena_floats = off;
+  // UDET_SERIAL=1 (read once, here; documented in include/udet.h next to udet_plan_set_concurrent): every lane collapses onto
+  // the caller's stream
   if (const char* e = getenv("UDET_SERIAL")) P->concurrent = atoi(e) == 0;
-  // Side streams.  Lanes that carry background work (filter gradients: 2,3; next-step PWC prefetch: 4,5) get the
-  // lowest priority so that the dependent chains on lanes 0/1 keep first call on freed CUs (UDET_PRIO=0: all equal).
-  {
-    int least = 0, greatest = 0;
-    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-    const int mode = getenv("UDET_PRIO") ? atoi(getenv("UDET_PRIO")) : 0;  // measured: any priority split costs 4-5 ms/step
-    for (int i = 0; i < Plan::NLANE - 1; ++i) {
-      const int lane = i + 1;
-      int prio = 0;
-      if (mode == 1 && lane >= 4) prio = least;
-      if (mode == 2 && lane >= 2) prio = least;
-      if (mode == 3) prio = lane >= 4 ? least : (lane == 1 ? greatest : 0);
-      const hipError_t rc = hipStreamCreateWithPriority(&P->side[i], hipStreamNonBlocking, prio);
-      if (rc != hipSuccess) { P->side[i] = nullptr; P->concurrent = false; }
-    }
+  // Side streams, all at the default priority (measured: any priority split between the lanes costs 4-5 ms per step).
+  for (int i = 0; i < Plan::NLANE - 1; ++i) {
+    const hipError_t rc = hipStreamCreateWithFlags(&P->side[i], hipStreamNonBlocking);
+    if (rc != hipSuccess) { P->side[i] = nullptr; P->concurrent = false; }
   }
   // views into the small region (read by the host wrapper)
   struct { const char* n; int a, d; size_t o; } views[4] = {{"losses", 1, 8, 0}, {"loss_coef", B, 4, 16}, {"noise_flag", 1, 2, 256},

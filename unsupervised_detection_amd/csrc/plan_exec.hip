@@ -62,12 +62,6 @@ struct Lane {
 };
 static Lane lane_of(Plan* P, hipStream_t main, int i) {
   if (i == 0 || !P->concurrent || P->profiling) return Lane{main, 0};
-  // UDET_LANES bit mask of enabled side lanes (default all): a disabled lane falls back onto its parent chain
-  static const int mask = getenv("UDET_LANES") ? atoi(getenv("UDET_LANES")) : 0x3e;
-  if (!(mask & (1 << i))) {
-    const int parent = i == 5 ? 4 : (i == 3 ? 1 : 0);  // heads -> prefetch chain, gen wgrad -> gen chain, else caller
-    return lane_of(P, main, parent);
-  }
   return Lane{P->side[i - 1], i};
 }
 static hipEvent_t next_event(Plan* P) {
@@ -814,8 +808,40 @@ int plan_apply(Plan* P, int net, float* w, float* g, float* m, float* v, float* 
   }
   const long t = ++P->adam_t;  // ONE optimizer object: beta powers advance on every apply (:216)
   const double lr_t = (double)c.lr * sqrt(1.0 - pow((double)c.beta2, (double)t)) / (1.0 - pow((double)c.beta1, (double)t));
-  return launch_adam(w, g, m, v, (long)np.total, (float)lr_t, c.beta1, c.beta2, c.adam_eps, c.clip, flag, c.noise_seed,
-                     (uint64_t)t, s);
+  const int* skip = nullptr;
+  if (c.conv_fp16) {  // overflow guard of the static fp16 gradient scale (see Plan::ovf_host)
+    int* cnt = reinterpret_cast<int*>(sm + 300) + 2 * (net - 1);  // {this apply, running total}
+    UDET_TRY(launch_nonfinite_count(g, (long)np.total, cnt, s));
+    skip = cnt;
+  }
+  UDET_TRY(launch_adam(w, g, m, v, (long)np.total, (float)lr_t, c.beta1, c.beta2, c.adam_eps, c.clip, flag, c.noise_seed,
+                       (uint64_t)t, s, 0, skip));
+  if (c.conv_fp16) {
+    if (!P->ovf_host) UDET_HIP(hipHostMalloc(reinterpret_cast<void**>(&P->ovf_host), 4 * sizeof(int), hipHostMallocDefault));
+    if (!P->ovf_ev[net]) UDET_HIP(hipEventCreateWithFlags(&P->ovf_ev[net], hipEventDisableTiming));
+    UDET_HIP(hipMemcpyAsync(P->ovf_host + 2 * (net - 1), skip, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
+    UDET_HIP(hipEventRecord(P->ovf_ev[net], s));
+    P->ovf_pending[net] = true;
+  }
+  return UDET_OK;
+}
+
+int plan_check_overflow(Plan* P, bool wait) {
+  if (!P->cfg.conv_fp16) return UDET_OK;
+  int bad = 0, which = 0;
+  for (int net = 1; net <= 2; ++net) {
+    if (!P->ovf_pending[net]) continue;
+    if (wait) UDET_HIP(hipEventSynchronize(P->ovf_ev[net]));
+    else if (hipEventQuery(P->ovf_ev[net]) != hipSuccess) continue;  // still in flight: reported by a later call
+    P->ovf_pending[net] = false;
+    const int n = P->ovf_host[2 * (net - 1)];
+    if (n > 0) { bad += n; which |= net; ++P->ovf_skipped; }
+  }
+  if (!bad) return UDET_OK;
+  set_error("fp16 mode: %d non-finite gradient value(s) in the %s gradients -- a gradient operand times 4096 overflowed fp16 (|dU| > 16); "
+            "the optimizer update of that step was NOT applied (weights and Adam slots unchanged)", bad,
+            which == 3 ? "generator and recover" : (which == 1 ? "generator" : "recover"));
+  return UDET_ERR_OVERFLOW;
 }
 
 }  // namespace udet

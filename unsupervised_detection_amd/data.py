@@ -160,12 +160,21 @@ def _read_image(path, channels):
 class Davis2016Reader(object):
     """data/davis2016_data_utils.py:68-354 as Python iterables of device batches."""
 
-    def __init__(self, root_dir, max_temporal_len=3, min_temporal_len=1, num_threads=6, device="cuda", seed=None, loader=None):
+    def __init__(self, root_dir, max_temporal_len=3, min_temporal_len=1, num_threads=6, device="cuda", seed=None, loader=None,
+                 shard=(0, 1)):
+        """shard = (rank, world) for data-parallel training: every rank shuffles the pair table with the SAME generator
+        (seed) and takes its own batch_size rows of each global batch of batch_size * world rows -- the ranks' pairs are
+        disjoint and one epoch covers the table once; temporal shifts and augmentation draws come from a per-rank
+        generator (seed + rank)."""
         assert min_temporal_len < max_temporal_len, "Temporal lenghts are not consistenst"
         assert min_temporal_len > 0, "Min temporal len should be positive"
         self.root_dir, self.max_temporal_len, self.min_temporal_len = root_dir, max_temporal_len, min_temporal_len
         self.num_threads, self.device = num_threads, device
-        self.rng = np.random.default_rng(seed)
+        self.rank, self.world = int(shard[0]), max(1, int(shard[1]))
+        assert 0 <= self.rank < self.world, "shard = (rank, world)"
+        self.order_rng = np.random.default_rng(seed)  # identical on every rank: the shuffle of the pair table
+        # one rank: a single stream for everything (as before); several: per-rank draws beside the shared shuffle
+        self.rng = self.order_rng if self.world == 1 else np.random.default_rng(None if seed is None else seed + 1 + self.rank)
         self.loader = loader or _read_image  # (path, channels) -> uint8 [H,W,C]
 
     def get_filenames_list(self, partition):
@@ -188,9 +197,10 @@ class Davis2016Reader(object):
 
         def gen():
             while True:
-                order = self.rng.permutation(len(table))
-                for s in range(0, len(order) - batch_size + 1, batch_size):  # drop_remainder=True
-                    rows = table[order[s:s + batch_size]]
+                order = self.order_rng.permutation(len(table))
+                gb = batch_size * self.world  # rows of one global batch; this rank's slice of it
+                for s in range(0, len(order) - gb + 1, gb):  # drop_remainder=True
+                    rows = table[order[s + self.rank * batch_size:s + (self.rank + 1) * batch_size]]
                     shift = self.rng.integers(self.min_temporal_len, self.max_temporal_len + 1, len(rows))
                     i1 = rows[:, 0].astype(np.int32)
                     i2 = (shift.astype(np.float32) * rows[:, 1] + rows[:, 0]).astype(np.int32)

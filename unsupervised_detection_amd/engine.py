@@ -29,6 +29,10 @@ lib.udet_buffer_count.restype = c_i
 lib.udet_buffer_count.argtypes = [c_p]
 lib.udet_buffer_info.restype = c_i
 lib.udet_buffer_info.argtypes = [c_p, c_i, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(c_sz), ctypes.POINTER(c_i)]
+lib.udet_plan_set_concurrent.restype = c_i
+lib.udet_plan_set_concurrent.argtypes = [c_p, c_i]
+lib.udet_fp16_overflow_count.restype = ctypes.c_long
+lib.udet_fp16_overflow_count.argtypes = [c_p]
 lib.udet_get_adam_step.restype = ctypes.c_long
 lib.udet_get_adam_step.argtypes = [c_p]
 lib.udet_set_adam_step.restype = None
@@ -218,6 +222,14 @@ class Engine:
         # packets and dispatch gaps)
         return {c: dict(groups=out[5 * i], ms=out[5 * i + 1], flops=out[5 * i + 2], bytes=out[5 * i + 3], bracket_ms=out[5 * i + 4])
                 for i, c in enumerate(cats)}
+
+    def set_concurrent(self, on: bool):
+        """False: every lane of the plan collapses onto the caller's stream (plain program order, bit-identical results)."""
+        check(lib.udet_plan_set_concurrent(self._h, 1 if on else 0))
+
+    def fp16_overflow_count(self) -> int:
+        """conv_fp16 plans: optimizer updates dropped so far because their gradients were not finite (synchronises)."""
+        return int(lib.udet_fp16_overflow_count(self._h))
 
     @property
     def adam_step(self):

@@ -24,7 +24,7 @@ import torch
 from . import data as _data
 from . import weights as W
 from .engine import GEN, REC, Engine, EngineConfig
-from .trainer import TrainState, train_step
+from .trainer import TrainState, flush_weights, train_step
 
 TEST_CROPS = [0.85, 0.9, 0.95, 1.0]  # adversarial_learner.py:531
 
@@ -37,17 +37,22 @@ def _engine_config(config, batch=None, in_hw=(384, 640)):
 
 
 def _latest_checkpoint(checkpoint_dir):
-    """tf.train.latest_checkpoint analogue for the files save() writes: the model-<epoch> with the largest epoch, else
-    model.best; '' when the directory holds none."""
+    """tf.train.latest_checkpoint analogue: the model-<N> with the largest N among the files save() writes (`model-N`
+    torch files, `model-N.tf.index` Saver prefixes of --save_tf_checkpoint) AND the reference's own `model-N.index`
+    (adversarial_learner.py:347-348 resumes from whatever its Saver left in checkpoint_dir); else model.best; '' when the
+    directory holds none.  A Saver checkpoint is returned as its prefix (what _load_weights' reader takes)."""
     import os
     import re
     if not (checkpoint_dir and os.path.isdir(checkpoint_dir)):
         return ""
     best, best_n = "", -1
-    for name in os.listdir(checkpoint_dir):
-        m = re.fullmatch(r"model-(\d+)", name)
-        if m and int(m.group(1)) > best_n:
-            best, best_n = os.path.join(checkpoint_dir, name), int(m.group(1))
+    for name in sorted(os.listdir(checkpoint_dir)):
+        m = re.fullmatch(r"(model-(\d+)(\.tf)?)(\.index)?", name)
+        if not m or (m.group(3) and not m.group(4)):  # model-N | model-N.index | model-N.tf.index
+            continue
+        n = int(m.group(2))
+        if n > best_n or (n == best_n and not m.group(4)):  # same N: prefer the native torch file
+            best, best_n = os.path.join(checkpoint_dir, m.group(1)), n
     if not best and os.path.isfile(os.path.join(checkpoint_dir, "model.best")):
         best = os.path.join(checkpoint_dir, "model.best")
     return best
@@ -139,7 +144,9 @@ class AdversarialLearner(object):
         if mode == "train":
             if getattr(config, "resume_train", False):
                 ckpt = getattr(config, "full_model_ckpt", "")
-                if not ckpt:
+                # :345-350: full_model_ckpt when it exists, ELSE the latest checkpoint of checkpoint_dir (a missing
+                # full_model_ckpt is not an error there)
+                if not (ckpt and (os.path.isfile(prefix_of(ckpt) + ".index") or os.path.isfile(ckpt))):
                     ckpt = _latest_checkpoint(getattr(config, "checkpoint_dir", ""))
                 assert ckpt, "Found no checkpoint to resume training!"
                 d, how = read(ckpt)
@@ -173,7 +180,12 @@ class AdversarialLearner(object):
         self.state = TrainState(self.engine, seed=getattr(config, "seed", 8964), **self._load_weights(config, "train"))
         n_params = sum(W.param_total(n) for n in (W.NET_PWC, W.NET_GEN, W.NET_REC))
         print("Number of params: {}".format(n_params))
-        self.train_steps_per_epoch = int(math.ceil(config.num_samples_train / config.batch_size))
+        # data parallel: every step consumes batch_size pairs on each of `world` ranks (cli.py shards the pair table), so an
+        # epoch -- validation, save_freq, max_epochs -- is num_samples_train / (batch_size * world) steps; world = 1 is the
+        # reference's ceil(num_samples_train / batch_size) (:320)
+        import torch.distributed as dist
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        self.train_steps_per_epoch = int(math.ceil(config.num_samples_train / (config.batch_size * world)))
         iters_rec, iters_gen = config.iters_rec, config.iters_gen
         print("-------------------------------------")
         print("Training {} Recover and {} Generator".format(iters_rec, iters_gen))
@@ -221,6 +233,8 @@ class AdversarialLearner(object):
         graph's generator on each pair, disambiguated masks against gt > 0.01."""
         from .evaluation import compute_all_IoU
         e = self.engine
+        if self.state is not None:
+            flush_weights(self.state)  # the last optimizer apply's re-layout is deferred: validate the weights save() writes
         total, steps, samples = 0.0, 0, 0
         for batch in source:
             if n_steps is not None and steps >= n_steps:

@@ -38,6 +38,16 @@ class TrainState:
             self.tuned_shapes = engine.autotune(self.w_gen, self.w_rec, self.g_gen, self.g_rec)
 
 
+def flush_weights(st: TrainState):
+    """train_step defers the re-layout of the weights an optimizer apply changed to the NEXT step.  Anything else that reads
+    the packed layout in between (a stand-alone forward: validation, inference on the training state) must see the weights
+    that were just trained -- and that save() writes: flush the pending re-layout first."""
+    dirty = getattr(st, "_dirty", 0)
+    if dirty:
+        st.engine.pack_trainable(st.w_gen if dirty & GEN else None, st.w_rec if dirty & REC else None)
+    st._dirty = 0
+
+
 def allreduce_mean_(t: torch.Tensor, group=None, async_op=False):
     """In-place mean over the data-parallel group (no-op without an initialised process group)."""
     import torch.distributed as dist
@@ -45,40 +55,40 @@ def allreduce_mean_(t: torch.Tensor, group=None, async_op=False):
         return None  # group=False: this process trains alone even though a process group exists (reference runs of the tests)
     if dist.get_backend(group) == "nccl":
         return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group, async_op=async_op)
-    work = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=False)
+    work = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=False)  # (gloo has no AVG)
     t.div_(dist.get_world_size(group))
     return work if async_op else None
 
 
 def _exchange_gradients(st: TrainState, which: int, group):
     """grad(global batch) = mean over ranks of grad(local batch): the step's only collective(s).
-    RCCL ("nccl"), which=BOTH: the recover gradients are exchanged on a communication stream that waits only for THEIR
-    completion event (udet_stream_wait_grads), i.e. under the rest of the longer generator-loss pass; the generator gradients
-    follow when the whole backward is done.  Both collectives are issued in the same order on every rank.
-    Other backends (gloo in the tests) and single-network steps: one blocking exchange of what the step computed."""
+
+    The stream / event choreography is the SAME for every backend -- only the collective inside `allreduce_mean_` differs (RCCL
+    "nccl" on the GPU box, gloo in the one-GPU tests), so tests/test_dp_gpu.py executes exactly the code an 8-GPU run does:
+      which = BOTH: a communication stream waits for the completion event of the RECOVER gradients alone
+        (udet_stream_wait_grads: udet_backward records it where g_rec is final, before the caller's stream joins the longer
+        generator-loss pass) and reduces g_rec there -- under the rest of the generator-loss pass;  the generator gradients are
+        reduced on the compute stream once the whole backward is done;  the compute stream then waits for the communication
+        stream.  Both collectives are issued in the same order on every rank.
+      which = REC / GEN: one collective on the compute stream over what the step computed."""
     import torch.distributed as dist
     if group is False or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return
     e = st.engine
-    if which == BOTH and dist.get_backend(group) == "nccl":
-        from ._ffi import check, lib
-        comm = getattr(st, "_comm_stream", None)
-        if comm is None:
-            comm = st._comm_stream = torch.cuda.Stream(device=e.device)
-        check(lib.udet_stream_wait_grads(e._h, W.NET_REC, comm.cuda_stream))
-        with torch.cuda.stream(comm):
-            w_rec = dist.all_reduce(st.g_rec, op=dist.ReduceOp.AVG, group=group, async_op=True)
-        w_gen = dist.all_reduce(st.g_gen, op=dist.ReduceOp.AVG, group=group, async_op=True)
-        w_rec.wait()  # the compute stream waits for both before the optimizer applies
-        w_gen.wait()
+    if which != BOTH:
+        allreduce_mean_(st.g_rec if which & REC else st.g_gen, group)
         return
-    if which == BOTH and getattr(st, "g_all", None) is not None:
-        allreduce_mean_(st.g_all, group)  # one collective for both networks
-        return
-    if which & REC:
-        allreduce_mean_(st.g_rec, group)
-    if which & GEN:
-        allreduce_mean_(st.g_gen, group)
+    from ._ffi import check, lib
+    comm = getattr(st, "_comm_stream", None)
+    if comm is None:
+        comm = st._comm_stream = torch.cuda.Stream(device=e.device)
+    main = torch.cuda.current_stream(e.device)
+    check(lib.udet_stream_wait_grads(e._h, W.NET_REC, comm.cuda_stream))
+    with torch.cuda.stream(comm):
+        allreduce_mean_(st.g_rec, group)  # (gloo: the host blocks here until g_rec is final and reduced; the generator-loss
+        done = comm.record_event()        #  pass is already enqueued and keeps running on the device)
+    allreduce_mean_(st.g_gen, group)
+    main.wait_event(done)  # the optimizer applies follow on the compute stream
 
 
 def train_step(st: TrainState, img1, img2, which: int = BOTH, group=None, next_pair=None):
@@ -92,10 +102,7 @@ def train_step(st: TrainState, img1, img2, which: int = BOTH, group=None, next_p
     e = st.engine
     # re-layout of whichever network the PREVIOUS steps updated (every forward reads both networks, so a recover step right
     # after a generator step must see the new generator too)
-    dirty = getattr(st, "_dirty", GEN | REC)
-    if dirty:
-        e.pack_trainable(st.w_gen if dirty & GEN else None, st.w_rec if dirty & REC else None)
-    st._dirty = 0
+    flush_weights(st)
     if getattr(st, "_prefetched", None) is not None:
         p1, p2 = st._prefetched
         if p1.data_ptr() != img1.data_ptr() or p2.data_ptr() != img2.data_ptr():
