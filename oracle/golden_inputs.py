@@ -12,6 +12,12 @@ STEP_CFG = dict(batch_size=2, in_height=128, in_width=192, img_height=64, img_wi
                 epsilon=75.0, beta1=0.9)
 
 
+# BASELINE.json configs[1] -- the shape bench.py measures (tests/golden/step_cfg2.npz)
+STEP_CFG2 = dict(batch_size=4, in_height=384, in_width=640, img_height=192, img_width=384, flow_normalizer=80.0, cbn=0.5,
+                 epsilon=75.0, beta1=0.9)
+CFG2_STRIDE = 4  # mask / predictions are kept at every 4th row and column (the flow, an INPUT of the replay, is kept whole)
+
+
 def tensor(name: str, shape, scale=1.0, offset=0.0):
     """float32 array ~ offset + scale * N(0,1), seeded by the name."""
     rs = np.random.RandomState(zlib.crc32(name.encode()) & 0x7fffffff)

@@ -145,6 +145,45 @@ def test_oracle_step_matches_reference_build_train_graph():
             _summaries_close(G.grad_summary(clipped[k].numpy()), g["grad/%s/%s" % (tag, k)], 2e-3, floor)
 
 
+class Cfg2(O.Flags):
+    img_height, img_width, batch_size = G.STEP_CFG2["img_height"], G.STEP_CFG2["img_width"], G.STEP_CFG2["batch_size"]
+    flow_normalizer, cbn, epsilon, beta1 = (G.STEP_CFG2[k] for k in ("flow_normalizer", "cbn", "epsilon", "beta1"))
+
+
+def _cfg2_sub(a):
+    return np.ascontiguousarray(np.asarray(a)[:, ::G.CFG2_STRIDE, ::G.CFG2_STRIDE])
+
+
+def test_oracle_step_matches_reference_build_train_graph_at_config2():
+    """The same replay at BASELINE.json configs[1] (B = 4, 384x640 -> 192x384; tests/golden/step_cfg2.npz was produced by the
+    reference's own build_train_graph at that shape): the oracle's trainable part on the reference's flow -- mask / prediction
+    samples, the 8 losses{} entries and the raw + clipped gradient summary of every variable."""
+    g = gold("step_cfg2")
+    c = G.STEP_CFG2
+    img1, _ = G.image_pair(c["batch_size"], c["in_height"], c["in_width"])
+    image = O.resize_bilinear_legacy(T(img1), c["img_height"], c["img_width"])  # adversarial_learner.py:87-90
+    assert np.array_equal(image.numpy()[:, ::32], g["image_rows"])
+    assert abs(float(image.double().sum()) - g["image_sum"][0]) < 1e-6 * g["image_sum"][1]
+    pg = {k: v.requires_grad_(True) for k, v in tparams(O.generator_param_specs()).items()}
+    pr = {k: v.requires_grad_(True) for k, v in tparams(O.recover_param_specs()).items()}
+    torch.set_num_threads(min(32, max(1, os.cpu_count() or 1)))
+    out = O.forward_from_flow(pg, pr, image, T(g["flow"]), Cfg2)
+    assert float(np.abs(_cfg2_sub(out["mask"].detach().numpy()) - g["mask"]).max()) < 1e-5
+    for k in ("generator", "recover", "red_rate", "red_rate_compl", "reconstruction_loss", "reconstruction_compl_loss",
+              "denominator_red_rate", "denominator_red_rate_compl"):
+        assert abs(float(out[k]) - float(g[k])) < 1e-4 * max(1.0, abs(float(g[k]))), k
+    m = out["mask"].detach()
+    pf = (out["pred"].detach() * m + T(g["flow"]) * (1 - m)).numpy()
+    assert rel(_cfg2_sub(pf), g["pred_flow"]) < 1e-4
+    for tag, loss, params in (("gen", out["generator"], pg), ("rec", out["recover"], pr)):
+        grads = O.grads_of(loss, params)
+        floor = 1e-3 * max(float(g["rawgrad/%s/%s" % (tag, k)][0]) for k in grads)
+        clipped, _ = O.clip_or_noise(grads, 0.2, False)
+        for k in grads:
+            _summaries_close(G.grad_summary(grads[k].numpy()), g["rawgrad/%s/%s" % (tag, k)], 2e-3, floor)
+            _summaries_close(G.grad_summary(clipped[k].numpy()), g["grad/%s/%s" % (tag, k)], 2e-3, floor)
+
+
 def _flip_flags(cases):
     """(outer, inner) draws of data/aug_flips.py:35-45 -> (flip_lr, flip_td): outer 0 = keep | rotate 180, outer 1 = lr | td."""
     outer, inner = int(cases[0]), int(cases[1])
@@ -255,6 +294,49 @@ def test_hip_step_matches_reference_build_train_graph(gpu_env):
     B = c["batch_size"]
     pred = eng.buffer("pred").cpu().numpy()[:B]
     assert rel(pred * mask + g["flow"] * (1 - mask), g["pred_flow"]) < 1e-3
+    L = eng.losses()
+    for k in L:
+        assert abs(L[k] - float(g[k])) < 1e-3 * max(1.0, abs(float(g[k]))), (k, L[k], float(g[k]))
+    g_gen = torch.zeros(W.param_total(W.NET_GEN), device="cuda")
+    g_rec = torch.zeros(W.param_total(W.NET_REC), device="cuda")
+    eng.backward(3, flat["gen"], flat["rec"], g_gen, g_rec)
+    for tag, net, got in (("gen", W.NET_GEN, g_gen.cpu()), ("rec", W.NET_REC, g_rec.cpu())):
+        d = W.as_dict(got, net)
+        floor = 1e-3 * max(float(g["rawgrad/%s/%s" % (tag, k)][0]) for k in d)
+        for k, v in d.items():
+            _summaries_close(G.grad_summary(v.numpy()), g["rawgrad/%s/%s" % (tag, k)], 2e-3, floor)
+            _summaries_close(G.grad_summary(v.clamp(-0.2, 0.2).numpy()), g["grad/%s/%s" % (tag, k)], 2e-3, floor)
+
+
+@pytest.mark.gpu
+def test_hip_step_matches_reference_build_train_graph_at_config2():
+    """The HIP path against the reference's own build_train_graph at BASELINE.json configs[1] (B = 4, 384x640 -> 192x384): image
+    resize, PWC flow, and -- on the reference's flow -- mask / prediction samples, the 8 losses{} entries and every variable's
+    raw + clipped gradient summary, at the north_star tolerance."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from unsupervised_detection_amd import weights as W
+    from unsupervised_detection_amd.engine import Engine, EngineConfig
+    g = gold("step_cfg2")
+    c = G.STEP_CFG2
+    B = c["batch_size"]
+    eng = Engine(EngineConfig(batch_size=B, in_height=c["in_height"], in_width=c["in_width"], img_height=c["img_height"],
+                              img_width=c["img_width"]))
+    flat = {"pwc": W.from_dict(tparams(O.pwc_param_specs()), W.NET_PWC).cuda(),
+            "gen": W.from_dict(tparams(O.generator_param_specs()), W.NET_GEN).cuda(),
+            "rec": W.from_dict(tparams(O.recover_param_specs()), W.NET_REC).cuda()}
+    eng.pack_pwc(flat["pwc"])
+    eng.pack_trainable(flat["gen"], flat["rec"])
+    img1, img2 = G.image_pair(B, c["in_height"], c["in_width"])
+    eng.forward(T(img1).cuda(), T(img2).cuda(), 3)
+    image = eng.buffer("image").cpu()
+    assert np.array_equal(image.numpy()[:, ::32], g["image_rows"])  # legacy bilinear resize: bit-exact
+    assert rel(eng.buffer("flow").cpu().numpy(), g["flow"]) < 1e-3   # PWC-Net end to end
+    eng.forward_from_flow(image.cuda(), T(g["flow"]).cuda(), 3)     # the reference's flow: PWC rounding must not leak into the rest
+    mask = eng.buffer("mask").cpu().numpy()
+    assert float(np.abs(_cfg2_sub(mask) - g["mask"]).max()) < 1e-3
+    pred = eng.buffer("pred").cpu().numpy()[:B]
+    assert rel(_cfg2_sub(pred * mask + g["flow"] * (1 - mask)), g["pred_flow"]) < 1e-3
     L = eng.losses()
     for k in L:
         assert abs(L[k] - float(g[k])) < 1e-3 * max(1.0, abs(float(g[k]))), (k, L[k], float(g[k]))
