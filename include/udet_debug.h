@@ -9,7 +9,7 @@ extern "C" {
 /* force (bm, bn, split-K) for every convolution launch (bm bit 16: non-specialised kernel, bit 17: LDS-DMA staging,
  * bit 18: tile-resident kernel with bm & 0xffff = tile height, bit 19: self-staging LDS-DMA kernel, bit 20: split-K summed by a
  * second launch, bit 21: split-K summed by the last-arriving workgroup, bit 22 / 23: LDS-DMA kernel with a 3 / 4 stage
- * ring); (0,0,-1) restores.  A forced family a launch is not
+ * ring, bit 24: the direct kernels for 2-channel inputs / outputs where the launch is eligible); (0,0,-1) restores.  A forced family a launch is not
  * eligible for falls back to the built-in choice.  Process-global state: never call it from product code. */
 void udet_debug_force_conv(int bm, int bn, int ks);
 /* fp16 multiplication (fp32 accumulation) in the single-operator convolution entry points; plans take it from
@@ -19,7 +19,7 @@ void udet_debug_conv_fp16(int on);
  * (what udet_autotune does for a plan); tools/conv_bench.py / wgrad_bench.py use it to measure the tuned kernels stand-alone */
 void udet_debug_set_tuning(int on);
 /* what the most recent convolution launch actually ran: family (0 plain, 1 wave-specialised, 2 LDS-DMA, 3 tile-resident,
- * 6 self-staging LDS-DMA) | tile rows << 8 | split count << 20 | folded split-K << 28 */
+ * 6 self-staging LDS-DMA, 7 / 8 direct kernel for two input / two output channels) | tile rows << 8 | split count << 20 | folded split-K << 28 */
 int udet_debug_last_conv(void);
 #ifdef __cplusplus
 }

@@ -1,6 +1,6 @@
 """GPU: the data-parallel contract of the real engine on a one-GPU box (tools/dp_check.py): two ranks share cuda:0, gradients
 are averaged over gloo, and after the schedule BOTH, REC, GEN, BOTH (a) the replicas' weights and Adam slots are bit-identical
-and (b) they equal a single process training on the concatenated global batch within 1e-6 -- once with the default epsilon and
+and (b) they equal a single process training on the concatenated global batch within 5e-6 (5 % of one Adam step) -- once with the default epsilon and
 once with every generator step forced onto the escape-noise branch (loss_utils.py:19-26)."""
 import json
 import os

@@ -234,6 +234,45 @@ def test_conv_kernel_families(ops, force_conv, family, case):
     assert (dx - gx.float()).abs().max() < 2e-4 * max(1.0, float(gx.abs().max()))
 
 
+@pytest.mark.parametrize("case", [(2, 13, 37, 98, 3), (1, 31, 45, 50, 5), (1, 9, 70, 386, 3), (3, 8, 8, 196, 3), (1, 40, 72, 64, 5)])
+def test_two_channel_heads_run_the_direct_kernels(ops, force_conv, case):
+    """The flow / up_feat heads (2 output channels over a deep input) and their backward-data pass (2 input channels, wide output):
+    the direct kernels of conv_thin.hip are what an untuned launch runs (families 8 / 7), they agree with the oracle, and they
+    agree with the implicit-GEMM kernel on the same problem to summation-order rounding."""
+    n, h, w, cin, k = case
+    x = rnd(n, h, w, cin, seed=51).double().requires_grad_(True)
+    wt = rnd(k, k, cin, 2, seed=52, scale=(2.0 / (k * k * cin)) ** 0.5).double()
+    b = rnd(2, seed=53, scale=0.1).double()
+    y = O.conv2d_same(x, wt, b, 1, 1)
+    dy = rnd(*y.shape, seed=54).double()
+    gx, = torch.autograd.grad((y * dy).sum(), [x])
+    xf, wf, bf, dyf = x.detach().float().cuda(), wt.float().cuda(), b.float().cuda(), dy.float().cuda()
+    got = ops.conv2d(xf, wf, bf, 1, 1, "none", 0.0, False).cpu()
+    assert (force_conv.udet_debug_last_conv() & 0xff) == 8
+    assert (got - y.detach().float()).abs().max() < 1e-4 * max(1.0, float(y.abs().max()))
+    dx = ops.conv2d_backward_data(dyf, None, wf, (h, w), 1, 1, "none", 0.0).cpu()
+    assert (force_conv.udet_debug_last_conv() & 0xff) == 7
+    assert (dx - gx.float()).abs().max() < 2e-4 * max(1.0, float(gx.abs().max()))
+    force_conv.udet_debug_force_conv(*FAMILIES["wave_spec"])
+    ref_y = ops.conv2d(xf, wf, bf, 1, 1, "none", 0.0, False).cpu()
+    assert (force_conv.udet_debug_last_conv() & 0xff) == 1
+    ref_dx = ops.conv2d_backward_data(dyf, None, wf, (h, w), 1, 1, "none", 0.0).cpu()
+    assert (got - ref_y).abs().max() < 2e-5 * max(1.0, float(ref_y.abs().max()))
+    assert (dx - ref_dx).abs().max() < 2e-5 * max(1.0, float(ref_dx.abs().max()))
+
+
+def test_transposed_two_channel_head_runs_the_direct_kernel(ops, force_conv):
+    """up_feat_l (models/PWCNet/model_pwcnet.py:283-286): conv2d_transpose 4x4 s2 with two output channels -- the four output
+    parity classes share the staged input tile of the direct kernel."""
+    x = rnd(2, 12, 20, 529, seed=55)
+    wt = rnd(4, 4, 2, 529, seed=56, scale=(1.0 / (16 * 529)) ** 0.5)
+    b = rnd(2, seed=57, scale=0.1)
+    y = ops.conv2d_transpose4x4s2(x.cuda(), wt.cuda(), b.cuda()).cpu()
+    assert (force_conv.udet_debug_last_conv() & 0xff) == 8
+    ref = O.conv2d_transpose_k4s2_same(x.double(), wt.double(), b.double()).float()
+    assert (y - ref).abs().max() < 1e-4 * max(1.0, float(ref.abs().max()))
+
+
 @pytest.mark.parametrize("family", list(FAMILIES))
 def test_conv2d_transpose_kernel_families(ops, force_conv, family):
     x = rnd(2, 12, 20, 64, seed=25)

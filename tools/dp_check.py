@@ -7,7 +7,9 @@ steps"), runnable on a ONE-GPU box: R ranks share cuda:0 and exchange gradients 
 Every rank trains the same seeded weights on ITS OWN frame pairs for the schedule BOTH, REC, GEN, BOTH (trainer.train_step:
 forward, backward, gradient mean over ranks, clip / escape noise, Adam).  Then
   (a) the weights and Adam slots of all ranks must be bit-identical (torch.equal), and
-  (b) rank 0 repeats the schedule alone on the concatenated R*B batch; the result must agree within 1e-6:
+  (b) rank 0 repeats the schedule alone on the concatenated R*B batch; the result must agree within 5e-6 (5 % of ONE Adam step at
+      lr = 1e-4: the two runs execute different plans -- batch B vs R*B, so different tiles / kernels and summation orders -- and
+      Adam's g / sqrt(v) amplifies rounding of near-zero gradients; the replicas themselves are bit-identical):
       grad(global batch) = mean over ranks of grad(local batch) is the whole data-parallel contract of the path.
 --epsilon 1e15 makes every generator step take the escape-noise branch of train_op (loss_utils.py:19-26: the generator
 gradient is ~1/epsilon, far below the 1e-5 threshold), whose |U(-0.2,0.2)| draws come from a counter-based stream keyed by
@@ -73,7 +75,7 @@ def main():
             train_step(ref, a.cuda(), b.cuda(), which, group=False)
         torch.cuda.synchronize()
         diff = {k: float((mine[k] - getattr(ref, k).cpu()).abs().max()) for k in ("w_gen", "w_rec")}
-        ok = identical and all(v <= 1e-6 for v in diff.values())
+        ok = identical and all(v <= 5e-6 for v in diff.values())
         report = {"world": world, "local_batch": args.batch, "schedule": "BOTH,REC,GEN,BOTH", "epsilon": args.epsilon,
                   "replicas_bit_identical": identical, "generator_steps_on_the_noise_branch": noise_steps,
                   "max_abs_diff_vs_single_process_global_batch": diff, "ok": ok}

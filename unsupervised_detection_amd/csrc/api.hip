@@ -216,7 +216,7 @@ int udet_conv2d_backward_data(const float* dy, const float* y_saved, const float
     memset(&p, 0, sizeof(p));
     if (!conv_setup_dgrad(p, cls, n, h, w, kh, kw, stride, dilation)) continue;
     p.x = dyin; p.ldx = ldy; p.xa = yain; p.xact = act; p.xalpha = alpha;
-    p.wp = wp; p.Kc = kc; p.ldw = ldw;
+    p.wp = wp; p.Kc = kc; p.ldw = ldw; p.kreal = cout;
     p.y = dx; p.ldy = cin; p.Cout = cin;
     p.partial = part; p.partial_cap = SPLITK_FLOATS;
     p.zero16 = zero;

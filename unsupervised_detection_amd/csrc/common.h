@@ -156,6 +156,9 @@ struct ConvParams {
   // and the accumulators by 1 / f16_xscale before the epilogue: gradients (backward-data) use 4096 against fp16 underflow.
   int f16;
   float f16_xscale;
+  // real input channels when fewer than Kc (the rest are zero padding of the tensor and zero rows of the packed weights); 0: Kc.
+  // Lets the direct kernel for 2-channel inputs (conv_thin.hip) skip the padding.
+  int kreal;
 };
 #define UDET_MAX_TICKETS 4096
 

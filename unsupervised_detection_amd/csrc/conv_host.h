@@ -5,6 +5,11 @@ void same_pad(int in, int k, int s, int d, int* before, int* out);
 void conv_setup_fwd(ConvParams& p, int N, int H, int W, int kh, int kw, int s, int d);
 int conv_dgrad_classes(int s, int H, int W);
 void conv_force_config(int bm, int bn, int ks);
+// direct kernels for the 2-channel heads (conv_thin.hip): eligibility of a launch / the launches
+bool conv_thin_n_ok(const ConvParams& p);
+bool conv_thin_k_ok(const ConvParams& p);
+int launch_conv_thin_n(const ConvParams& p, hipStream_t stream);
+int launch_conv_thin_k(const ConvParams& p, hipStream_t stream);
 void conv_debug_f16(int on);  // fp16 multiplication in the single-operator launches (plans carry udet_config.conv_fp16)
 int conv_debug_f16_on();
 int conv_last_config();

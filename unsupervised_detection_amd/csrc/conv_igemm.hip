@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "common.h"
+#include "conv_host.h"
 #include <algorithm>
 
 namespace udet {
@@ -1215,9 +1216,9 @@ void conv_force_config(int bm, int bn, int ks) {
   g_force_tail = ks < 0 ? 0 : ((ks >> 8) & 0xff);  // ks + 256 r: tail split for r workgroup slots per CU (ks & 255 slices; 0: as many as fill a round)
   // bit 16: non-specialised, 17: LDS-DMA (wave-specialised), 18: tile kernel, 19: self-staging LDS-DMA (4 waves, BK 16);
   // bit 20: split-K through the second launch, bit 21: split-K folded into the last-arriving workgroup;
-  // bit 22 / 23: LDS-DMA with a 3 / 4 stage ring
+  // bit 22 / 23: LDS-DMA with a 3 / 4 stage ring; bit 24: the direct 2-channel-head kernels (conv_thin.hip) where a launch is eligible
   g_force_fold = (bm >> 20) & 1 ? 0 : ((bm >> 21) & 1 ? 1 : -1);
-  g_force_ws = (bm >> 16) & 1 ? 0 : ((bm >> 17) & 1 ? 2 : ((bm >> 18) & 1 ? 3 : ((bm >> 19) & 1 ? 6 : ((bm >> 22) & 1 ? 4 : ((bm >> 23) & 1 ? 5 : -1)))));
+  g_force_ws = (bm >> 16) & 1 ? 0 : ((bm >> 17) & 1 ? 2 : ((bm >> 18) & 1 ? 3 : ((bm >> 19) & 1 ? 6 : ((bm >> 22) & 1 ? 4 : ((bm >> 23) & 1 ? 5 : ((bm >> 24) & 1 ? 7 : -1))))));
 }
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
@@ -1342,6 +1343,10 @@ static ConvCfg heuristic_cfg(const ConvParams& p) {
   return c;
 }
 static int run_cfg(ConvParams& p, const ConvCfg& c, hipStream_t stream) {
+  if (c.ws == 7 || c.ws == 8) {  // direct kernels for the 2-channel heads (conv_thin.hip): 7 two input channels, 8 two output channels
+    p.ksplit = 1; p.fold = 0; p.tail_full = 0; p.tail_ks = 0;
+    return c.ws == 7 ? launch_conv_thin_k(p, stream) : launch_conv_thin_n(p, stream);
+  }
   if (c.ws == 3) {  // tile-resident direct convolution (conv_tile.hip); bm carries the tile height
     p.ksplit = 1;
     p.fold = 0;
@@ -1449,7 +1454,7 @@ bool tune_compare(const float* a, const float* b, size_t n, hipStream_t stream, 
 
 static uint64_t conv_key(const ConvParams& p) {
   const int f[] = {p.N, p.H, p.W, p.up_shift, p.Kc, p.Cout, p.ntaps, p.ncls, p.OHq, p.OWq, p.isy, p.osy, p.xa ? 1 : 0,
-                   p.ldx, p.ldy, p.accumulate, p.res ? 1 : 0, p.y2 ? 1 : 0, p.partial ? 1 : 0, p.cls_tap[1], p.uo ? 1 : 0, p.f16 ? 1 : 0};
+                   p.ldx, p.ldy, p.accumulate, p.res ? 1 : 0, p.y2 ? 1 : 0, p.partial ? 1 : 0, p.cls_tap[1], p.uo ? 1 : 0, p.f16 ? 1 : 0, p.kreal};
   uint64_t h = 1469598103934665603ull;
   for (int v : f) { h ^= (uint64_t)(uint32_t)v; h *= 1099511628211ull; }
   return h;
@@ -1566,7 +1571,13 @@ static ConvCfg tune_cfg_impl(ConvParams& p, hipStream_t stream) {
       if (ms5 < a * 0.97f) { a = b = ms5; best = d; }
     }
   }
-  if (best.ks > 1 && best.ws != 3 && best.tail == 0) {  // the other way of summing the slabs: last-arriving workgroup <-> second launch
+  for (int ws : {7, 8}) {  // the direct kernels for 2-channel inputs / outputs
+    if (!(ws == 7 ? conv_thin_k_ok(p) : conv_thin_n_ok(p)) || p.f16) continue;  // (fp16 mode: every configuration must multiply alike)
+    const ConvCfg d = {0, 0, 1, ws, 0, 0};
+    const float ms = time_cfg(p, d, 5, stream);
+    if (ms < (a < b ? a : b) * 0.97f) { a = b = ms; best = d; }
+  }
+  if (best.ks > 1 && best.ws != 3 && best.ws < 7 && best.tail == 0) {  // the other way of summing the slabs: last-arriving workgroup <-> second launch
     const ConvCfg w = best;
     for (int ks : {w.ks, w.ks / 2, w.ks / 4}) {  // the folded form sums its slabs in one workgroup: fewer slabs may suit it better
       if (ks < 2) continue;
@@ -1659,7 +1670,8 @@ int launch_conv(ConvParams& p, hipStream_t stream) {
     bool tile = false;
     for (auto& t : TILES) tile = tile || (c.bm == t[0] && c.bn == t[1]);
     if (c.ws == 3) tile = (c.bm == 4 || c.bm == 8) && (c.bn == 16 || c.bn == 32);
-    if (!tile || c.ws < 0 || c.ws > 6) {
+    if (c.ws == 7 || c.ws == 8) tile = true;  // (the direct 2-channel kernels carry no tile; eligibility is re-checked below)
+    if (!tile || c.ws < 0 || c.ws > 8) {
       c = heuristic_cfg(p);
     } else {
       const int cap = max_ksplit(p);
@@ -1676,6 +1688,10 @@ int launch_conv(ConvParams& p, hipStream_t stream) {
       g_cache[key] = c;
     } else {
       c = heuristic_cfg(p);
+      // untuned default for the 2-channel heads: the direct kernels (an order of magnitude fewer padded multiplications)
+      // (not while a test pins an implicit-GEMM tile: udet_debug_force_conv)
+      if (!g_force_bm && !p.f16 && conv_thin_n_ok(p)) c.ws = 8;
+      else if (!g_force_bm && !p.f16 && conv_thin_k_ok(p)) c.ws = 7;
     }
   }
   if (g_force_bm) { c.bm = g_force_bm; c.bn = g_force_bn; }
@@ -1689,6 +1705,8 @@ int launch_conv(ConvParams& p, hipStream_t stream) {
   if ((c.ws == 2 || c.ws == 4 || c.ws == 5 || c.ws == 6) && !dma_ok(p)) c.ws = 1;
   if (c.ws == 6 && !self_staging_tile(c.bm, c.bn)) c.ws = 2;
   if (g_force_ws == 3) { c.ws = 3; c.bm = (g_force_bm == 4) ? 4 : 8; c.bn = g_force_bn == 16 ? 16 : 32; }
+  if (g_force_ws == 7) c.ws = conv_thin_k_ok(p) ? 7 : (conv_thin_n_ok(p) ? 8 : heuristic_cfg(p).ws);
+  if ((c.ws == 7 && !conv_thin_k_ok(p)) || (c.ws == 8 && !conv_thin_n_ok(p)) || ((c.ws == 7 || c.ws == 8) && p.f16)) c = heuristic_cfg(p);
   if (c.ws == 3 && !tile_ok(p, c.bm, c.bn == 16 ? 16 : 32)) { c = heuristic_cfg(p); }
   g_last_cfg = (c.ws & 0xff) | ((c.bm & 0xfff) << 8) | ((c.ks & 0xff) << 20) | ((c.ks > 1 && c.fold && c.ws != 3 && p.tickets ? 1 : 0) << 28) |
                ((c.ks > 1 && c.tail > 0 ? 1 : 0) << 29);

@@ -1,0 +1,239 @@
+// Direct (non-MFMA) convolution kernels for the two degenerate GEMM shapes of the path: the 2-channel heads.
+//
+// Every flow / up_feat / upflow head of PWC-Net and of the recover decoder (models/PWCNet/model_pwcnet.py:283-286,503-506;
+// models/nets.py:81-107) has TWO output channels over a deep input (50 .. 664 channels), and its backward-data pass has two
+// INPUT channels and a wide output.  On the matrix cores both are 2 useful columns (rows) of a 32-wide tile; the step ran them as
+// a 1x1 GEMM over (tap, channel) columns + a gather pass (two or three launches, the 5x5 head 92 us) and as K = 36 .. 100 implicit
+// GEMMs at 1 - 15 TFLOP/s.  Here:
+//   conv_thin_n_kernel  (N <= 2 outputs): a workgroup stages the input halo of its 8x32 (4x64) output pixels once per block of 32
+//                       channels as [channel][pixel] in LDS; a thread owns one output pixel and walks taps x channels with one
+//                       conflict-free ds_read_b32 and two FMAs whose weight operands are SCALAR loads (the weights of a
+//                       (tap, channel) are the same for every pixel).  The four output-parity classes of a transposed head share the
+//                       staged tile.  Bound by the LDS read rate: 25 taps x 50 channels on 221 k pixels in ~20 us.
+//   conv_thin_k_kernel  (K <= 2 real input channels, wide output): a lane owns one OUTPUT channel and keeps its (tap, k) weights in
+//                       registers; a wave walks pixels, whose 2-channel input window comes from a small LDS tile by broadcast
+//                       reads.  Stores are 256-byte rows.  Bound by the output traffic.
+// Same ConvParams contract and epilogue as the implicit-GEMM kernels; selected by launch_conv (families 7 / 8), verified against the
+// implicit-GEMM result by the autotuner like every other family.
+#include "common.h"
+
+namespace udet {
+
+__device__ __forceinline__ void thin_epilogue(const ConvParams& p, int off, int n, float v) {
+  if (p.bias) v += p.bias[n];
+  v = act_fwd(v, p.act, p.alpha);
+  if (p.y2) p.y2[(size_t)off * p.ldy2 + p.y2_coff + n] = v;
+  if (p.res) v += p.res[(size_t)off * p.ldres + p.res_coff + n];
+  float* dst = p.y + (size_t)off * p.ldy + p.y_coff + n;
+  if (p.accumulate) v += *dst;
+  *dst = v;
+  if (p.uo && n >= p.u_c0 && n < p.u_c1)
+    p.uo[(size_t)off * p.ldu + p.u_coff + n] = v * act_dfo(p.ua[(size_t)off * p.ldua + p.ua_coff + n], p.uact, p.ualpha);
+}
+
+struct ThinGeom {
+  int min_dy, min_dx, PH, PW;  // halo tile of one workgroup on the (logical) input grid
+};
+static void thin_geom(const ConvParams& p, int th, int tw, ThinGeom* g) {
+  int mn_y = 0, mx_y = 0, mn_x = 0, mx_x = 0;
+  for (int t = 0; t < p.ntaps; ++t) {
+    if (t == 0 || p.taps[t].dy < mn_y) mn_y = p.taps[t].dy;
+    if (t == 0 || p.taps[t].dy > mx_y) mx_y = p.taps[t].dy;
+    if (t == 0 || p.taps[t].dx < mn_x) mn_x = p.taps[t].dx;
+    if (t == 0 || p.taps[t].dx > mx_x) mx_x = p.taps[t].dx;
+  }
+  g->min_dy = mn_y; g->min_dx = mn_x;
+  g->PH = (th - 1) * p.isy + (mx_y - mn_y) + 1;
+  g->PW = (tw - 1) * p.isx + (mx_x - mn_x) + 1;
+}
+
+// ------------------------------------------------------------------------------------------------------------ thin N ----
+#define THIN_CB 32  // channels staged per pass
+template <int TH>
+__global__ __launch_bounds__(256) void conv_thin_n_kernel(const ConvParams p, const ThinGeom g) {
+  constexpr int TW = 256 / TH;
+  extern __shared__ __attribute__((aligned(16))) float xs_[];  // [THIN_CB][PIXP] input tile | [ntaps][THIN_CB] float2 weights
+  const int PIX = g.PH * g.PW, PIXP = PIX | 1;
+  float2* ws_ = reinterpret_cast<float2*>(xs_ + (((size_t)THIN_CB * PIXP + 1) & ~(size_t)1));
+  const int t = threadIdx.x, ty = t / TW, tx = t - ty * TW;
+  const int tiles_x = (p.OWq + TW - 1) / TW, tiles_y = (p.OHq + TH - 1) / TH;
+  const int bid = blockIdx.x;
+  const int bx = bid % tiles_x, by = (bid / tiles_x) % tiles_y, n = bid / (tiles_x * tiles_y);
+  const int oy0 = by * TH, ox0 = bx * TW;
+  const int iy0 = oy0 * p.isy + g.min_dy, ix0 = ox0 * p.isx + g.min_dx;
+  const int Hs = p.H >> p.up_shift, Ws = p.W >> p.up_shift;
+  const float* xb = p.x + (size_t)n * Hs * Ws * p.ldx + p.x_coff;
+  const int ncls = p.ncls > 1 ? 4 : 1;
+  const int base = (ty * p.isy) * g.PW + tx * p.isx;
+  float acc[4][2];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) acc[c][0] = acc[c][1] = 0.f;
+
+  for (int c0 = 0; c0 < p.Kc; c0 += THIN_CB) {
+    const int cw = p.Kc - c0 < THIN_CB ? p.Kc - c0 : THIN_CB, cq = cw >> 2;
+    __syncthreads();  // the previous pass's reads are done
+    for (int e = t; e < PIX * cq; e += 256) {
+      const int pix = e / cq, c4 = e - pix * cq;
+      const int py = pix / g.PW, px = pix - py * g.PW;
+      const int iy = iy0 + py, ix = ix0 + px;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+        v = *reinterpret_cast<const float4*>(xb + (size_t)((iy >> p.up_shift) * Ws + (ix >> p.up_shift)) * p.ldx + c0 + c4 * 4);
+      float* d = xs_ + (size_t)(c4 * 4) * PIXP + pix;
+      d[0] = v.x; d[PIXP] = v.y; d[2 * PIXP] = v.z; d[3 * PIXP] = v.w;
+    }
+    // this pass's weights: every lane reads the same (tap, channel) pair at a time -- LDS broadcast reads, not 2 global loads per
+    // multiply-add (the compiler does not turn the uniform global loads into scalar loads)
+    for (int e = t; e < p.ntaps * cw; e += 256) {
+      const int tap = e / cw, ci = e - tap * cw;
+      const float* wr = p.wp + ((size_t)p.taps[tap].widx * p.Kc + c0 + ci) * p.ldw;
+      ws_[tap * THIN_CB + ci] = make_float2(wr[0], p.Cout > 1 ? wr[1] : 0.f);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int cls = 0; cls < 4; ++cls) {
+      if (cls >= ncls) break;
+      const int t0 = p.cls_tap[cls], t1 = p.cls_tap[cls + 1];
+      float a0 = acc[cls][0], a1 = acc[cls][1];
+      for (int tap = t0; tap < t1; ++tap) {
+        const float* xr = xs_ + base + (p.taps[tap].dy - g.min_dy) * g.PW + (p.taps[tap].dx - g.min_dx);
+        const float2* wr = ws_ + tap * THIN_CB;
+#pragma unroll 8
+        for (int ci = 0; ci < cw; ++ci) {
+          const float a = xr[(size_t)ci * PIXP];
+          const float2 w = wr[ci];
+          a0 = fmaf(a, w.x, a0);
+          a1 = fmaf(a, w.y, a1);
+        }
+      }
+      acc[cls][0] = a0; acc[cls][1] = a1;
+    }
+  }
+  const int oy = oy0 + ty, ox = ox0 + tx;
+  if (oy >= p.OHq || ox >= p.OWq) return;
+#pragma unroll
+  for (int cls = 0; cls < 4; ++cls) {
+    if (cls >= ncls) break;
+    const int ooy = p.ncls > 1 ? (cls >> 1) : p.ooy, oox = p.ncls > 1 ? (cls & 1) : p.oox;
+    const int off = (n * p.OH + oy * p.osy + ooy) * p.OW + ox * p.osx + oox;
+    thin_epilogue(p, off, 0, acc[cls][0]);
+    if (p.Cout > 1) thin_epilogue(p, off, 1, acc[cls][1]);
+  }
+}
+
+static size_t thin_n_lds(const ConvParams& p, const ThinGeom& g) {
+  const size_t pixp = (size_t)(g.PH * g.PW) | 1;
+  return (((size_t)THIN_CB * pixp + 1) & ~(size_t)1) * sizeof(float) + (size_t)p.ntaps * THIN_CB * sizeof(float2);
+}
+// tile height: 4 (256 threads = 4 x 64) once 8 x 32 tiles would leave CUs idle, provided that wider halo tile still fits the LDS
+static bool thin_n_pick(const ConvParams& p, int* th, ThinGeom* g) {
+  const long t8 = (long)p.N * ((p.OHq + 7) / 8) * ((p.OWq + 31) / 32);
+  for (int cand : {(t8 < 512 && p.OWq > 32) ? 4 : 8, 8}) {
+    thin_geom(p, cand, 256 / cand, g);
+    if (thin_n_lds(p, *g) <= 64 * 1024) { *th = cand; return true; }
+  }
+  return false;
+}
+bool conv_thin_n_ok(const ConvParams& p) {
+  if (p.Cout > 2 || p.Cout < 1 || p.xa != nullptr || p.Kc % 4 || p.ldw < 2 || p.ntaps < 1 || p.isy != p.isx || p.isy < 1 || p.isy > 2) return false;
+  ThinGeom g;
+  int th;
+  return thin_n_pick(p, &th, &g);
+}
+int launch_conv_thin_n(const ConvParams& p, hipStream_t stream) {
+  ThinGeom g;
+  int th = 0;
+  if (!conv_thin_n_ok(p) || !thin_n_pick(p, &th, &g)) { set_error("conv_thin_n: launch not eligible"); return UDET_ERR_UNSUPPORTED; }
+  const int tw = 256 / th;
+  const size_t lds = thin_n_lds(p, g);
+  const int tiles = p.N * ((p.OHq + th - 1) / th) * ((p.OWq + tw - 1) / tw);
+  if (th == 8) UDET_LAUNCH(conv_thin_n_kernel<8>, dim3(tiles), dim3(256), lds, stream, p, g);
+  else UDET_LAUNCH(conv_thin_n_kernel<4>, dim3(tiles), dim3(256), lds, stream, p, g);
+  UDET_HIP(hipGetLastError());
+  return UDET_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------ thin K ----
+// T: tap capacity (the launch has ntaps <= T), two real input channels.  Tile: 8 x 16 output pixels per workgroup and one block of
+// 64 output channels; wave w walks tile rows 2w, 2w+1.
+template <int T>
+__global__ __launch_bounds__(256) void conv_thin_k_kernel(const ConvParams p, const ThinGeom g) {
+  constexpr int TH = 8, TW = 16;
+  extern __shared__ __attribute__((aligned(16))) float xs_[];  // [PIX] float2
+  float2* xs = reinterpret_cast<float2*>(xs_);
+  const int PIX = g.PH * g.PW;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int tiles_x = (p.OWq + TW - 1) / TW, tiles_y = (p.OHq + TH - 1) / TH;
+  const int bid = blockIdx.x;
+  const int bx = bid % tiles_x, by = (bid / tiles_x) % tiles_y, n = bid / (tiles_x * tiles_y);
+  const int oy0 = by * TH, ox0 = bx * TW;
+  const int iy0 = oy0 + g.min_dy, ix0 = ox0 + g.min_dx;
+  const float* xb = p.x + (size_t)n * p.H * p.W * p.ldx + p.x_coff;
+  const int co = blockIdx.y * 64 + lane;
+  // this lane's weights: w[t][k] = Wp[widx_t][k][co]
+  float w[T][2];
+  int toff[T];
+#pragma unroll
+  for (int i = 0; i < T; ++i) {
+    const bool on = i < p.ntaps && co < p.ldw;
+    const float* src = p.wp + ((size_t)(i < p.ntaps ? p.taps[i].widx : 0) * p.Kc) * p.ldw + (co < p.ldw ? co : 0);
+    w[i][0] = on ? src[0] : 0.f;
+    w[i][1] = on ? src[p.ldw] : 0.f;
+    toff[i] = i < p.ntaps ? (p.taps[i].dy - g.min_dy) * g.PW + (p.taps[i].dx - g.min_dx) : 0;
+  }
+  for (int pix = t; pix < PIX; pix += 256) {
+    const int py = pix / g.PW, px = pix - py * g.PW;
+    const int iy = iy0 + py, ix = ix0 + px;
+    float2 v = make_float2(0.f, 0.f);
+    if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) v = *reinterpret_cast<const float2*>(xb + (size_t)(iy * p.W + ix) * p.ldx);
+    xs[pix] = v;
+  }
+  __syncthreads();
+  if (co >= p.Cout) return;
+  for (int r = 0; r < 2; ++r) {
+    const int ty = wave * 2 + r, oy = oy0 + ty;
+    if (oy >= p.OHq) break;
+    // four neighbouring pixels at a time: eight independent accumulation chains hide the multiply-add and LDS latencies
+    for (int tx = 0; tx < TW; tx += 4) {
+      if (ox0 + tx >= p.OWq) break;
+      const float2* xr = xs + ty * g.PW + tx;
+      float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < T; ++i) {
+        const float2* q = xr + toff[i];  // same address in every lane: broadcast reads
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float2 v = q[u];
+          a0[u] = fmaf(v.x, w[i][0], a0[u]);
+          a1[u] = fmaf(v.y, w[i][1], a1[u]);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (ox0 + tx + u < p.OWq)
+          thin_epilogue(p, (n * p.OH + oy * p.osy + p.ooy) * p.OW + (ox0 + tx + u) * p.osx + p.oox, co, a0[u] + a1[u]);
+    }
+  }
+}
+
+bool conv_thin_k_ok(const ConvParams& p) {
+  const int kr = p.kreal > 0 ? p.kreal : p.Kc;
+  if (kr != 2 || p.Kc < 2 || p.ldx % 2 || p.x_coff % 2 || (reinterpret_cast<uintptr_t>(p.x) & 7)) return false;
+  if (p.ncls == 4 || p.isy != 1 || p.isx != 1 || p.up_shift || p.xa != nullptr || p.ntaps < 1 || p.ntaps > 25 || p.Cout < 32) return false;
+  ThinGeom g;
+  thin_geom(p, 8, 16, &g);
+  return (size_t)g.PH * g.PW * sizeof(float2) <= 32 * 1024;
+}
+int launch_conv_thin_k(const ConvParams& p, hipStream_t stream) {
+  if (!conv_thin_k_ok(p)) { set_error("conv_thin_k: launch not eligible"); return UDET_ERR_UNSUPPORTED; }
+  ThinGeom g;
+  thin_geom(p, 8, 16, &g);
+  const size_t lds = (size_t)g.PH * g.PW * sizeof(float2);
+  const dim3 grid(p.N * ((p.OHq + 7) / 8) * ((p.OWq + 15) / 16), (p.Cout + 63) / 64);
+  if (p.ntaps <= 9) UDET_LAUNCH(conv_thin_k_kernel<9>, grid, dim3(256), lds, stream, p, g);
+  else UDET_LAUNCH(conv_thin_k_kernel<25>, grid, dim3(256), lds, stream, p, g);
+  UDET_HIP(hipGetLastError());
+  return UDET_OK;
+}
+
+}  // namespace udet

@@ -135,7 +135,19 @@ static int run_fwd(Plan* P, const Layer& L, int N, float* ws, const Lane& ln, si
   // (the measurement pass books the multiply-adds the launch executes: 16 of the reference's 36 tap products per low-resolution
   // pixel for the up-sampling layers)
   prof_begin(P, PROF_CONV_FWD, layer_flops(L, N) * ((L.up && L.wu_off) ? 4.0 / 9.0 : 1.0), 0, s, L.name.c_str());
-  if (L.col2im && (!L.transposed || ncls == 1) && x_extra == 0 && y_extra == 0) {
+  // 2-channel heads: the direct kernel (conv_thin.hip) through the ordinary launch below wherever it is eligible; otherwise
+  // (fp16 mode) the GEMM + gather formulation
+  bool direct_head = false;
+  if (L.col2im && !P->cfg.conv_fp16 && L.Kc <= 64) {  // (deep inputs: the 1x1 GEMM already reads them at the memory rate)
+    ConvParams q;
+    memset(&q, 0, sizeof(q));
+    if (L.transposed) (void)conv_setup_dgrad(q, 0, N, 2 * L.H, 2 * L.W, L.kh, L.kw, 2, 1);
+    else conv_setup_fwd(q, N, L.H, L.W, L.kh, L.kw, L.stride, L.dil);
+    q.Kc = L.Kc; q.ldw = L.ldw; q.Cout = L.cout;
+    if (q.ncls != 4) { q.ncls = 1; q.cls_tap[0] = 0; q.cls_tap[1] = q.ntaps; }
+    direct_head = conv_thin_n_ok(q);
+  }
+  if (L.col2im && !direct_head && (!L.transposed || ncls == 1) && x_extra == 0 && y_extra == 0) {
     // 2-channel head: the (tap, output channel) pairs become the N axis of ONE 1x1 GEMM over the deep channel axis
     // (every input byte read once, no 16x padding of the MFMA columns per tap), then a gather-sum over the taps
     const Buf& bz = P->buf(L.zbuf);
@@ -210,7 +222,7 @@ static int run_dgrad(Plan* P, const Layer& L, int N, int dy, bool dy_is_du, int 
     else if (!conv_setup_dgrad(p, cls, N, L.H << up, L.W << up, L.kh, L.kw, L.stride, L.dil)) continue;
     p.x = ws + bdy.off; p.ldx = bdy.ld; p.x_coff = L.y_coff;
     if (L.act != ACT_NONE && !dy_is_du) { p.xa = ws + ba.off; p.xact = L.act; p.xalpha = L.alpha; }
-    p.wp = ws + (upeff ? L.wuT_off : L.wpT_off); p.Kc = L.KcT; p.ldw = L.ldwT;
+    p.wp = ws + (upeff ? L.wuT_off : L.wpT_off); p.Kc = L.KcT; p.ldw = L.ldwT; p.kreal = L.cout;
     p.y = ws + bdx.off; p.ldy = bdx.ld; p.y_coff = dx_coff; p.Cout = L.cin;
     p.accumulate = accumulate;
     if (res >= 0) { p.res = ws + P->buf(res).off; p.ldres = P->buf(res).ld; p.res_coff = 0; }
