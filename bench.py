@@ -149,7 +149,7 @@ def main():
                     "after the headline region; 0 skips that extra measurement")
     ap.add_argument("--ensemble-frames", type=int, default=12, help="frames of the configs[3] ensemble workload timed after the headline "
                     "region (extra field `ensemble`); 0 skips it")
-    ap.add_argument("--pmc-json", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_step.json"),
+    ap.add_argument("--pmc-json", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_step.json"),
                     help="PMC counters of whole steps collected offline with tools/pmc_step.py (separate rocprofv3 --pmc passes); fills "
                          "roofline.traffic with the convolution kernels' HBM bytes per step")
     args = ap.parse_args()
@@ -379,7 +379,7 @@ def main():
         if args.pmc_json and os.path.exists(args.pmc_json):
             with open(args.pmc_json) as f:
                 pmc = json.load(f)
-            conv = ("conv_igemm", "conv_tile", "conv_wgrad", "wgrad_reduce", "conv_splitk_epilogue", "tap_gather", "bn_dot", "bn_finish")
+            conv = ("conv_igemm", "conv_tile", "conv_thin", "conv_wgrad", "wgrad_reduce", "conv_splitk_epilogue", "tap_gather", "bn_dot", "bn_finish")
             fam = [k for k in pmc.get("kernel_families", []) if any(c in k["kernel"] for c in conv)]
             if "traffic_bytes_per_launch" in pmc:  # tools/pmc_report.py: one launch
                 traffic = pmc["traffic_bytes_per_launch"]
@@ -395,7 +395,8 @@ def main():
         peak_tf = 2500.0 if args.fp16_convs else PEAK_FP32_MFMA_TFLOPS  # dense MFMA peak of the multiplication dtype (MI355X_MICROARCH.md)
         roofline = {"bound": "mfma",
                     "kernel": "conv_igemm_dma_kernel / conv_igemm_kernel / conv_tile_kernel / conv_wgrad_kernel (v_mfma_f32_32x32x2_f32, "
-                              "16x16x4 for <=16 output channels): every convolution launch of one step, executed serially; duration = "
+                              "16x16x4 for <=16 output channels; conv_thin_* direct kernels for the 2-channel heads): every convolution "
+                              "launch of one step, executed serially; duration = "
                               "the launch's own start -> stop HIP events (carried by its dispatch packet on the launch stream: the "
                               "kernel execution time rocprofv3 --kernel-trace reports)",
                     "achieved": round(achieved, 2), "peak": peak_tf, "unit": "TFLOP/s",
