@@ -64,8 +64,11 @@ def test_pipelined_and_concurrent_steps_are_bit_identical_to_serial(monkeypatch)
     pairs = [((torch.rand(2, 128, 192, 3, generator=gen) - 0.5).cuda(), (torch.rand(2, 128, 192, 3, generator=gen) - 0.5).cuda())
              for _ in range(3)]
 
-    def run(pipelined):
-        st = TrainState(Engine(cfg), seed=5)
+    def run(pipelined, concurrent=None):
+        eng = Engine(cfg)
+        if concurrent is not None:
+            eng.set_concurrent(concurrent)  # udet_plan_set_concurrent: the documented switch (UDET_SERIAL only sets its initial value)
+        st = TrainState(eng, seed=5)
         for i, (a, b) in enumerate(pairs):
             nxt = pairs[i + 1] if (pipelined and i + 1 < len(pairs)) else None
             train_step(st, a, b, BOTH, next_pair=nxt)
@@ -78,3 +81,6 @@ def test_pipelined_and_concurrent_steps_are_bit_identical_to_serial(monkeypatch)
     g1, r1, l1 = run(True)
     assert torch.equal(g0, g1) and torch.equal(r0, r1)
     assert l0 == l1
+    g2, r2, l2 = run(False, concurrent=False)   # the same through the API, on a plan created concurrent
+    g3, r3, l3 = run(True, concurrent=True)
+    assert torch.equal(g0, g2) and torch.equal(r0, r2) and torch.equal(g0, g3) and torch.equal(r0, r3) and l0 == l2 == l3
