@@ -53,9 +53,10 @@ def allreduce_mean_(t: torch.Tensor, group=None, async_op=False):
     import torch.distributed as dist
     if group is False or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return None  # group=False: this process trains alone even though a process group exists (reference runs of the tests)
-    if dist.get_backend(group) == "nccl":
-        return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group, async_op=async_op)
-    work = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=False)  # (gloo has no AVG)
+    # SUM + one in-place division on every backend (gloo has no AVG; on RCCL the extra elementwise pass over the 19 MB payload costs
+    # ~10 us and keeps ONE code path that the one-GPU gloo tests execute end to end).  Every rank divides the same sum by the same
+    # count: replicas stay bit-identical.
+    work = dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group, async_op=False)
     t.div_(dist.get_world_size(group))
     return work if async_op else None
 
