@@ -140,6 +140,9 @@ def main():
                     "not a reference capability -- parity tolerance 2e-2.  The default run is the fp32 headline.")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU-oracle leg (and with it the parity check)")
     ap.add_argument("--no-pipeline", action="store_true", help="no cross-step prefetch of the PWC flow (every step serial in itself)")
+    ap.add_argument("--extra-streams", type=int, default=0, help="robustness probe: create (and use once) this many PyTorch streams before "
+                    "the plan is built, which shifts ROCm's stream -> hardware-queue assignment the way a process group's streams do; the "
+                    "plan's lane placement (udet_plan_lane_queues) must keep the step time unchanged")
     ap.add_argument("--no-autotune", action="store_true", help="use the built-in tile heuristics instead of the one-off autotune pass")
     ap.add_argument("--tune-cache", default="", help="file of tuned configurations: loaded when it exists (no tuning pass), written otherwise")
     ap.add_argument("--trace-only", action="store_true", help="warm-up + timed steps and nothing else (for rocprofv3 kernel traces: "
@@ -187,6 +190,11 @@ def main():
     from unsupervised_detection_amd.engine import BOTH, Engine, EngineConfig
     from unsupervised_detection_amd.trainer import TrainState, allreduce_mean_, train_step
 
+    extra_streams = [torch.cuda.Stream() for _ in range(args.extra_streams)]
+    for s_ in extra_streams:
+        with torch.cuda.stream(s_):
+            torch.zeros(16, device="cuda").add_(1.0)
+    torch.cuda.synchronize()
     eng = Engine(EngineConfig(batch_size=args.batch, conv_fp16=args.fp16_convs), device=f"cuda:{local_rank}")
     loaded = 0
     if args.tune_cache and os.path.exists(args.tune_cache):
@@ -248,6 +256,7 @@ def main():
     for _ in range(args.warmup):
         run_step()
     barrier()
+    lane_nq, lane_q = eng.lane_queues()  # (placed by the first warm-up step on this stream; this call only reads the layout)
     stage("warm-up done")
     # per-step completion events on the stream every launch of the step is issued from (the plan's side streams are joined to
     # it before the optimizer applies): step k's duration = event k - event k-1 -> the distribution behind the mean
@@ -441,6 +450,7 @@ def main():
             "ms_per_step_median": round(pct(0.5), 3), "ms_per_step_p95": round(pct(0.95), 3), "ms_per_step_min": round(step_ms[0], 3),
             "ms_per_step_max": round(step_ms[-1], 3), "value_at_median": round(args.batch * world / (pct(0.5) * 1e-3), 3),
             "resident_batches": NPAIRS,
+            "lanes": {"hardware_queues_in_use": lane_nq, "queue_of_lane": lane_q, "extra_streams": args.extra_streams},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16 x f16 -> f32 in the convolution MFMAs (fp32 tensors, losses, reductions, optimizer)" if args.fp16_convs else "f32",
             "data": "synthetic (DAVIS-480p-shaped pairs, reader preprocessing applied before timing; random-init weights)",

@@ -303,6 +303,18 @@ int udet_profile_end(udet_plan* plan, double* out, int ncat, void* stream);
  * Kernel-selection forcing for tests lives in a separate library (include/udet_debug.h, libudet_debug.so). */
 int udet_plan_set_concurrent(udet_plan* plan, int on);
 
+/* Lane placement.  ROCm maps every stream of a process onto one of GPU_MAX_HW_QUEUES (default 4) hardware queues when the stream is
+ * created, and two streams on one queue execute in submission order -- which lanes of a plan share a queue changes the step time by up
+ * to 20 % and depends on every other stream the process (PyTorch's pool, RCCL) created before.  A plan therefore owns eight candidate
+ * streams and, the first time it is driven from a given caller stream, probes (a 40 us spin kernel on one stream, an empty kernel on
+ * the other) which candidates run concurrently with the caller's stream and with each other, then lays its six lanes out on
+ * four independent queues: {0 = the caller's stream, 2} {1} {3} {4, 5}; with fewer independent queues lanes are merged.  That first
+ * call synchronises the device once (~3 ms).  udet_plan_lane_queues places the lanes for `stream` if that has not happened yet and
+ * writes the queue-group index of each of the six lanes (0 = the caller's queue) to queue[6]; returns the number of independent
+ * queues in use (4 on a default runtime), < 0 on error.  Do not raise GPU_MAX_HW_QUEUES: above four queues a cross-stream dependency
+ * costs 79 us instead of 12 (profiles/r03_hop_bench.txt). */
+int udet_plan_lane_queues(udet_plan* plan, void* stream, int* queue);
+
 #ifdef __cplusplus
 }
 #endif

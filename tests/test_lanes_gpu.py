@@ -1,0 +1,33 @@
+"""GPU: lane placement (include/udet.h: udet_plan_lane_queues).  ROCm assigns streams to its four hardware queues in creation order,
+so which lanes of a plan can overlap depends on every stream the process created before; the plan probes that and lays its lanes out
+on four independent queues whatever the process did earlier."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+LAYOUT = [0, 1, 0, 2, 3, 3]  # {caller's stream, lane 2} {1} {3} {4, 5}
+
+
+def small_engine():
+    from unsupervised_detection_amd.engine import Engine, EngineConfig
+    return Engine(EngineConfig(batch_size=1, in_height=64, in_width=128, img_height=64, img_width=64))
+
+
+@pytest.mark.parametrize("extra", [0, 1, 2, 3, 5])
+def test_lanes_sit_on_four_independent_queues_whatever_streams_exist(extra):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    keep = [torch.cuda.Stream() for _ in range(extra)]  # shifts the least-referenced-queue assignment of every later stream
+    for s in keep:
+        with torch.cuda.stream(s):
+            torch.zeros(8, device="cuda").add_(1.0)
+    torch.cuda.synchronize()
+    eng = small_engine()
+    for caller in (torch.cuda.current_stream(), torch.cuda.Stream(), torch.cuda.Stream()):
+        with torch.cuda.stream(caller):
+            n, q = eng.lane_queues()
+        assert n == 4, "expected ROCm's default of four hardware queues (is GPU_MAX_HW_QUEUES set?)"
+        assert q == LAYOUT
+    with torch.cuda.stream(caller):  # cached: the same answer, no new probe
+        assert eng.lane_queues() == (4, LAYOUT)

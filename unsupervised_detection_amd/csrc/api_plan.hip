@@ -53,10 +53,13 @@ int udet_buffer_info(const udet_plan* h, int i, const char** name, size_t* offse
 int udet_plan_set_concurrent(udet_plan* h, int on) {
   if (!h) { set_error("plan_set_concurrent: null plan"); return UDET_ERR_ARG; }
   if (on)
-    for (auto st : h->p->side)
-      if (!st) { set_error("plan_set_concurrent: the plan has no side streams"); return UDET_ERR_UNSUPPORTED; }
+    if (!h->p->cand[0]) { set_error("plan_set_concurrent: the plan has no side streams"); return UDET_ERR_UNSUPPORTED; }
   h->p->concurrent = on != 0;
   return UDET_OK;
+}
+int udet_plan_lane_queues(udet_plan* h, void* stream, int* queue) {
+  if (!h || !queue) { set_error("plan_lane_queues: null argument"); return UDET_ERR_ARG; }
+  return plan_lane_queues(h->p, (hipStream_t)stream, queue);
 }
 long udet_fp16_overflow_count(udet_plan* h) {
   (void)plan_check_overflow(h->p, true);  // (the error text stays in udet_last_error; the count is the answer here)

@@ -1,0 +1,46 @@
+// Which of a process's streams can actually run side by side?  ROCm maps every stream onto one of GPU_MAX_HW_QUEUES (default 4)
+// hardware queues when the stream is created (least-referenced queue first); two streams on one queue execute in submission order.
+// The probe: a ~40 us spin kernel on `a`, then an empty kernel on `b`; `b`'s kernel finishing before `a`'s spin means different queues.
+#include "lanes.h"
+
+#include "common.h"
+
+namespace udet {
+
+__global__ void lane_spin_kernel(long ticks) {
+  const long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) {}
+}
+__global__ void lane_noop_kernel() {}
+
+int streams_concurrent(hipStream_t a, hipStream_t b, bool* concurrent) {
+  *concurrent = false;
+  if (a == b) return UDET_OK;
+  hipEvent_t e0 = nullptr, ea = nullptr, eb = nullptr;
+  UDET_HIP(hipEventCreate(&e0));
+  UDET_HIP(hipEventCreate(&ea));
+  UDET_HIP(hipEventCreate(&eb));
+  static bool warm = false;  // (the first launch of a kernel resolves its code object: not inside the timed window)
+  if (!warm) {
+    lane_spin_kernel<<<1, 64, 0, a>>>(1);
+    lane_noop_kernel<<<1, 64, 0, b>>>();
+    warm = true;
+  }
+  UDET_HIP(hipStreamSynchronize(a));
+  UDET_HIP(hipStreamSynchronize(b));
+  UDET_HIP(hipEventRecord(e0, a));
+  lane_spin_kernel<<<1, 64, 0, a>>>(4000);  // wall_clock64 ticks at 100 MHz
+  UDET_HIP(hipEventRecord(ea, a));
+  lane_noop_kernel<<<1, 64, 0, b>>>();
+  UDET_HIP(hipEventRecord(eb, b));
+  UDET_HIP(hipEventSynchronize(ea));
+  UDET_HIP(hipEventSynchronize(eb));
+  float ta = 0.f, tb = 0.f;
+  UDET_HIP(hipEventElapsedTime(&ta, e0, ea));
+  UDET_HIP(hipEventElapsedTime(&tb, e0, eb));
+  *concurrent = tb < 0.6f * ta;
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(ea); (void)hipEventDestroy(eb);
+  return UDET_OK;
+}
+
+}  // namespace udet

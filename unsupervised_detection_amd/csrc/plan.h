@@ -78,8 +78,22 @@ struct Plan {
   size_t arena_floats = 0;       // everything
   // Concurrency: independent chains of the step run on side streams forked from / joined to the caller's stream
   // with events (lane 0 = the caller's stream).  Every lane owns its split-K and wgrad scratch.
-  enum { NLANE = 6 };
-  hipStream_t side[NLANE - 1] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  // Lane placement: ROCm maps a process's streams onto GPU_MAX_HW_QUEUES (4) hardware queues in creation order, two streams on one
+  // queue execute in submission order, and which lanes share a queue decides 11.1 vs 13.3 ms per step.  The plan
+  // therefore owns NCAND candidate streams and, the first time it is driven from a given caller stream, PROBES (lanes.h) which of
+  // them run concurrently with that stream and with each other; it then lays the lanes out as
+  //   {0: caller's stream, 2: the same stream} {1} {3} {4, 5}          -- four queues, the layout the step was tuned on;
+  // with fewer independent queues available lanes 3 -> 1, then 4/5 -> 1, then everything -> 0.
+  enum { NLANE = 6, NCAND = 8 };
+  hipStream_t cand[NCAND] = {};
+  struct Placement {
+    hipStream_t main = nullptr;
+    hipStream_t lane[NLANE] = {};
+    int queue[NLANE] = {};  // index of the hardware-queue group the lane sits on (0 = the caller's)
+    int nqueues = 1;
+  };
+  std::vector<Placement> placements;  // one per caller stream seen so far
+  int placed = -1;                    // index of the placement in use
   hipEvent_t prefetch_ev = nullptr;  // completion of the last udet_prefetch_flow (lane 4)
   hipEvent_t grad_ev[3] = {nullptr, nullptr, nullptr};  // [net]: that network's gradient buffer is final (last udet_backward)
   bool prefetch_pending = false;
@@ -144,6 +158,7 @@ int plan_backward(Plan* P, int which, const float* w_gen, const float* w_rec, fl
 int plan_apply(Plan* P, int net, float* w, float* g, float* m, float* v, float* ws, hipStream_t s);
 // fp16 mode: reports (once) an optimizer update that was dropped because its gradients were not finite; wait: synchronise first
 int plan_check_overflow(Plan* P, bool wait);
+int plan_lane_queues(Plan* P, hipStream_t s, int* queue);  // places the lanes for `s` if necessary; returns the queues in use
 enum { PROF_CONV_FWD = 0, PROF_CONV_DGRAD = 1, PROF_CONV_WGRAD = 2, PROF_WARP = 3, PROF_CORR = 4, PROF_NCAT = 5 };
 void prof_begin(Plan* P, int cat, double flops, double bytes, hipStream_t s, const char* name = "");
 void prof_end(Plan* P, hipStream_t s);

@@ -169,7 +169,7 @@ static Layer mk_layer(int net, const std::string& name, const std::string& wname
 static size_t align64(size_t v) { return (v + 63) & ~(size_t)63; }
 
 Plan::~Plan() {
-  for (auto& st : side)
+  for (auto& st : cand)
     if (st) (void)hipStreamDestroy(st);
   for (auto& e : ev_pool) (void)hipEventDestroy(e);
   for (auto& e : ev_pool_prefetch) (void)hipEventDestroy(e);
@@ -504,9 +504,10 @@ Plan* plan_build(const Config& cfg) {
   // the caller's stream
   if (const char* e = getenv("UDET_SERIAL")) P->concurrent = atoi(e) == 0;
   // Side streams, all at the default priority (measured: any priority split between the lanes costs 4-5 ms per step).
-  for (int i = 0; i < Plan::NLANE - 1; ++i) {
-    const hipError_t rc = hipStreamCreateWithFlags(&P->side[i], hipStreamNonBlocking);
-    if (rc != hipSuccess) { P->side[i] = nullptr; P->concurrent = false; }
+  // (candidates: the lanes are placed on them at first use, see Plan::Placement)
+  for (int i = 0; i < Plan::NCAND; ++i) {
+    const hipError_t rc = hipStreamCreateWithFlags(&P->cand[i], hipStreamNonBlocking);
+    if (rc != hipSuccess) { P->cand[i] = nullptr; if (i == 0) P->concurrent = false; }
   }
   // views into the small region (read by the host wrapper)
   struct { const char* n; int a, d; size_t o; } views[4] = {{"losses", 1, 8, 0}, {"loss_coef", B, 4, 16}, {"noise_flag", 1, 2, 256},

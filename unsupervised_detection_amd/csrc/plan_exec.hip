@@ -8,6 +8,7 @@
 
 #include "conv_host.h"
 #include "elementwise.h"
+#include "lanes.h"
 #include "plan.h"
 
 namespace udet {
@@ -60,9 +61,48 @@ struct Lane {
   hipStream_t s;
   int slot;
 };
+// first use from `main`: find candidate streams that run concurrently with it and with each other (one probe each, ~0.1 ms; the
+// device is synchronised once) and lay the lanes out on them -- see Plan::Placement
+static const Plan::Placement& place_lanes(Plan* P, hipStream_t main) {
+  if (P->placed >= 0 && P->placements[P->placed].main == main) return P->placements[P->placed];
+  for (size_t k = 0; k < P->placements.size(); ++k)
+    if (P->placements[k].main == main) { P->placed = (int)k; return P->placements[k]; }
+  (void)hipDeviceSynchronize();
+  hipStream_t pick[3] = {nullptr, nullptr, nullptr};
+  int np = 0;
+  for (int k = 0; k < Plan::NCAND && np < 3; ++k) {
+    hipStream_t c = P->cand[k];
+    bool ok = false;
+    if (!c || streams_concurrent(main, c, &ok) != UDET_OK || !ok) continue;
+    for (int j = 0; j < np && ok; ++j) {
+      bool cc = false;
+      if (streams_concurrent(pick[j], c, &cc) != UDET_OK || !cc) ok = false;
+    }
+    if (ok) pick[np++] = c;
+  }
+  Plan::Placement pl;
+  pl.main = main;
+  pl.nqueues = np + 1;
+  const int q1 = np > 0 ? 1 : 0, q3 = np > 1 ? (np > 2 ? 2 : 1) : q1, q4 = np > 2 ? 3 : (np > 1 ? 2 : q1);
+  // measured alternatives (ms per step; this one 10.90): lane 3 on lane 1's queue 11.20, lane 2 on its own queue and 3 with 1 11.12,
+  // lane 2 with 1 11.42, lane 5 with 3 10.96 / with 1 or 0 12.2, lanes 2 and 3 swapped 10.94 (profiles/r03_hop_bench.txt)
+  const int queue[Plan::NLANE] = {0, q1, 0, q3, q4, q4};
+  for (int i = 0; i < Plan::NLANE; ++i) {
+    pl.queue[i] = queue[i];
+    pl.lane[i] = queue[i] == 0 ? main : pick[queue[i] - 1];
+  }
+  P->placements.push_back(pl);
+  P->placed = (int)P->placements.size() - 1;
+  return P->placements[P->placed];
+}
 static Lane lane_of(Plan* P, hipStream_t main, int i) {
   if (i == 0 || !P->concurrent || P->profiling) return Lane{main, 0};
-  return Lane{P->side[i - 1], i};
+  return Lane{place_lanes(P, main).lane[i], i};
+}
+int plan_lane_queues(Plan* P, hipStream_t s, int* queue) {
+  const Plan::Placement& pl = place_lanes(P, s);
+  for (int i = 0; i < Plan::NLANE; ++i) queue[i] = pl.queue[i];
+  return pl.nqueues;
 }
 static hipEvent_t next_event(Plan* P) {
   std::vector<hipEvent_t>& pool = P->in_prefetch ? P->ev_pool_prefetch : P->ev_pool;

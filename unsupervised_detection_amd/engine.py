@@ -31,6 +31,8 @@ lib.udet_buffer_info.restype = c_i
 lib.udet_buffer_info.argtypes = [c_p, c_i, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(c_sz), ctypes.POINTER(c_i)]
 lib.udet_plan_set_concurrent.restype = c_i
 lib.udet_plan_set_concurrent.argtypes = [c_p, c_i]
+lib.udet_plan_lane_queues.restype = c_i
+lib.udet_plan_lane_queues.argtypes = [c_p, c_p, ctypes.POINTER(c_i)]
 lib.udet_fp16_overflow_count.restype = ctypes.c_long
 lib.udet_fp16_overflow_count.argtypes = [c_p]
 lib.udet_get_adam_step.restype = ctypes.c_long
@@ -226,6 +228,15 @@ class Engine:
     def set_concurrent(self, on: bool):
         """False: every lane of the plan collapses onto the caller's stream (plain program order, bit-identical results)."""
         check(lib.udet_plan_set_concurrent(self._h, 1 if on else 0))
+
+    def lane_queues(self):
+        """(independent hardware queues in use, queue-group index of each of the plan's six lanes) for the current stream; places the
+        lanes (a probe that synchronises the device once) if this stream has not driven the plan yet -- include/udet.h."""
+        q = (c_i * 6)()
+        n = int(lib.udet_plan_lane_queues(self._h, self._stream(), q))
+        if n < 0:
+            check(n)
+        return n, [int(v) for v in q]
 
     def fp16_overflow_count(self) -> int:
         """conv_fp16 plans: optimizer updates dropped so far because their gradients were not finite (synchronises)."""
