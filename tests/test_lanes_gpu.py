@@ -31,3 +31,13 @@ def test_lanes_sit_on_four_independent_queues_whatever_streams_exist(extra):
         assert q == LAYOUT
     with torch.cuda.stream(caller):  # cached: the same answer, no new probe
         assert eng.lane_queues() == (4, LAYOUT)
+
+
+def test_serial_plans_report_one_queue():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    eng = small_engine()
+    eng.set_concurrent(False)
+    assert eng.lane_queues() == (1, [0] * 6)
+    eng.set_concurrent(True)
+    assert eng.lane_queues() == (4, LAYOUT)

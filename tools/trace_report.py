@@ -44,6 +44,8 @@ def main():
     table, conv_ns, all_ns = [], 0.0, 0.0
     for r in rows:
         name, calls, tot = r["Name"], int(r["Calls"]), float(r["TotalDurationNs"])
+        if "lane_spin_kernel" in name or "lane_noop_kernel" in name:  # the one-off lane-placement probe (plan_exec.hip), not part of a step
+            continue
         short = name.replace("void udet::", "").replace("(udet::ConvParams)", "").replace("udet::", "")
         is_conv = any(k in name for k in CONV)
         all_ns += tot

@@ -100,6 +100,10 @@ static Lane lane_of(Plan* P, hipStream_t main, int i) {
   return Lane{place_lanes(P, main).lane[i], i};
 }
 int plan_lane_queues(Plan* P, hipStream_t s, int* queue) {
+  if (!P->concurrent) {  // every lane is the caller's stream
+    for (int i = 0; i < Plan::NLANE; ++i) queue[i] = 0;
+    return 1;
+  }
   const Plan::Placement& pl = place_lanes(P, s);
   for (int i = 0; i < Plan::NLANE; ++i) queue[i] = pl.queue[i];
   return pl.nqueues;
