@@ -305,8 +305,8 @@ int udet_plan_set_concurrent(udet_plan* plan, int on);
 
 /* Lane placement.  ROCm maps every stream of a process onto one of GPU_MAX_HW_QUEUES (default 4) hardware queues when the stream is
  * created, and two streams on one queue execute in submission order -- which lanes of a plan share a queue changes the step time by up
- * to 20 % and depends on every other stream the process (PyTorch's pool, RCCL) created before.  A plan therefore owns eight candidate
- * streams and, the first time it is driven from a given caller stream, probes (a 40 us spin kernel on one stream, an empty kernel on
+ * to 20 % and depends on every other stream the process (PyTorch's pool, RCCL) created before.  A plan therefore owns candidate
+ * streams (eight; up to 32 are drawn while fewer than three independent queues have been found) and, the first time it is driven from a given caller stream, probes (a 40 us spin kernel on one stream, an empty kernel on
  * the other) which candidates run concurrently with the caller's stream and with each other, then lays its six lanes out on
  * four independent queues: {0 = the caller's stream, 2} {1} {3} {4, 5}; with fewer independent queues lanes are merged.  That first
  * call synchronises the device once (~3 ms).  udet_plan_lane_queues places the lanes for `stream` if that has not happened yet and

@@ -53,7 +53,7 @@ int udet_buffer_info(const udet_plan* h, int i, const char** name, size_t* offse
 int udet_plan_set_concurrent(udet_plan* h, int on) {
   if (!h) { set_error("plan_set_concurrent: null plan"); return UDET_ERR_ARG; }
   if (on)
-    if (!h->p->cand[0]) { set_error("plan_set_concurrent: the plan has no side streams"); return UDET_ERR_UNSUPPORTED; }
+    if (h->p->cand.empty()) { set_error("plan_set_concurrent: the plan has no side streams"); return UDET_ERR_UNSUPPORTED; }
   h->p->concurrent = on != 0;
   return UDET_OK;
 }

@@ -80,12 +80,14 @@ struct Plan {
   // with events (lane 0 = the caller's stream).  Every lane owns its split-K and wgrad scratch.
   // Lane placement: ROCm maps a process's streams onto GPU_MAX_HW_QUEUES (4) hardware queues in creation order, two streams on one
   // queue execute in submission order, and which lanes share a queue decides 11.1 vs 13.3 ms per step.  The plan
-  // therefore owns NCAND candidate streams and, the first time it is driven from a given caller stream, PROBES (lanes.h) which of
+  // therefore owns candidate streams (NCAND at first; more are created, up to MAXCAND, while the probe has not found three
+  // independent queues -- every new stream goes to the queue with the fewest streams, so a process whose queues are unevenly
+  // loaded needs more draws) and, the first time it is driven from a given caller stream, PROBES (lanes.h) which of
   // them run concurrently with that stream and with each other; it then lays the lanes out as
   //   {0: caller's stream, 2: the same stream} {1} {3} {4, 5}          -- four queues, the layout the step was tuned on;
   // with fewer independent queues available lanes 3 -> 1, then 4/5 -> 1, then everything -> 0.
-  enum { NLANE = 6, NCAND = 8 };
-  hipStream_t cand[NCAND] = {};
+  enum { NLANE = 6, NCAND = 8, MAXCAND = 32 };
+  std::vector<hipStream_t> cand;
   struct Placement {
     hipStream_t main = nullptr;
     hipStream_t lane[NLANE] = {};

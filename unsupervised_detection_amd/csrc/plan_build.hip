@@ -506,9 +506,10 @@ Plan* plan_build(const Config& cfg) {
   // Side streams, all at the default priority (measured: any priority split between the lanes costs 4-5 ms per step).
   // (candidates: the lanes are placed on them at first use, see Plan::Placement)
   for (int i = 0; i < Plan::NCAND; ++i) {
-    const hipError_t rc = hipStreamCreateWithFlags(&P->cand[i], hipStreamNonBlocking);
-    if (rc != hipSuccess) { P->cand[i] = nullptr; if (i == 0) P->concurrent = false; }
+    hipStream_t c = nullptr;
+    if (hipStreamCreateWithFlags(&c, hipStreamNonBlocking) == hipSuccess) P->cand.push_back(c);
   }
+  if (P->cand.empty()) P->concurrent = false;
   // views into the small region (read by the host wrapper)
   struct { const char* n; int a, d; size_t o; } views[4] = {{"losses", 1, 8, 0}, {"loss_coef", B, 4, 16}, {"noise_flag", 1, 2, 256},
                                                             {"loss_sums", B, 5, 1024}};

@@ -70,10 +70,15 @@ static const Plan::Placement& place_lanes(Plan* P, hipStream_t main) {
   (void)hipDeviceSynchronize();
   hipStream_t pick[3] = {nullptr, nullptr, nullptr};
   int np = 0;
-  for (int k = 0; k < Plan::NCAND && np < 3; ++k) {
+  for (size_t k = 0; np < 3; ++k) {
+    if (k == P->cand.size()) {  // every candidate so far shares a queue with the caller or a pick: draw another stream
+      hipStream_t c = nullptr;
+      if (k >= (size_t)Plan::MAXCAND || hipStreamCreateWithFlags(&c, hipStreamNonBlocking) != hipSuccess) break;
+      P->cand.push_back(c);
+    }
     hipStream_t c = P->cand[k];
     bool ok = false;
-    if (!c || streams_concurrent(main, c, &ok) != UDET_OK || !ok) continue;
+    if (streams_concurrent(main, c, &ok) != UDET_OK || !ok) continue;
     for (int j = 0; j < np && ok; ++j) {
       bool cc = false;
       if (streams_concurrent(pick[j], c, &cc) != UDET_OK || !cc) ok = false;
