@@ -200,26 +200,8 @@ def main():
     loaded = 0
     if args.tune_cache and os.path.exists(args.tune_cache):
         loaded = max(0, int(lib.udet_tune_load(args.tune_cache.encode())))  # < 0: a file of another build -> tune again
-    # N > 1: rank 0 tunes, the other ranks load ITS configurations (one node, one /tmp): every GPU then runs the same kernels --
-    # eight independent tuning passes pick slightly different tiles for a few shapes, and the slowest rank is what a step costs
-    shared = None
-    if world > 1 and not loaded and not args.no_autotune:
-        name = [os.path.join(tempfile.gettempdir(), "udet_tune_%s_%d.txt" % (os.environ.get("MASTER_PORT", "0"), os.getpid())) if rank == 0 else None]
-        dist.broadcast_object_list(name, src=0)
-        shared = name[0]
-    st = None
-    if shared is None or rank == 0:
-        st = TrainState(eng, seed=8964, autotune=not (args.no_autotune or loaded > 0))  # identical weights on every rank; kernels autotuned once
-        if shared is not None:
-            lib.udet_tune_save(shared.encode())
-    if shared is not None:
-        dist.barrier()
-        if rank != 0:
-            loaded = max(0, int(lib.udet_tune_load(shared.encode())))
-            st = TrainState(eng, seed=8964, autotune=loaded == 0)
-        dist.barrier()
-        if rank == 0:
-            os.remove(shared)
+    # (N > 1: rank 0 tunes and the other ranks load its configurations -- TrainState._autotune_shared -- so every GPU runs the same kernels)
+    st = TrainState(eng, seed=8964, autotune=not (args.no_autotune or loaded > 0))  # identical weights on every rank; kernels autotuned once
     if args.tune_cache and not loaded and not args.no_autotune and rank == 0:
         lib.udet_tune_save(args.tune_cache.encode())
     w0 = None

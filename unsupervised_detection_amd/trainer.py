@@ -35,7 +35,41 @@ class TrainState:
         engine.pack_trainable(self.w_gen, self.w_rec)
         self._dirty = 0  # networks whose flat weights changed since their last re-layout (GEN | REC bits)
         if autotune:
-            self.tuned_shapes = engine.autotune(self.w_gen, self.w_rec, self.g_gen, self.g_rec)
+            self.tuned_shapes = self._autotune_shared()
+
+    def _autotune_shared(self) -> int:
+        """The one-off kernel autotune.  In a data-parallel job rank 0 tunes and every other rank loads ITS configurations (the text of
+        udet_tune_save, broadcast through the process group -- a collective: every rank must construct its TrainState with autotune=True):
+        all GPUs then run the same kernels.  Independent tuning passes pick different tiles for a few shapes; the slowest rank is what a
+        step costs, and the ranks' local gradients would differ in their rounding."""
+        import os
+        import tempfile
+
+        import torch.distributed as dist
+
+        from ._ffi import lib
+        e = self.engine
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return e.autotune(self.w_gen, self.w_rec, self.g_gen, self.g_rec)
+        text, n = [None], 0
+        fd, path = tempfile.mkstemp(prefix="udet_tune_", suffix=".txt")
+        os.close(fd)
+        try:
+            if dist.get_rank() == 0:
+                n = e.autotune(self.w_gen, self.w_rec, self.g_gen, self.g_rec)
+                lib.udet_tune_save(path.encode())
+                with open(path) as f:
+                    text[0] = f.read()
+            dist.broadcast_object_list(text, src=0)
+            if dist.get_rank() != 0:
+                with open(path, "w") as f:
+                    f.write(text[0])
+                n = int(lib.udet_tune_load(path.encode()))
+                if n < 0:  # (cannot happen between ranks of one build; tune locally rather than run untuned)
+                    n = e.autotune(self.w_gen, self.w_rec, self.g_gen, self.g_rec)
+        finally:
+            os.remove(path)
+        return n
 
 
 def flush_weights(st: TrainState):
