@@ -32,6 +32,7 @@ def _cfg(**kw):
     c = default_flags()
     c.img_height, c.img_width, c.batch_size = 64, 128, 2
     c.synthetic = True  # explicit opt-in: seeded random weights instead of the mandatory checkpoints
+    c.autotune = False  # (the start-up autotune is covered by tests/test_autotune_gpu.py and one training test below)
     for k, v in kw.items():
         setattr(c, k, v)
     return c

@@ -19,6 +19,9 @@ _DEFS = [
     ("synthetic", bool, False),
     # not a reference flag: BASELINE.json configs[4] -- fp16 multiplication (fp32 accumulation) in the convolution GEMMs
     ("conv_fp16", bool, False),
+    # not a reference flag: the one-off kernel autotune of the training plan at start-up (~10 s; rank 0 tunes, the other ranks of a
+    # data-parallel job load its configurations).  Untuned plans run on the built-in tile heuristics, ~10 % slower per step.
+    ("autotune", bool, True),
 ]
 
 

@@ -177,7 +177,8 @@ class AdversarialLearner(object):
         B = config.batch_size
         self.engine = Engine(_engine_config(config, B))
         self.global_step = 0
-        self.state = TrainState(self.engine, seed=getattr(config, "seed", 8964), **self._load_weights(config, "train"))
+        self.state = TrainState(self.engine, seed=getattr(config, "seed", 8964), autotune=bool(getattr(config, "autotune", False)),
+                                **self._load_weights(config, "train"))
         n_params = sum(W.param_total(n) for n in (W.NET_PWC, W.NET_GEN, W.NET_REC))
         print("Number of params: {}".format(n_params))
         # data parallel: every step consumes batch_size pairs on each of `world` ranks (cli.py shards the pair table), so an
