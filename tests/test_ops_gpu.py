@@ -182,6 +182,7 @@ THIN_CASES = [
     (1, 30, 50, 16, 16, 3, 1),    # ragged: 50 = 32 + 18 columns, 30 rows; partial tiles on both axes
     (2, 13, 37, 32, 32, 5, 1),    # odd sizes, 5x5
     (1, 31, 47, 32, 64, 3, 2),    # odd grid, stride 2: backward-data falls back to one launch per parity class
+    (1, 24, 64, 32, 194, 4, 1),   # the backward-data view of recover deconv2: 194 output columns = seven 32-column blocks
 ]
 
 
@@ -228,8 +229,8 @@ def test_conv_kernel_families(ops, force_conv, family, case):
     assert (got - y.detach().float()).abs().max() < 1e-4 * max(1.0, float(y.abs().max()))
     # backward-data of the linear layer (no act' on load: the form the step uses, dU being materialised by its producer)
     dx = ops.conv2d_backward_data(dy.float().cuda(), lin.detach().float().cuda(), wt.float().cuda(), (h, w), s, 1, "none", 0.0).cpu()
-    # backward-data: K = cout, N = cin (at most 64 columns in the tile-resident kernel), stride-1 walk over the dY grid
-    if WS_OF[family] != 3 or (cin <= 64 and _tile_fits(8 if family == "tile8" else 4, cout, cin, k, 1)):
+    # backward-data: K = cout (at most 256 channels in the tile-resident kernel), N = cin (at most 256 columns), stride-1 walk over the dY grid
+    if WS_OF[family] != 3 or (cin <= 256 and cout <= 256 and _tile_fits(8 if family == "tile8" else 4, cout, cin, k, 1)):
         assert (force_conv.udet_debug_last_conv() & 0xff) == WS_OF[family]
     assert (dx - gx.float()).abs().max() < 2e-4 * max(1.0, float(gx.abs().max()))
 

@@ -1301,7 +1301,9 @@ int launch_conv_tile(const ConvParams& p, int th, int cbmax, hipStream_t stream)
 static bool tile_ok(const ConvParams& p, int th, int cb = 32) {
   if (cb == 16 && p.Kc <= 16) return false;  // (the same launch as cb = 32)
   const size_t b = conv_tile_lds_bytes(p, th, cb, nullptr, nullptr);
-  return b > 0 && b <= 96 * 1024 && p.Kc <= 256 && p.Cout <= 64;
+  // (<= 256 columns: the kernel walks 32-column blocks as blockIdx.y and re-reads the halo per block -- thin inputs with wide outputs,
+  // the backward-data view of the recover decoder: 32 -> 194 channels 163 -> 150 us; beyond that the implicit GEMM always won)
+  return b > 0 && b <= 96 * 1024 && p.Kc <= 256 && p.Cout <= 256;
 }
 static bool self_staging_tile(int bm, int bn) {  // tiles conv_igemm_dma4_kernel is instantiated for
   return ((bm == 128 || bm == 64) && (bn == 64 || bn == 128)) || (bn == 32 && (bm == 128 || bm == 256));
