@@ -55,8 +55,9 @@ static double layer_flops(const Layer& L, int N) {
 }
 
 // ---------------------------------------------------------------- lanes ----
-// Lane 0 is the caller's stream; lanes 1..3 are the plan's side streams.  While profiling (per-kernel timing) or
-// with UDET_SERIAL=1 every lane collapses onto the caller's stream, which reproduces the plain program order.
+// Lane 0 is the caller's stream; lanes 1..5 are placed on the plan's candidate streams by place_lanes (lanes that share a hardware
+// queue are the same stream).  While profiling (per-kernel timing) or with UDET_SERIAL=1 every lane collapses onto the caller's
+// stream, which reproduces the plain program order.
 struct Lane {
   hipStream_t s;
   int slot;
