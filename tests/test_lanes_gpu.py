@@ -41,3 +41,39 @@ def test_serial_plans_report_one_queue():
     assert eng.lane_queues() == (1, [0] * 6)
     eng.set_concurrent(True)
     assert eng.lane_queues() == (4, LAYOUT)
+
+
+def test_fewer_hardware_queues_merge_lanes_and_keep_results(tmp_path):
+    """GPU_MAX_HW_QUEUES=2 (read by the ROCm runtime at start-up, hence a subprocess): the probe finds one independent queue besides
+    the caller's, lanes 1 / 3 / 4 / 5 share it, and a training step gives the same bits as the serial program."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import json, sys, torch
+sys.path.insert(0, %r)
+from unsupervised_detection_amd.engine import BOTH, Engine, EngineConfig
+from unsupervised_detection_amd.trainer import TrainState, train_step
+def run(concurrent):
+    eng = Engine(EngineConfig(batch_size=1, in_height=64, in_width=128, img_height=64, img_width=64))
+    eng.set_concurrent(concurrent)
+    st = TrainState(eng, seed=3)
+    g = torch.Generator().manual_seed(1)
+    a = (torch.rand(1, 64, 128, 3, generator=g) - 0.5).cuda(); b = (torch.rand(1, 64, 128, 3, generator=g) - 0.5).cuda()
+    for _ in range(2):
+        train_step(st, a, b, BOTH)
+    torch.cuda.synchronize()
+    return eng.lane_queues(), st.w_gen.cpu(), st.w_rec.cpu()
+(n, q), wg, wr = run(True)
+_, wg0, wr0 = run(False)
+print(json.dumps({"n": n, "q": q, "same": bool(torch.equal(wg, wg0) and torch.equal(wr, wr0))}))
+''' % root
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="2")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n"] == 2 and out["q"] == [0, 1, 0, 1, 1, 1] and out["same"]
