@@ -75,6 +75,49 @@ def test_dp_allreduce_mean_world2_gloo():
     assert np.array_equal(res[0][2], res[1][2])  # replicas stay bit-identical after the update
 
 
+def _tune_worker(rank, world, port, q, tune_file):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from unsupervised_detection_amd._ffi import lib
+    from unsupervised_detection_amd.trainer import TrainState
+
+    class FakeEngine:  # rank 0's "autotune" fills the library's configuration cache from a file; any other rank tuning is a failure
+        def autotune(self, *a):
+            assert rank == 0, "only rank 0 may tune"
+            return int(lib.udet_tune_load(tune_file.encode()))
+    st = TrainState.__new__(TrainState)
+    st.engine, st.w_gen, st.w_rec, st.g_gen, st.g_rec = FakeEngine(), None, None, None, None
+    before = int(lib.udet_tuned_shapes())
+    n = st._autotune_shared()
+    q.put((rank, before, n, int(lib.udet_tuned_shapes())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_autotune_is_shared_through_the_process_group(tmp_path):
+    """trainer.TrainState._autotune_shared: rank 0 tunes, the text of udet_tune_save travels through the process group, every other
+    rank loads it -- all ranks end up with the same configurations (host-only part of the C ABI: runs without a GPU)."""
+    from unsupervised_detection_amd._ffi import lib
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r03_tune.txt")).readline()
+    f = tmp_path / "tune.txt"
+    f.write_text(hdr + "c 1111 128 64 2 2 0 0\nc 2222 64 64 1 4 0 0\nw 3333 7\n")
+    assert int(lib.udet_tune_load(str(f).encode())) >= 2  # (the build accepts its own header)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29800 + os.getpid() % 200
+    ps = [ctx.Process(target=_tune_worker, args=(r, 2, port, q, str(f))) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda t: t[0])
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][1] == 0 and res[1][1] == 0            # fresh processes: nothing tuned
+    assert res[0][2] == res[1][2] and res[0][2] >= 2    # both report the same number of configurations ...
+    assert res[0][3] == res[1][3] == res[0][2]          # ... and hold them
+
+
 def _fake_davis(root, seqs=(("bear", 6), ("camel", 5), ("cows", 7))):
     os.makedirs(os.path.join(root, "ImageSets", "480p"), exist_ok=True)
     rows = []
