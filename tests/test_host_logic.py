@@ -98,7 +98,10 @@ def _tune_worker(rank, world, port, q, tune_file):
 def test_autotune_is_shared_through_the_process_group(tmp_path):
     """trainer.TrainState._autotune_shared: rank 0 tunes, the text of udet_tune_save travels through the process group, every other
     rank loads it -- all ranks end up with the same configurations (host-only part of the C ABI: runs without a GPU)."""
-    hdr = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r03_tune.txt")).readline()
+    from unsupervised_detection_amd._ffi import lib
+    g = tmp_path / "hdr.txt"
+    assert lib.udet_tune_save(str(g).encode()) == 0
+    hdr = g.read_text().splitlines()[0] + "\n"  # this build's header line (format version + tuning ABI)
     f = tmp_path / "tune.txt"
     f.write_text(hdr + "c 918273 128 64 2 2 0 0\nc 918274 64 64 1 4 0 0\nw 918275 7\n")  # (the process-global cache is only touched in the workers)
     ctx = mp.get_context("spawn")
