@@ -61,6 +61,8 @@ def main():
             if p[i]["kernel"] != e["kernel"]:
                 raise SystemExit("dispatch order differs between passes at %d: %s vs %s" % (i, p[i]["kernel"], e["kernel"]))
             e.update({k: v for k, v in p[i].items() if k not in ("kernel", "dur_us")})
+            if "GRBM_GUI_ACTIVE" in p[i]:
+                e["dur_us_clk"] = p[i]["dur_us"]  # the duration of the launch in the pass that counted its clock cycles
         e["dur_us"] = min(p[i]["dur_us"] for p in passes)
         merged.append(e)
 
@@ -70,6 +72,10 @@ def main():
     def mfma_busy(e):  # SQ_VALU_MFMA_BUSY_CYCLES is summed over the SIMDs in quad-cycles; GRBM_GUI_ACTIVE over the 8 XCDs
         g = e.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
         return round(e.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (g * 1024), 3) if g > 0 else None
+    def clock_ghz(e):  # effective shader clock while the launch ran (the chip clocks to its power budget: MI355X_MICROARCH.md, DVFS);
+                       # meaningful for long launches only -- GRBM_GUI_ACTIVE also counts the cycles around a dispatch
+        g, d = e.get("GRBM_GUI_ACTIVE", 0.0) / 8.0, e.get("dur_us_clk", 0.0)
+        return round(g / (d * 1e3), 3) if g > 0 and d > 0 else None
     fam = collections.defaultdict(lambda: collections.defaultdict(float))
     for e in merged:
         f = fam[e["kernel"]]
@@ -93,7 +99,8 @@ def main():
            "kernel_us_per_step_under_pmc": round(sum(e["dur_us"] for e in merged) / nsteps, 1),
            "top10_dispatches_of_one_step": [{"kernel": e["kernel"], "us": round(e["dur_us"], 1), "hbm_MB": round(traffic(e) / 1e6, 2),
                                              "fetch_MB_x2": round(e.get("FETCH_SIZE", 0.0) * 2048 / 1e6, 2),
-                                             "write_MB": round(e.get("WRITE_SIZE", 0.0) * 1024 / 1e6, 2), "mfma_pipe_busy_frac": mfma_busy(e)}
+                                             "write_MB": round(e.get("WRITE_SIZE", 0.0) * 1024 / 1e6, 2), "mfma_pipe_busy_frac": mfma_busy(e),
+                                             "effective_clock_GHz": clock_ghz(e)}
                                             for e in top],
            "kernel_families": families[:30]}
     with open(a.out, "w") as f:
