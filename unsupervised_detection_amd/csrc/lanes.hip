@@ -17,6 +17,10 @@ int streams_concurrent(hipStream_t a, hipStream_t b, bool* concurrent) {
   *concurrent = false;
   if (a == b) return UDET_OK;
   hipEvent_t e0 = nullptr, ea = nullptr, eb = nullptr;
+  struct Guard {  // (the error paths below return early)
+    hipEvent_t *a, *b, *c;
+    ~Guard() { for (hipEvent_t* e : {a, b, c}) if (*e) (void)hipEventDestroy(*e); }
+  } guard{&e0, &ea, &eb};
   UDET_HIP(hipEventCreate(&e0));
   UDET_HIP(hipEventCreate(&ea));
   UDET_HIP(hipEventCreate(&eb));
@@ -39,7 +43,6 @@ int streams_concurrent(hipStream_t a, hipStream_t b, bool* concurrent) {
   UDET_HIP(hipEventElapsedTime(&ta, e0, ea));
   UDET_HIP(hipEventElapsedTime(&tb, e0, eb));
   *concurrent = tb < 0.6f * ta;
-  (void)hipEventDestroy(e0); (void)hipEventDestroy(ea); (void)hipEventDestroy(eb);
   return UDET_OK;
 }
 

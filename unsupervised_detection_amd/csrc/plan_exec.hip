@@ -68,6 +68,7 @@ static const Plan::Placement& place_lanes(Plan* P, hipStream_t main) {
   if (P->placed >= 0 && P->placements[P->placed].main == main) return P->placements[P->placed];
   for (size_t k = 0; k < P->placements.size(); ++k)
     if (P->placements[k].main == main) { P->placed = (int)k; return P->placements[k]; }
+  if (P->placements.size() >= 16) { P->placements.clear(); P->placed = -1; }  // (a caller that keeps making new streams: start over)
   (void)hipDeviceSynchronize();
   hipStream_t pick[3] = {nullptr, nullptr, nullptr};
   int np = 0;
