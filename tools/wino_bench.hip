@@ -1,0 +1,357 @@
+// Prototype + micro-benchmark of the fused Winograd F(2x2,3x3) fp32-MFMA convolution.
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/wino_bench tools/wino_bench.hip && /tmp/wino_bench [shape ...]
+// One workgroup = 4 waves (one per SIMD, 512-register budget).  A wave owns ALL 16 Winograd positions of a 32-tile x 32-channel
+// block: 16 accumulators of v_mfma_f32_32x32x2_f32 = 256 registers, so the output transform A^T M A needs no cross-wave traffic.
+// Workgroup tile: WT x WN waves = (32 WT) tiles x (32 WN) output channels.  K runs in stages of 8 input channels:
+//   input  stage: the raw (2 TH + 2) x (2 TW + 2) pixel halo of the workgroup's tiles, [quad][row][column parity][column / 2][4 ch]
+//                 (16-byte slots, row stride == 4 (mod 8) slots: the ds_read_b128 of the 4x4 patch are conflict-free)
+//   weight stage: the pre-transformed U = G g G^T, [position][lane half][n][4 ch] = the global layout, 32 KB for 64 channels
+// both land by global_load_lds_dwordx4 issued by the MFMA waves themselves (3-stage ring, one barrier per stage); the input
+// transform B^T d B (32 adds per channel) sits on the LDS -> VGPR path; lanes 0-31 hold channels 4q..4q+3 of k-group q,
+// lanes 32-63 channels 4q+4..4q+7: MFMA j of a position consumes component j of both halves.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <vector>
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void* lds_ptr;
+
+struct WinoParams {
+  const float* x;
+  int ldx, x_coff, N, H, W, Kc;  // Kc: input channels (multiple of 4)
+  const float* u;                // transformed weights [kg][nb][16][2][32*WN][4]
+  int nkg;                       // ceil(Kc / 8)
+  const float* bias;
+  float* y;
+  int ldy, y_coff, Cout;
+  int dil;     // dilation: the d*d output sub-lattices are independent d = 1 problems
+  int Hs, Ws;  // ceil(H / d), ceil(W / d)
+  int BY, BX;  // workgroup blocks per sub-lattice image
+  const float* zero16;
+  float alpha;  // leaky slope
+};
+
+#define CHECK(x)                                                                      \
+  do {                                                                                \
+    hipError_t e_ = (x);                                                              \
+    if (e_ != hipSuccess) {                                                           \
+      fprintf(stderr, "%s:%d %s -> %s\n", __FILE__, __LINE__, #x, hipGetErrorString(e_)); \
+      exit(1);                                                                        \
+    }                                                                                 \
+  } while (0)
+
+constexpr int row_slots(int pw) { return (pw + 3) / 8 * 8 + 4; }  // smallest S >= pw with S % 8 == 4
+
+// tiles of a workgroup: (4 WTY) x (8 WTX) with WT = WTY * WTX waves along the tile axes
+template <int WTY, int WTX, int WN, int NS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino_kernel(const WinoParams p) {
+  static_assert(WTY * WTX * WN == 4, "4 waves");
+  constexpr int TH = 4 * WTY, TW = 8 * WTX;       // tiles
+  constexpr int PH = 2 * TH + 2, PW = 2 * TW + 2;  // halo pixels
+  constexpr int CS = PW / 2;                       // used slots per column parity
+  constexpr int S = row_slots(PW);                 // slots per halo row: >= PW, == 4 (mod 8)
+  static_assert(S % 8 == 4 && S >= PW, "row stride");
+  constexpr int HP = S / 2;                                  // slot offset of the odd-column half
+  constexpr int IN_SLOTS = 2 * PH * S;                       // 16-byte slots of one input stage
+  constexpr int IN_INSTR = (IN_SLOTS + 255) / 256;           // DMA instructions per wave
+  constexpr int IN_BYTES = IN_INSTR * 256 * 16;
+  constexpr int BN = 32 * WN;
+  constexpr int W_BYTES = 16 * 2 * BN * 16;
+  constexpr int W_INSTR = W_BYTES / 4096;
+  constexpr int STAGE = IN_BYTES + W_BYTES;
+  constexpr int L = IN_INSTR + W_INSTR;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int wn = wave % WN, wt = wave / WN, wty = wt / WTX, wtx = wt % WTX;
+
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int d = p.dil;
+  const int bx = bid % p.BX;
+  int rem = bid / p.BX;
+  const int by = rem % p.BY;
+  rem /= p.BY;
+  const int sx = rem % d;
+  rem /= d;
+  const int sy = rem % d;
+  const int n = rem / d;
+  const int Hs = (p.H - sy + d - 1) / d, Ws = (p.W - sx + d - 1) / d;  // this sub-lattice's grid
+  const int Y0 = by * 2 * TH, X0 = bx * 2 * TW;                          // first output pixel (sub-lattice coordinates)
+  const int nb = blockIdx.y;
+
+  // ---- per-lane DMA sources (constant over the stages up to the channel offset) ----
+  int in_off[IN_INSTR], in_q4[IN_INSTR];
+#pragma unroll
+  for (int i = 0; i < IN_INSTR; ++i) {
+    const int Lx = (i * 4 + wave) * 64 + lane;
+    const int quad = Lx / (PH * S), r2 = Lx - quad * (PH * S);
+    const int row = r2 / S, s = r2 - row * S;
+    const int par = s / HP, cs = s - par * HP;
+    const int col = 2 * cs + par;
+    const int yy = Y0 - 1 + row, xx = X0 - 1 + col;
+    const bool ok = quad < 2 && cs < CS && yy >= 0 && yy < Hs && xx >= 0 && xx < Ws;
+    in_off[i] = ok ? ((n * p.H + sy + d * yy) * p.W + sx + d * xx) * p.ldx + p.x_coff + quad * 4 : -1;
+    in_q4[i] = quad * 4;
+  }
+  const float* zero = p.zero16;
+  const float* ubase = p.u + (size_t)nb * (W_BYTES / 4) + (size_t)lane * 4;
+  const size_t ustride = (size_t)gridDim.y * (W_BYTES / 4);  // floats per k-group
+
+  auto issue = [&](int kg, int buf) {
+    char* sb = smem + buf * STAGE;
+    const int c0 = kg * 8;
+#pragma unroll
+    for (int i = 0; i < IN_INSTR; ++i) {
+      const float* src = (in_off[i] >= 0 && c0 + in_q4[i] < p.Kc) ? p.x + (in_off[i] + c0) : zero;
+      __builtin_amdgcn_global_load_lds(src, (lds_ptr)(sb + (i * 4 + wave) * 1024), 16, 0, 0);
+    }
+    const float* us = ubase + (size_t)kg * ustride;
+#pragma unroll
+    for (int i = 0; i < W_INSTR; ++i)
+      __builtin_amdgcn_global_load_lds(us + (i * 4 + wave) * 256, (lds_ptr)(sb + IN_BYTES + (i * 4 + wave) * 1024), 16, 0, 0);
+  };
+
+  floatx16 acc[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+  const int ty = li >> 3, tx = li & 7;
+  // byte offset of this lane's patch origin inside an input stage
+  const int a_base = ((lh * PH + 2 * (wty * 4 + ty)) * S + (wtx * 8 + tx)) * 16;
+  const int b_base = IN_BYTES + (lh * BN + wn * 32 + li) * 16;
+
+  const int nkg = p.nkg;
+  constexpr int LW = L;  // DMA instructions per wave and stage
+  // prologue: NS - 1 stages in flight
+#pragma unroll
+  for (int s = 0; s < NS - 1; ++s)
+    if (s < nkg) issue(s, s);
+  int buf = 0;
+  for (int kg = 0; kg < nkg; ++kg) {
+    // stage kg has landed (loads retire in order: only the stages issued after it may still be in flight)
+    if (NS > 2 && kg + NS - 2 < nkg) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 2) * LW) : "memory");
+    else if (NS > 3 && kg + NS - 3 < nkg) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NS - 3) * LW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    {  // every wave has left stage kg - 1: its buffer takes stage kg + NS - 1
+      const int nk = kg + NS - 1;
+      int nbuf = buf + NS - 1;
+      nbuf = nbuf >= NS ? nbuf - NS : nbuf;
+      if (nk < nkg) issue(nk, nbuf);
+    }
+    const char* sb = smem + buf * STAGE;
+    float4 raw[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        raw[r][c] = *reinterpret_cast<const float4*>(sb + a_base + (r * S + (c & 1) * HP + (c >> 1)) * 16);
+    float4 bf[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) bf[q] = *reinterpret_cast<const float4*>(sb + b_base + q * (2 * BN * 16));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float dd[4][4], t[4][4], v[4][4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dd[r][c] = j == 0 ? raw[r][c].x : (j == 1 ? raw[r][c].y : (j == 2 ? raw[r][c].z : raw[r][c].w));
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        t[0][c] = dd[0][c] - dd[2][c];
+        t[1][c] = dd[1][c] + dd[2][c];
+        t[2][c] = dd[2][c] - dd[1][c];
+        t[3][c] = dd[1][c] - dd[3][c];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[i][0] = t[i][0] - t[i][2];
+        v[i][1] = t[i][1] + t[i][2];
+        v[i][2] = t[i][2] - t[i][1];
+        v[i][3] = t[i][1] - t[i][3];
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float bv = j == 0 ? bf[q].x : (j == 1 ? bf[q].y : (j == 2 ? bf[q].z : bf[q].w));
+        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[q >> 2][q & 3], bv, acc[q], 0, 0, 0);
+      }
+    }
+    buf = buf + 1 == NS ? 0 : buf + 1;
+  }
+
+  // ---- output transform + epilogue: Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1] ----
+  const int co = nb * BN + wn * 32 + li;
+  const float bias = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;  // tile of the wave's 4 x 8 block
+    const int oy = Y0 + 2 * (wty * 4 + (m >> 3)), ox = X0 + 2 * (wtx * 8 + (m & 7));
+    float s[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      s[i][0] = acc[i * 4 + 0][r] + acc[i * 4 + 1][r] + acc[i * 4 + 2][r];
+      s[i][1] = acc[i * 4 + 1][r] - acc[i * 4 + 2][r] - acc[i * 4 + 3][r];
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const float y0 = s[0][b] + s[1][b] + s[2][b];
+      const float y1 = s[1][b] - s[2][b] - s[3][b];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int yy = oy + a, xx = ox + b;
+        if (yy < Hs && xx < Ws && co < p.Cout) {
+          float v = (a ? y1 : y0) + bias;
+          v = v > 0.f ? v : v * p.alpha;
+          p.y[((size_t)(n * p.H + sy + d * yy) * p.W + sx + d * xx) * p.ldy + p.y_coff + co] = v;
+        }
+      }
+    }
+  }
+}
+
+// U = G g G^T, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1];  layout [kg][nb][pos][half][BN][4]
+__global__ void wino_weights_kernel(const float* __restrict__ w, float* __restrict__ u, int Cin, int Cout, int nkg, int nnb, int BN) {
+  const long total = (long)nkg * nnb * 16 * 2 * BN * 4;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    long r = e;
+    const int j = (int)(r & 3); r >>= 2;
+    const int nn = (int)(r % BN); r /= BN;
+    const int kh = (int)(r & 1); r >>= 1;
+    const int pos = (int)(r & 15); r >>= 4;
+    const int nb = (int)(r % nnb);
+    const int kg = (int)(r / nnb);
+    const int c = kg * 8 + kh * 4 + j, co = nb * BN + nn;
+    float val = 0.f;
+    if (c < Cin && co < Cout) {
+      const float G[4][3] = {{1.f, 0.f, 0.f}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0.f, 0.f, 1.f}};
+      const int pi = pos >> 2, pj = pos & 3;
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) val += G[pi][a] * G[pj][b] * w[((size_t)(a * 3 + b) * Cin + c) * Cout + co];
+    }
+    u[e] = val;
+  }
+}
+
+// plain direct convolution (the check): 3x3, stride 1, dilation d, SAME padding, bias, leaky
+__global__ void ref_conv_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w, const float* __restrict__ bias,
+                                float* __restrict__ y, int N, int H, int W, int Cin, int Cout, int d, float alpha) {
+  const long total = (long)N * H * W * Cout;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int co = (int)(e % Cout);
+    long pix = e / Cout;
+    const int ox = (int)(pix % W);
+    pix /= W;
+    const int oy = (int)(pix % H), n = (int)(pix / H);
+    double acc = bias[co];
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) {
+        const int iy = oy + (a - 1) * d, ix = ox + (b - 1) * d;
+        if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+        const float* xp = x + ((size_t)(n * H + iy) * W + ix) * ldx;
+        const float* wp = w + (size_t)(a * 3 + b) * Cin * Cout + co;
+        for (int c = 0; c < Cin; ++c) acc += (double)xp[c] * wp[(size_t)c * Cout];
+      }
+    float v = (float)acc;
+    y[e] = v > 0.f ? v : v * alpha;
+  }
+}
+
+struct Shape { const char* name; int N, H, W, Cin, Cout, d; };
+
+template <int WTY, int WTX, int WN, int NS>
+static float run(const Shape& s, const float* x, int ldx, const float* w, const float* bias, float* y, const float* zero, int reps, float* u_buf) {
+  constexpr int TH = 4 * WTY, TW = 8 * WTX, BN = 32 * WN;
+  WinoParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = x; p.ldx = ldx; p.x_coff = 0; p.N = s.N; p.H = s.H; p.W = s.W; p.Kc = (s.Cin + 3) & ~3;
+  p.nkg = (p.Kc + 7) / 8;
+  const int nnb = (s.Cout + BN - 1) / BN;
+  hipLaunchKernelGGL(wino_weights_kernel, dim3(1024), dim3(256), 0, 0, w, u_buf, s.Cin, s.Cout, p.nkg, nnb, BN);
+  p.u = u_buf; p.bias = bias; p.y = y; p.ldy = s.Cout; p.y_coff = 0; p.Cout = s.Cout; p.dil = s.d;
+  p.Hs = (s.H + s.d - 1) / s.d; p.Ws = (s.W + s.d - 1) / s.d;
+  p.BY = (p.Hs + 2 * TH - 1) / (2 * TH); p.BX = (p.Ws + 2 * TW - 1) / (2 * TW);
+  p.zero16 = zero; p.alpha = 0.1f;
+  constexpr int PH = 2 * TH + 2, PW = 2 * TW + 2;
+  constexpr int S = row_slots(PW);
+  constexpr int IN_BYTES = ((2 * PH * S + 255) / 256) * 256 * 16;
+  constexpr int STAGE = IN_BYTES + 16 * 2 * BN * 16;
+  const int shmem = NS * STAGE;
+  auto kern = wino_kernel<WTY, WTX, WN, NS>;
+  CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, shmem));
+  dim3 grid(s.N * s.d * s.d * p.BY * p.BX, nnb);
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(kern, grid, dim3(256), shmem, 0, p);
+  CHECK(hipGetLastError());
+  CHECK(hipEventRecord(e0, 0));
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, grid, dim3(256), shmem, 0, p);
+  CHECK(hipEventRecord(e1, 0));
+  CHECK(hipEventSynchronize(e1));
+  float ms = 0.f;
+  CHECK(hipEventElapsedTime(&ms, e0, e1));
+  printf("    <%d,%d,%d,%d> grid %dx%d lds %d KB S=%d: ", WTY, WTX, WN, NS, grid.x, grid.y, shmem / 1024, S);
+  return ms * 1e3f / reps;
+}
+
+int main(int argc, char** argv) {
+  const Shape shapes[] = {
+      {"pwc.dc_conv21", 4, 96, 160, 565, 128, 1}, {"pwc.conv2_1", 4, 96, 160, 243, 128, 1}, {"pwc.conv2_3", 4, 96, 160, 467, 64, 1},
+      {"pwc.conv2_4", 4, 96, 160, 531, 32, 1},    {"pwc.dc_conv22", 4, 96, 160, 128, 128, 2}, {"pwc.dc_conv31", 4, 48, 80, 597, 128, 1},
+      {"gen.conv5", 4, 48, 96, 128, 128, 1},      {"gen.conv3", 4, 96, 192, 64, 64, 1},     {"odd", 2, 37, 53, 20, 40, 1},
+      {"odd.d3", 1, 41, 50, 36, 70, 3}};
+  const int reps = 20;
+  for (const Shape& s : shapes) {
+    bool sel = argc <= 1;
+    for (int i = 1; i < argc; ++i) sel = sel || strstr(s.name, argv[i]);
+    if (!sel) continue;
+    const int ldx = (s.Cin + 7) & ~7;
+    const size_t nx = (size_t)s.N * s.H * s.W * ldx, nw = (size_t)9 * s.Cin * s.Cout, ny = (size_t)s.N * s.H * s.W * s.Cout;
+    std::vector<float> hx(nx), hw(nw), hb(s.Cout);
+    unsigned seed = 12345u;
+    auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return ((seed >> 8) & 0xffff) / 65536.f - 0.5f; };
+    for (size_t i = 0; i < nx; ++i) hx[i] = (int)(i % ldx) < s.Cin ? rnd() : 0.f;
+    const float ws = sqrtf(2.f / (9.f * s.Cin)) * 2.f;
+    for (auto& v : hw) v = rnd() * ws;
+    for (auto& v : hb) v = rnd() * 0.1f;
+    float *x, *w, *b, *y, *yr, *zero, *u;
+    CHECK(hipMalloc(&x, nx * 4)); CHECK(hipMalloc(&w, nw * 4)); CHECK(hipMalloc(&b, s.Cout * 4));
+    CHECK(hipMalloc(&y, ny * 4)); CHECK(hipMalloc(&yr, ny * 4)); CHECK(hipMalloc(&zero, 256));
+    const size_t nu = (size_t)((ldx + 7) / 8) * ((s.Cout + 127) / 128 * 128 + 128) * 16 * 8;
+    CHECK(hipMalloc(&u, nu * 4));
+    CHECK(hipMemset(zero, 0, 256));
+    CHECK(hipMemcpy(x, hx.data(), nx * 4, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(w, hw.data(), nw * 4, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy(b, hb.data(), s.Cout * 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(ref_conv_kernel, dim3(4096), dim3(256), 0, 0, x, ldx, w, b, yr, s.N, s.H, s.W, s.Cin, s.Cout, s.d, 0.1f);
+    CHECK(hipDeviceSynchronize());
+    std::vector<float> hy(ny), hr(ny);
+    CHECK(hipMemcpy(hr.data(), yr, ny * 4, hipMemcpyDeviceToHost));
+    const double gflop = 2.0 * s.N * s.H * s.W * (double)s.Cout * s.Cin * 9 * 1e-9;
+    printf("%s  N=%d %dx%d %d->%d d=%d  %.2f GFLOP\n", s.name, s.N, s.H, s.W, s.Cin, s.Cout, s.d, gflop);
+    auto report = [&](float us) {
+      CHECK(hipMemcpy(hy.data(), y, ny * 4, hipMemcpyDeviceToHost));
+      double md = 0, mr = 0;
+      for (size_t i = 0; i < ny; ++i) { md = fmax(md, fabs((double)hy[i] - hr[i])); mr = fmax(mr, fabs((double)hr[i])); }
+      printf("%8.1f us  %6.1f TFLOP/s (direct-equivalent)  max|diff| %.2e / scale %.2e\n", us, gflop / us * 1e3, md, mr);
+      CHECK(hipMemset(y, 0, ny * 4));
+    };
+    report(run<2, 1, 2, 3>(s, x, ldx, w, b, y, zero, reps, u));
+    report(run<2, 1, 2, 2>(s, x, ldx, w, b, y, zero, reps, u));
+    report(run<2, 2, 1, 3>(s, x, ldx, w, b, y, zero, reps, u));
+    report(run<1, 1, 4, 2>(s, x, ldx, w, b, y, zero, reps, u));
+    hipFree(x); hipFree(w); hipFree(b); hipFree(y); hipFree(yr); hipFree(zero); hipFree(u);
+  }
+  return 0;
+}
