@@ -220,6 +220,232 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// v2: the same tile / stage / LDS layout, hand software-pipelined for ONE wave per SIMD.
+// A stage is four phases, phase i = position row i (16 MFMAs on 4 accumulators x 4 channel components): it needs patch rows
+// {0,2} {1,2} {1,2} {1,3} and the weight fragments of positions 4i..4i+3.  The LDS reads of phase i + 1 are issued before the
+// multiplications of phase i; the wait-and-barrier that hands stage k + 1 over sits between phases 2 and 3 of stage k, so
+// phase 3 prefetches phase 0 of the NEXT stage and no phase ever starts by waiting out the LDS latency behind a barrier.  The
+// DMA of stage k + 2 (into the buffer of stage k - 1, which every wave has left at that barrier) is issued in two parts, inside
+// phase 3 of stage k and phase 0 of stage k + 1, and has until the next barrier to land.
+// ABL (ablation bits): 1 no DMA after the prologue, 2 no MFMA, 4 no input transform, 8 no LDS fragment reads in the loop
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int WTY, int WTX, int WN, int ABL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino2_kernel(const WinoParams p) {
+  static_assert(WTY * WTX * WN == 4, "4 waves");
+  constexpr int NS = 3;
+  constexpr int TH = 4 * WTY, TW = 8 * WTX;
+  constexpr int PH = 2 * TH + 2, PW = 2 * TW + 2;
+  constexpr int CS = PW / 2;
+  constexpr int S = row_slots(PW);
+  constexpr int HP = S / 2;
+  constexpr int IN_SLOTS = 2 * PH * S;
+  constexpr int IN_INSTR = (IN_SLOTS + 255) / 256;
+  constexpr int IN_BYTES = IN_INSTR * 256 * 16;
+  constexpr int BN = 32 * WN;
+  constexpr int W_BYTES = 16 * 2 * BN * 16;
+  constexpr int W_INSTR = W_BYTES / 4096;
+  constexpr int STAGE = IN_BYTES + W_BYTES;
+  constexpr int L = IN_INSTR + W_INSTR;
+  constexpr int LA = (L + 1) / 2;  // DMA instructions of part A (input first)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int wn = wave % WN, wt = wave / WN, wty = wt / WTX, wtx = wt % WTX;
+
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int d = p.dil;
+  const int bx = bid % p.BX;
+  int rem = bid / p.BX;
+  const int by = rem % p.BY;
+  rem /= p.BY;
+  const int sx = rem % d;
+  rem /= d;
+  const int sy = rem % d;
+  const int n = rem / d;
+  const int Hs = (p.H - sy + d - 1) / d, Ws = (p.W - sx + d - 1) / d;
+  const int Y0 = by * 2 * TH, X0 = bx * 2 * TW;
+  const int nb = blockIdx.y;
+
+  int in_off[IN_INSTR], in_q4[IN_INSTR];
+#pragma unroll
+  for (int i = 0; i < IN_INSTR; ++i) {
+    const int Lx = (i * 4 + wave) * 64 + lane;
+    const int quad = Lx / (PH * S), r2 = Lx - quad * (PH * S);
+    const int row = r2 / S, s = r2 - row * S;
+    const int par = s / HP, cs = s - par * HP;
+    const int col = 2 * cs + par;
+    const int yy = Y0 - 1 + row, xx = X0 - 1 + col;
+    const bool ok = quad < 2 && cs < CS && yy >= 0 && yy < Hs && xx >= 0 && xx < Ws;
+    in_off[i] = ok ? ((n * p.H + sy + d * yy) * p.W + sx + d * xx) * p.ldx + p.x_coff + quad * 4 : -1;
+    in_q4[i] = quad * 4;
+  }
+  const float* zero = p.zero16;
+  const float* ubase = p.u + (size_t)nb * (W_BYTES / 4) + (size_t)lane * 4;
+  const float* ubase0 = p.u + (size_t)nb * (W_BYTES / 4);
+  const size_t ustride = (size_t)gridDim.y * (W_BYTES / 4);
+
+  // DMA instructions [i0, i1) of stage kg into buffer buf (instruction index: input first, then weights).  Inline assembly on
+  // purpose: behind the builtin hipcc orders every later LDS read after the DMA with s_waitcnt vmcnt(0) (it models the DMA as a
+  // store to LDS), which serialises fill and multiplication in a kernel whose waves do both; the hand-over is the explicit
+  // vmcnt + barrier below.
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned lane16 = lane * 16;
+  auto issue = [&](int kg, int buf, int i0, int i1) {
+    const unsigned sb = lds0 + buf * STAGE;
+    const int c0 = kg * 8;
+    const float* us = ubase0 + (size_t)kg * ustride;
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+      if (i < i0 || i >= i1) continue;
+      if (i < IN_INSTR) {
+        const float* src = (in_off[i] >= 0 && c0 + in_q4[i] < p.Kc) ? p.x + (in_off[i] + c0) : zero;
+        asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(sb + (i * 4 + wave) * 1024) : "m0");
+      } else {
+        const int w = i - IN_INSTR;
+        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane16), "s"(us + (w * 4 + wave) * 256),
+                     "s"(sb + IN_BYTES + (w * 4 + wave) * 1024)
+                     : "m0");
+      }
+    }
+  };
+
+  floatx16 acc[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+  const int ty = li >> 3, tx = li & 7;
+  const int a_base = ((lh * PH + 2 * (wty * 4 + ty)) * S + (wtx * 8 + tx)) * 16;
+  const int b_base = IN_BYTES + (lh * BN + wn * 32 + li) * 16;
+
+  float4 row[4][4];
+  float4 bfr[2][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) row[r][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bfr[s][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto ld_row = [&](const char* sb, int r) {
+    if (ABL & 8) return;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) row[r][c] = *reinterpret_cast<const float4*>(sb + a_base + (r * S + (c & 1) * HP + (c >> 1)) * 16);
+  };
+  auto ld_bf = [&](const char* sb, int i, int s) {
+    if (ABL & 8) return;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bfr[s][q] = *reinterpret_cast<const float4*>(sb + b_base + (4 * i + q) * (2 * BN * 16));
+  };
+  auto comp = [](const float4& v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); };
+
+  const int nkg = p.nkg;
+  issue(0, 0, 0, L);
+  if (nkg > 1) issue(1, 1, 0, L);
+  if (nkg > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  ld_row(smem, 0);
+  ld_row(smem, 2);
+  ld_bf(smem, 0, 0);
+
+  int buf = 0;
+  for (int kg = 0; kg < nkg; ++kg) {
+    const char* sb = smem + buf * STAGE;
+    const int b1 = buf + 1 == NS ? 0 : buf + 1, b2 = b1 + 1 == NS ? 0 : b1 + 1;
+    const char* sbn = smem + b1 * STAGE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      // ---- LDS reads of the next phase, DMA parts ----
+      if (i == 0) {
+        ld_row(sb, 1);
+        ld_bf(sb, 1, 1);
+        if (!(ABL & 1) && kg > 0 && kg + 1 < nkg) issue(kg + 1, b1, LA, L);  // part B of the stage whose part A went out in the previous phase 3
+      } else if (i == 1) {
+        ld_bf(sb, 2, 0);
+      } else if (i == 2) {
+        ld_row(sb, 3);
+        ld_bf(sb, 3, 1);
+      } else {
+        ld_row(sbn, 0);
+        ld_row(sbn, 2);
+        ld_bf(sbn, 0, 0);
+        if (!(ABL & 1) && kg + 2 < nkg) issue(kg + 2, b2, 0, LA);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- phase i: position row i ----
+      constexpr int RA[4] = {0, 1, 2, 1}, RB[4] = {2, 2, 1, 3};  // t_i = d[RA] (+/-) d[RB]: d0-d2, d1+d2, d2-d1, d1-d3
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float t[4], v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float a = comp(row[RA[i]][c], j), b = comp(row[RB[i]][c], j);
+          t[c] = (ABL & 4) ? a : (i == 1 ? a + b : a - b);
+        }
+        if (ABL & 4) {
+          v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+        } else {
+          v[0] = t[0] - t[2];
+          v[1] = t[1] + t[2];
+          v[2] = t[2] - t[1];
+          v[3] = t[1] - t[3];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (ABL & 2) acc[4 * i + q][j] += v[q] * comp(bfr[i & 1][q], j);
+          else acc[4 * i + q] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[q], comp(bfr[i & 1][q], j), acc[4 * i + q], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (i == 2) {  // stage kg + 1 is in LDS for everybody; stage kg - 1's buffer is free
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+    }
+    buf = b1;
+  }
+
+  const int co = nb * BN + wn * 32 + li;
+  const float bias = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+    const int oy = Y0 + 2 * (wty * 4 + (m >> 3)), ox = X0 + 2 * (wtx * 8 + (m & 7));
+    float s[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      s[i][0] = acc[i * 4 + 0][r] + acc[i * 4 + 1][r] + acc[i * 4 + 2][r];
+      s[i][1] = acc[i * 4 + 1][r] - acc[i * 4 + 2][r] - acc[i * 4 + 3][r];
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const float y0 = s[0][b] + s[1][b] + s[2][b];
+      const float y1 = s[1][b] - s[2][b] - s[3][b];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int yy = oy + a, xx = ox + b;
+        if (yy < Hs && xx < Ws && co < p.Cout) {
+          float v = (a ? y1 : y0) + bias;
+          v = v > 0.f ? v : v * p.alpha;
+          p.y[((size_t)(n * p.H + sy + d * yy) * p.W + sx + d * xx) * p.ldy + p.y_coff + co] = v;
+        }
+      }
+    }
+  }
+}
+
 // U = G g G^T, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1];  layout [kg][nb][pos][half][BN][4]
 __global__ void wino_weights_kernel(const float* __restrict__ w, float* __restrict__ u, int Cin, int Cout, int nkg, int nnb, int BN) {
   const long total = (long)nkg * nnb * 16 * 2 * BN * 4;
@@ -269,7 +495,7 @@ __global__ void ref_conv_kernel(const float* __restrict__ x, int ldx, const floa
 
 struct Shape { const char* name; int N, H, W, Cin, Cout, d; };
 
-template <int WTY, int WTX, int WN, int NS>
+template <int WTY, int WTX, int WN, int NS, int V2 = 0, int ABL = 0>
 static float run(const Shape& s, const float* x, int ldx, const float* w, const float* bias, float* y, const float* zero, int reps, float* u_buf) {
   constexpr int TH = 4 * WTY, TW = 8 * WTX, BN = 32 * WN;
   WinoParams p;
@@ -287,7 +513,7 @@ static float run(const Shape& s, const float* x, int ldx, const float* w, const 
   constexpr int IN_BYTES = ((2 * PH * S + 255) / 256) * 256 * 16;
   constexpr int STAGE = IN_BYTES + 16 * 2 * BN * 16;
   const int shmem = NS * STAGE;
-  auto kern = wino_kernel<WTY, WTX, WN, NS>;
+  auto kern = V2 ? wino2_kernel<WTY, WTX, WN, ABL> : wino_kernel<WTY, WTX, WN, NS>;
   CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, shmem));
   dim3 grid(s.N * s.d * s.d * p.BY * p.BX, nnb);
   hipEvent_t e0, e1;
@@ -301,7 +527,7 @@ static float run(const Shape& s, const float* x, int ldx, const float* w, const 
   CHECK(hipEventSynchronize(e1));
   float ms = 0.f;
   CHECK(hipEventElapsedTime(&ms, e0, e1));
-  printf("    <%d,%d,%d,%d> grid %dx%d lds %d KB S=%d: ", WTY, WTX, WN, NS, grid.x, grid.y, shmem / 1024, S);
+  printf("    %s<%d,%d,%d,%d> abl %d grid %dx%d lds %d KB S=%d: ", V2 ? "v2" : "v1", WTY, WTX, WN, NS, ABL, grid.x, grid.y, shmem / 1024, S);
   return ms * 1e3f / reps;
 }
 
@@ -348,9 +574,16 @@ int main(int argc, char** argv) {
       CHECK(hipMemset(y, 0, ny * 4));
     };
     report(run<2, 1, 2, 3>(s, x, ldx, w, b, y, zero, reps, u));
-    report(run<2, 1, 2, 2>(s, x, ldx, w, b, y, zero, reps, u));
-    report(run<2, 2, 1, 3>(s, x, ldx, w, b, y, zero, reps, u));
-    report(run<1, 1, 4, 2>(s, x, ldx, w, b, y, zero, reps, u));
+    report(run<2, 1, 2, 3, 1>(s, x, ldx, w, b, y, zero, reps, u));
+    report(run<2, 2, 1, 3, 1>(s, x, ldx, w, b, y, zero, reps, u));
+    if (getenv("WINO_ABL")) {
+      report(run<2, 1, 2, 3, 1, 1>(s, x, ldx, w, b, y, zero, reps, u));
+      report(run<2, 1, 2, 3, 1, 2>(s, x, ldx, w, b, y, zero, reps, u));
+      report(run<2, 1, 2, 3, 1, 4>(s, x, ldx, w, b, y, zero, reps, u));
+      report(run<2, 1, 2, 3, 1, 8>(s, x, ldx, w, b, y, zero, reps, u));
+      report(run<2, 1, 2, 3, 1, 9>(s, x, ldx, w, b, y, zero, reps, u));
+      report(run<2, 1, 2, 3, 1, 13>(s, x, ldx, w, b, y, zero, reps, u));
+    }
     hipFree(x); hipFree(w); hipFree(b); hipFree(y); hipFree(yr); hipFree(zero); hipFree(u);
   }
   return 0;
