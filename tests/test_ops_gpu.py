@@ -235,6 +235,40 @@ def test_conv_kernel_families(ops, force_conv, family, case):
     assert (dx - gx.float()).abs().max() < 2e-4 * max(1.0, float(gx.abs().max()))
 
 
+# Winograd F(2x2,3x3) family (conv_wino.hip; bit 25 of the forced tile, low bits = variant 0: 64 tiles x 64 channels, 1: 128 x 32):
+# n, h, w, cin, cout, dilation
+WINO_CASES = [
+    (1, 32, 64, 64, 64, 1),     # whole blocks
+    (2, 37, 53, 24, 40, 1),     # odd grid (partial tiles on both axes), ragged channel counts
+    (1, 41, 50, 40, 70, 3),     # dilation 3: nine sub-lattices of unequal size
+    (1, 24, 40, 128, 128, 2),   # generator atrous shape, two N blocks
+    (2, 16, 16, 568, 32, 1),    # deep ragged slab window (PWC estimator), 32 output channels
+    (1, 9, 7, 8, 96, 1),        # smaller than one block, one K stage
+]
+
+
+@pytest.mark.parametrize("variant,ks", [(0, 1), (1, 1), (0, 3), (1, 2)])
+@pytest.mark.parametrize("case", WINO_CASES)
+def test_conv_winograd_family(ops, force_conv, variant, ks, case):
+    """3x3 stride-1 convolutions and their backward-data pass through the fused Winograd kernel (forward: pack mode 7 layout built
+    from the packed weights; backward-data: the mirrored / transposed tap set), incl. K slices through the split-K slabs."""
+    n, h, w, cin, cout, d = case
+    x = rnd(n, h, w, cin, seed=61).double().requires_grad_(True)
+    wt = rnd(3, 3, cin, cout, seed=62, scale=(2.0 / (9 * cin)) ** 0.5).double()
+    b = rnd(cout, seed=63, scale=0.1).double()
+    y = _oracle_conv(x, wt, b, 1, d, "leaky", 0.1, False)
+    lin = O.conv2d_same(x, wt, None, 1, d)
+    dy = rnd(*y.shape, seed=64).double()
+    gx, = torch.autograd.grad((lin * dy).sum(), [x])
+    force_conv.udet_debug_force_conv((1 << 25) + variant, 0, ks)
+    got = ops.conv2d(x.detach().float().cuda(), wt.float().cuda(), b.float().cuda(), 1, d, "leaky", 0.1, False).cpu()
+    assert (force_conv.udet_debug_last_conv() & 0xff) == 9  # the family under test really ran
+    assert (got - y.detach().float()).abs().max() < 1e-4 * max(1.0, float(y.abs().max()))
+    dx = ops.conv2d_backward_data(dy.float().cuda(), lin.detach().float().cuda(), wt.float().cuda(), (h, w), 1, d, "none", 0.0).cpu()
+    assert (force_conv.udet_debug_last_conv() & 0xff) == 9
+    assert (dx - gx.float()).abs().max() < 2e-4 * max(1.0, float(gx.abs().max()))
+
+
 @pytest.mark.parametrize("case", [(2, 13, 37, 98, 3), (1, 31, 45, 50, 5), (1, 9, 70, 386, 3), (3, 8, 8, 196, 3), (1, 40, 72, 64, 5)])
 def test_two_channel_heads_run_the_direct_kernels(ops, force_conv, case):
     """The flow / up_feat heads (2 output channels over a deep input) and their backward-data pass (2 input channels, wide output):

@@ -156,6 +156,10 @@ struct ConvParams {
   // and the accumulators by 1 / f16_xscale before the epilogue: gradients (backward-data) use 4096 against fp16 underflow.
   int f16;
   float f16_xscale;
+  // Winograd F(2x2,3x3) family (conv_wino.hip): the launch's 3x3 tap set pre-transformed, U = G g G^T laid out
+  // [Kc / 8][16 positions][2 lane halves][wino_np][4 channels]; null: the family is not available for this launch
+  const float* wino_u;
+  int wino_np;
   // real input channels when fewer than Kc (the rest are zero padding of the tensor and zero rows of the packed weights); 0: Kc.
   // Lets the direct kernel for 2-channel inputs (conv_thin.hip) skip the padding.
   int kreal;
@@ -175,6 +179,8 @@ struct PackJob {
   int T, R, C, Kc, ldw, k_split, k_gap, mode;  // mode 0 forward, 1 transposed, 2 bias (dst[c] = b*gamma*c + beta | b),
                                                // 3/4 taps-into-N: dst[kmap(r)][t*C+c] = src[t][r][c] (3) | src[t][c][r] (4)
                                                // 5/6 NN x2 + 3x3 as four 2x2 convolutions (T = 16 = class*4 + tap), forward / transposed
+                                               // 7/8 Winograd U = G g G^T of a 3x3 filter, forward / backward-data (taps mirrored, [k=co][n=ci]):
+                                               //     dst [Kc / 8][16][2][ldw = wino_np][4] (ConvParams::wino_u)
 };
 
 // --------------------------------------------------------------- wgrad ----

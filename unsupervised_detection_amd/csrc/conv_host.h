@@ -10,6 +10,22 @@ bool conv_thin_n_ok(const ConvParams& p);
 bool conv_thin_k_ok(const ConvParams& p);
 int launch_conv_thin_n(const ConvParams& p, hipStream_t stream);
 int launch_conv_thin_k(const ConvParams& p, hipStream_t stream);
+// Winograd F(2x2,3x3) family (conv_wino.hip): eligibility (3x3 taps of uniform dilation, stride 1, Kc % 8 == 0, p.wino_u set), the
+// launch (variant: 0 = 64 tiles x 64 channels per workgroup, 1 = 128 tiles x 32 channels; ks K slices through the split-K slabs)
+// and the weight transform (mode 7 / 8 of PackJob) as a one-off launch
+bool conv_wino_geometry(const ConvParams& p, int* dil, int widx_at[9]);
+bool conv_wino_ok(const ConvParams& p);
+bool conv_wino_variant_ok(const ConvParams& p, int variant);
+int conv_wino_np(int cout);  // padded N extent of the transformed weights
+size_t conv_wino_floats(int Kc, int cout);
+long conv_wino_workgroups(const ConvParams& p, int variant);
+int conv_wino_max_ksplit(const ConvParams& p, int variant);
+int launch_conv_wino(ConvParams& p, int variant, int ks, hipStream_t stream);
+int launch_splitk_second_pass(const ConvParams& p, hipStream_t stream);  // conv_igemm.hip: sums p.partial's ksplit slabs + epilogue
+int launch_wino_pack(const float* src, float* dst, int R, int C, int Kc, int np, int k_split, int k_gap, int transposed, hipStream_t stream);
+// U straight from PACKED weights [tap][Kc][ldw] and the launch's own tap table (single-operator launches, tests)
+int launch_wino_from_packed(const ConvParams& p, float* dst, int np, hipStream_t stream);
+__device__ float wino_pack_elem(const PackJob& j, const float* __restrict__ src, const float* __restrict__ gamma, float bn_c, long e);
 void conv_debug_f16(int on);  // fp16 multiplication in the single-operator launches (plans carry udet_config.conv_fp16)
 int conv_debug_f16_on();
 int conv_last_config();
@@ -27,7 +43,7 @@ void conv_tune_dump(FILE* f);
 void conv_tune_put(unsigned long long key, int bm, int bn, int ks, int ws, int fold, int tail);
 void wgrad_tune_dump(FILE* f);
 // bumped whenever a kernel family, a tile set or a problem key changes: tuning files of another build are rejected (udet_tune_load)
-#define UDET_TUNE_ABI 3
+#define UDET_TUNE_ABI 4
 void wgrad_tune_put(unsigned long long key, int cfg);  // debugging / tuning hook: bm == 0 and ks < 0 restore the heuristics
 bool conv_setup_dgrad(ConvParams& p, int cls, int N, int H, int W, int kh, int kw, int s, int d);
 int launch_pack_weights(const float* src, float* dst, int T, int R, int C, int Kc, int ldw, int k_split, int k_gap,

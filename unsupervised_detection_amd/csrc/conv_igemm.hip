@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "common.h"
+#include "conv_epilogue.h"
 #include "conv_host.h"
 #include <algorithm>
 
@@ -87,54 +88,6 @@ __device__ __forceinline__ void kc_advance(const KOrder& o, KCursor& k, int step
 __device__ __forceinline__ bool kc_valid(const KOrder& o, const KCursor& k) { return k.blk < o.nblk; }
 __device__ __forceinline__ int kc_chan(const KOrder& o, const KCursor& k) { return k.blk * o.CB + k.c; }
 
-// bias, activation, second output, residual, accumulate, store (+ optional dU emission) of one output element
-__device__ __forceinline__ void conv_epilogue(const ConvParams& p, int off, int n, float v) {
-  if (p.bias) v += p.bias[n];
-  v = act_fwd(v, p.act, p.alpha);
-  if (p.y2) p.y2[(size_t)off * p.ldy2 + p.y2_coff + n] = v;
-  if (p.res) v += p.res[(size_t)off * p.ldres + p.res_coff + n];
-  float* dst = p.y + (size_t)off * p.ldy + p.y_coff + n;
-  if (p.accumulate) v += *dst;
-  *dst = v;
-  if (p.uo && n >= p.u_c0 && n < p.u_c1)
-    p.uo[(size_t)off * p.ldu + p.u_coff + n] = v * act_dfo(p.ua[(size_t)off * p.ldua + p.ua_coff + n], p.uact, p.ualpha);
-}
-
-// Four consecutive channels of one output element row at once (every operand 16-byte aligned: epilogue4_ok).
-__device__ __forceinline__ float4 act_fwd4(float4 v, int act, float alpha) {
-  return make_float4(act_fwd(v.x, act, alpha), act_fwd(v.y, act, alpha), act_fwd(v.z, act, alpha), act_fwd(v.w, act, alpha));
-}
-__device__ __forceinline__ void conv_epilogue4(const ConvParams& p, int off, int n, float4 v) {
-  if (p.bias) {
-    v.x += p.bias[n]; v.y += p.bias[n + 1]; v.z += p.bias[n + 2]; v.w += p.bias[n + 3];
-  }
-  v = act_fwd4(v, p.act, p.alpha);
-  if (p.y2) *reinterpret_cast<float4*>(p.y2 + (size_t)off * p.ldy2 + p.y2_coff + n) = v;
-  if (p.res) {
-    const float4 r = *reinterpret_cast<const float4*>(p.res + (size_t)off * p.ldres + p.res_coff + n);
-    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-  }
-  float4* dst = reinterpret_cast<float4*>(p.y + (size_t)off * p.ldy + p.y_coff + n);
-  if (p.accumulate) {
-    const float4 o = *dst;
-    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-  }
-  *dst = v;
-  if (p.uo && n >= p.u_c0 && n < p.u_c1) {  // (u_c0, u_c1 multiples of 4: the quad is inside or outside as a whole)
-    const float4 ua = *reinterpret_cast<const float4*>(p.ua + (size_t)off * p.ldua + p.ua_coff + n);
-    *reinterpret_cast<float4*>(p.uo + (size_t)off * p.ldu + p.u_coff + n) =
-        make_float4(v.x * act_dfo(ua.x, p.uact, p.ualpha), v.y * act_dfo(ua.y, p.uact, p.ualpha), v.z * act_dfo(ua.z, p.uact, p.ualpha),
-                    v.w * act_dfo(ua.w, p.uact, p.ualpha));
-  }
-}
-__device__ __forceinline__ bool epilogue4_out_ok(const ConvParams& p) {  // conv_epilogue4 may be used on this launch's outputs
-  auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-  bool ok = (p.Cout & 3) == 0 && ((p.ldy | p.y_coff) & 3) == 0 && al(p.y);
-  if (p.y2) ok = ok && ((p.ldy2 | p.y2_coff) & 3) == 0 && al(p.y2);
-  if (p.res) ok = ok && ((p.ldres | p.res_coff) & 3) == 0 && al(p.res);
-  if (p.uo) ok = ok && ((p.ldu | p.u_coff | p.ldua | p.ua_coff | p.u_c0 | p.u_c1) & 3) == 0 && al(p.uo) && al(p.ua);
-  return ok;
-}
 // per-wave LDS scratch of the transposing store below: 16 rows x UDET_XP floats, carved out of the (now idle) stage buffers
 #define UDET_XP 40
 template <size_t SA, size_t SB>
@@ -1207,6 +1160,24 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue4_kernel(const ConvPa
   }
 }
 
+// second pass of a split-K launch (no tail split, not folded): sums the ksplit slabs of p.partial and runs the epilogue
+int launch_splitk_second_pass(const ConvParams& p, hipStream_t stream) {
+  const int Mtot = p.N * p.OHq * p.OWq;
+  const long total = (long)p.ncls * Mtot * p.Cout;
+  // lanes per element: keep >= ~64k threads busy while the split count allows it
+  const int sl = (p.ksplit >= 16 && total * 16 <= 262144) ? 16 : ((p.ksplit >= 4 && total * 4 <= 262144) ? 4 : 1);
+  long nbl = (total * sl + 255) / 256;
+  const int nb = (int)(nbl > 4096 ? 4096 : nbl);
+  if (sl == 16) UDET_LAUNCH(conv_splitk_epilogue_kernel<16>, dim3(nb), dim3(256), 0, stream, p);
+  else if (sl == 4) UDET_LAUNCH(conv_splitk_epilogue_kernel<4>, dim3(nb), dim3(256), 0, stream, p);
+  else if (p.ldp % 4 == 0 && !(reinterpret_cast<uintptr_t>(p.partial) & 15)) {
+    const long nb4l = ((long)p.ncls * Mtot * (p.ldp >> 2) + 255) / 256;
+    UDET_LAUNCH(conv_splitk_epilogue4_kernel, dim3((int)(nb4l > 4096 ? 4096 : nb4l)), dim3(256), 0, stream, p);
+  } else UDET_LAUNCH(conv_splitk_epilogue_kernel<1>, dim3(nb), dim3(256), 0, stream, p);
+  UDET_HIP(hipGetLastError());
+  return UDET_OK;
+}
+
 static int g_force_bm = 0, g_force_bn = 0, g_force_ks = -1, g_force_ws = -1, g_force_fold = -1, g_force_tail = 0;
 static int g_last_cfg = 0;  // kernel family / tile / split count of the most recent launch_conv (debug query)
 int conv_last_config() { return g_last_cfg; }
@@ -1218,7 +1189,8 @@ void conv_force_config(int bm, int bn, int ks) {
   // bit 20: split-K through the second launch, bit 21: split-K folded into the last-arriving workgroup;
   // bit 22 / 23: LDS-DMA with a 3 / 4 stage ring; bit 24: the direct 2-channel-head kernels (conv_thin.hip) where a launch is eligible
   g_force_fold = (bm >> 20) & 1 ? 0 : ((bm >> 21) & 1 ? 1 : -1);
-  g_force_ws = (bm >> 16) & 1 ? 0 : ((bm >> 17) & 1 ? 2 : ((bm >> 18) & 1 ? 3 : ((bm >> 19) & 1 ? 6 : ((bm >> 22) & 1 ? 4 : ((bm >> 23) & 1 ? 5 : ((bm >> 24) & 1 ? 7 : -1))))));
+  // bit 25: the Winograd F(2x2,3x3) family (conv_wino.hip) where a launch is eligible; bm & 0xffff = variant (0: 64 tiles x 64 channels, 1: 128 x 32)
+  g_force_ws = (bm >> 16) & 1 ? 0 : ((bm >> 17) & 1 ? 2 : ((bm >> 18) & 1 ? 3 : ((bm >> 19) & 1 ? 6 : ((bm >> 22) & 1 ? 4 : ((bm >> 23) & 1 ? 5 : ((bm >> 24) & 1 ? 7 : ((bm >> 25) & 1 ? 9 : -1)))))));
 }
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
@@ -1259,18 +1231,7 @@ static int launch_cfg(ConvParams& p, int ws, hipStream_t stream) {
     UDET_LAUNCH(conv_splitk_epilogue4_kernel, dim3((int)(nb4l > 4096 ? 4096 : nb4l)), dim3(256), 0, stream, p);
     UDET_HIP(hipGetLastError());
   } else if (p.ksplit > 1 && !p.fold) {
-    const long total = (long)p.ncls * Mtot * p.Cout;
-    // lanes per element: keep >= ~64k threads busy while the split count allows it
-    const int sl = (p.ksplit >= 16 && total * 16 <= 262144) ? 16 : ((p.ksplit >= 4 && total * 4 <= 262144) ? 4 : 1);
-    long nbl = (total * sl + 255) / 256;
-    const int nb = (int)(nbl > 4096 ? 4096 : nbl);
-    if (sl == 16) UDET_LAUNCH(conv_splitk_epilogue_kernel<16>, dim3(nb), dim3(256), 0, stream, p);
-    else if (sl == 4) UDET_LAUNCH(conv_splitk_epilogue_kernel<4>, dim3(nb), dim3(256), 0, stream, p);
-    else if (p.ldp % 4 == 0 && !(reinterpret_cast<uintptr_t>(p.partial) & 15)) {
-      const long nb4l = ((long)p.ncls * Mtot * (p.ldp >> 2) + 255) / 256;
-      UDET_LAUNCH(conv_splitk_epilogue4_kernel, dim3((int)(nb4l > 4096 ? 4096 : nb4l)), dim3(256), 0, stream, p);
-    } else UDET_LAUNCH(conv_splitk_epilogue_kernel<1>, dim3(nb), dim3(256), 0, stream, p);
-    UDET_HIP(hipGetLastError());
+    UDET_TRY(launch_splitk_second_pass(p, stream));
   }
   return UDET_OK;
 }
@@ -1349,6 +1310,7 @@ static int run_cfg(ConvParams& p, const ConvCfg& c, hipStream_t stream) {
     p.ksplit = 1; p.fold = 0; p.tail_full = 0; p.tail_ks = 0;
     return c.ws == 7 ? launch_conv_thin_k(p, stream) : launch_conv_thin_n(p, stream);
   }
+  if (c.ws == 9) return launch_conv_wino(p, c.bm, c.ks, stream);  // Winograd F(2x2,3x3) (conv_wino.hip); bm carries the variant
   if (c.ws == 3) {  // tile-resident direct convolution (conv_tile.hip); bm carries the tile height
     p.ksplit = 1;
     p.fold = 0;
@@ -1456,7 +1418,8 @@ bool tune_compare(const float* a, const float* b, size_t n, hipStream_t stream, 
 
 static uint64_t conv_key(const ConvParams& p) {
   const int f[] = {p.N, p.H, p.W, p.up_shift, p.Kc, p.Cout, p.ntaps, p.ncls, p.OHq, p.OWq, p.isy, p.osy, p.xa ? 1 : 0,
-                   p.ldx, p.ldy, p.accumulate, p.res ? 1 : 0, p.y2 ? 1 : 0, p.partial ? 1 : 0, p.cls_tap[1], p.uo ? 1 : 0, p.f16 ? 1 : 0, p.kreal};
+                   p.ldx, p.ldy, p.accumulate, p.res ? 1 : 0, p.y2 ? 1 : 0, p.partial ? 1 : 0, p.cls_tap[1], p.uo ? 1 : 0, p.f16 ? 1 : 0, p.kreal,
+                   p.wino_u ? p.wino_np : 0};
   uint64_t h = 1469598103934665603ull;
   for (int v : f) { h ^= (uint64_t)(uint32_t)v; h *= 1099511628211ull; }
   return h;
@@ -1579,6 +1542,27 @@ static ConvCfg tune_cfg_impl(ConvParams& p, hipStream_t stream) {
     const float ms = time_cfg(p, d, 5, stream);
     if (ms < (a < b ? a : b) * 0.97f) { a = b = ms; best = d; }
   }
+  if (conv_wino_ok(p)) {  // Winograd F(2x2,3x3): 2.25x fewer multiplications; K slices where the tiles do not fill the chip
+    for (int v = 0; v < 2; ++v) {
+      if (!conv_wino_variant_ok(p, v)) continue;
+      const long wgs = conv_wino_workgroups(p, v);
+      const int cap = conv_wino_max_ksplit(p, v);
+      std::vector<int> kss = {1};
+      if (wgs < 384)
+        for (int r = 1; r <= 3; ++r) {
+          const int ks = (int)(256L * r / (wgs > 0 ? wgs : 1));
+          if (ks >= 2 && ks <= cap && std::find(kss.begin(), kss.end(), ks) == kss.end()) kss.push_back(ks);
+        }
+      for (int ks : kss) {
+        const ConvCfg d = {v, 0, ks, 9, 0, 0};
+        const float ms = time_cfg(p, d, 3, stream);
+        if (ms < (a < b ? a : b) * 0.97f) {
+          const float ms5 = time_cfg(p, d, 5, stream);
+          if (ms5 < (a < b ? a : b) * 0.97f) { a = b = ms5; best = d; }
+        }
+      }
+    }
+  }
   if (best.ks > 1 && best.ws != 3 && best.ws < 7 && best.tail == 0) {  // the other way of summing the slabs: last-arriving workgroup <-> second launch
     const ConvCfg w = best;
     for (int ks : {w.ks, w.ks / 2, w.ks / 4}) {  // the folded form sums its slabs in one workgroup: fewer slabs may suit it better
@@ -1673,10 +1657,11 @@ int launch_conv(ConvParams& p, hipStream_t stream) {
     for (auto& t : TILES) tile = tile || (c.bm == t[0] && c.bn == t[1]);
     if (c.ws == 3) tile = (c.bm == 4 || c.bm == 8) && (c.bn == 16 || c.bn == 32);
     if (c.ws == 7 || c.ws == 8) tile = true;  // (the direct 2-channel kernels carry no tile; eligibility is re-checked below)
-    if (!tile || c.ws < 0 || c.ws > 8) {
+    if (c.ws == 9) tile = c.bm == 0 || c.bm == 1;  // (Winograd: bm carries the variant; eligibility is re-checked below)
+    if (!tile || c.ws < 0 || c.ws > 9) {
       c = heuristic_cfg(p);
     } else {
-      const int cap = max_ksplit(p);
+      const int cap = c.ws == 9 ? 16 : max_ksplit(p);  // (launch_conv_wino clamps to its own capacity)
       if (c.ks < 1) c.ks = 1;
       if (c.ks > cap) { c.ks = cap; c.tail = 0; }
       c.fold = c.fold ? 1 : 0;
@@ -1696,8 +1681,8 @@ int launch_conv(ConvParams& p, hipStream_t stream) {
       else if (!g_force_bm && !p.f16 && conv_thin_k_ok(p)) c.ws = 7;
     }
   }
-  if (g_force_bm) { c.bm = g_force_bm; c.bn = g_force_bn; }
-  if (g_force_ks >= 0) { c.ks = g_force_ks > max_ksplit(p) ? max_ksplit(p) : g_force_ks; c.tail = 0; }
+  if (g_force_bm && g_force_ws != 9) { c.bm = g_force_bm; c.bn = g_force_bn; }
+  if (g_force_ks >= 0) { c.ks = (g_force_ks > max_ksplit(p) && g_force_ws != 9) ? max_ksplit(p) : g_force_ks; c.tail = 0; }
   if (g_force_ws >= 0) c.ws = g_force_ws;
   if (g_force_fold >= 0) c.fold = g_force_fold;
   if (g_force_tail > 0) {
@@ -1710,6 +1695,30 @@ int launch_conv(ConvParams& p, hipStream_t stream) {
   if (g_force_ws == 7) c.ws = conv_thin_k_ok(p) ? 7 : (conv_thin_n_ok(p) ? 8 : heuristic_cfg(p).ws);
   if ((c.ws == 7 && !conv_thin_k_ok(p)) || (c.ws == 8 && !conv_thin_n_ok(p)) || ((c.ws == 7 || c.ws == 8) && p.f16)) c = heuristic_cfg(p);
   if (c.ws == 3 && !tile_ok(p, c.bm, c.bn == 16 ? 16 : 32)) { c = heuristic_cfg(p); }
+  if (g_force_ws == 9) {  // test / tool hook: a single-operator launch carries no transformed weights -- build them here, from the packed ones
+    int d9, w9[9];
+    if (!p.wino_u && !p.f16 && !p.xa && p.Kc % 8 == 0 && p.Kc >= 8 && conv_wino_geometry(p, &d9, w9)) {
+      static float* g_wino_scratch = nullptr;
+      static size_t g_wino_cap = 0;
+      static std::mutex mu;
+      std::lock_guard<std::mutex> l(mu);
+      const int np9 = conv_wino_np(p.Cout);
+      const size_t need = (size_t)(p.Kc / 8) * 16 * 2 * np9 * 4;
+      if (need > g_wino_cap) {
+        (void)hipStreamSynchronize(stream);
+        if (g_wino_scratch) (void)hipFree(g_wino_scratch);
+        g_wino_scratch = nullptr; g_wino_cap = 0;
+        if (hipMalloc(reinterpret_cast<void**>(&g_wino_scratch), need * sizeof(float)) == hipSuccess) g_wino_cap = need;
+      }
+      if (g_wino_scratch && launch_wino_from_packed(p, g_wino_scratch, np9, stream) == UDET_OK) { p.wino_u = g_wino_scratch; p.wino_np = np9; }
+    }
+    const int v9 = g_force_bm & 1;
+    if (conv_wino_ok(p) && (conv_wino_variant_ok(p, v9) || conv_wino_variant_ok(p, 1 - v9))) {
+      c.ws = 9; c.bm = conv_wino_variant_ok(p, v9) ? v9 : 1 - v9; c.bn = 0; c.fold = 0; c.tail = 0;
+      if (g_force_ks < 0) c.ks = 1;
+    } else if (c.ws == 9) c = heuristic_cfg(p);
+  }
+  if (c.ws == 9 && (!conv_wino_ok(p) || !conv_wino_variant_ok(p, c.bm))) c = heuristic_cfg(p);
   g_last_cfg = (c.ws & 0xff) | ((c.bm & 0xfff) << 8) | ((c.ks & 0xff) << 20) | ((c.ks > 1 && c.fold && c.ws != 3 && p.tickets ? 1 : 0) << 28) |
                ((c.ks > 1 && c.tail > 0 ? 1 : 0) << 29);
   return run_cfg(p, c, stream);

@@ -1,0 +1,470 @@
+// Fused Winograd F(2x2,3x3) convolution on the fp32 matrix cores of gfx950 (v_mfma_f32_32x32x2_f32).
+//
+//   Y = A^T [ sum_c (G g_c G^T) .* (B^T d_c B) ] A          16 multiplications per 2x2 output tile and channel pair instead of 36
+//
+// for the 3x3 stride-1 convolutions of the path (PWC-Net's dense estimators and context networks, the generator's 64 / 128-channel
+// layers) and their backward-data passes (a 3x3 stride-1 convolution with mirrored taps and transposed weights).  Dilation d is
+// handled as d*d independent d = 1 problems on the output sub-lattices.
+//
+// One workgroup = 4 waves = ONE wave per SIMD with the 512-register budget.  A wave owns ALL 16 Winograd positions of a
+// 32-tile x 32-channel block: 16 accumulators = 256 registers, so the output transform A^T M A needs no cross-wave traffic.
+// Workgroup tile = (WTY x WTX x WN waves): (4 WTY) x (8 WTX) tiles of 2x2 pixels, 32 WN output channels.
+// K runs in stages of 8 input channels over a 3-buffer LDS ring:
+//   input stage : the RAW (2 TH + 2) x (2 TW + 2) pixel halo, [channel quad][row][column parity][column / 2][4 channels]
+//                 (16-byte slots; row stride == 4 (mod 8) slots makes the ds_read_b128 of a lane's 4x4 patch conflict-free);
+//                 the input transform B^T d B (32 additions per channel) sits on the LDS -> VGPR path
+//   weight stage: the pre-transformed U = G g G^T as the lane layout of the MFMA B operand, [position][lane half][n][4 channels]
+//                 (ConvParams::wino_u, built by pack mode 7 / 8 whenever the weights are re-laid-out)
+// both land by global_load_lds_dwordx4 issued by the MFMA waves themselves.  Lanes 0-31 hold channels 0-3 of the stage, lanes
+// 32-63 channels 4-7: MFMA j of a position consumes component j of both lane halves (K = 2 per MFMA).
+// The loop is software-pipelined by hand for one wave per SIMD: a stage is four phases (phase i = position row i: 16 MFMAs on 4
+// accumulators), the LDS reads of phase i + 1 are issued before the multiplications of phase i, and the wait + barrier that hands
+// stage k + 1 over sits between phases 2 and 3 of stage k -- phase 3 prefetches phase 0 of the next stage, so no phase starts by
+// waiting out the LDS latency behind a barrier.  The DMA is inline assembly on purpose: behind the builtin, hipcc orders every later
+// LDS read after the DMA with s_waitcnt vmcnt(0) (it models the DMA as a store to LDS), which serialises fill and multiplication in
+// a kernel whose waves do both.
+//
+// Replaces the TF-1.13 Conv2D / Conv2DBackpropInput kernels behind the 3x3 stride-1 layers of
+// models/PWCNet/model_pwcnet.py:476-506,559-576 and models/nets.py:19-36 (same call sites as conv_igemm.hip).
+// Measured (tools/wino_bench.hip, profiles/r04_wino_proto_v2.txt): pwcnet/ctxt/dc_conv21 439 us against 701 us for the
+// implicit GEMM (182 TFLOP/s direct-equivalent); error against a double-precision direct convolution 1.3e-6 of the output scale.
+#include <string.h>
+
+#include <mutex>
+
+#include "common.h"
+#include "conv_epilogue.h"
+#include "conv_host.h"
+
+namespace udet {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+static constexpr int wino_row_slots(int pw) { return (pw + 3) / 8 * 8 + 4; }  // smallest S >= pw with S % 8 == 4
+
+template <int WTY, int WTX, int WN>
+struct WinoGeom {
+  static constexpr int NS = 3;
+  static constexpr int TH = 4 * WTY, TW = 8 * WTX;        // tiles of a workgroup
+  static constexpr int PH = 2 * TH + 2, PW = 2 * TW + 2;  // halo pixels
+  static constexpr int CS = PW / 2;                       // used slots per column parity
+  static constexpr int S = wino_row_slots(PW);            // slots per halo row
+  static constexpr int HP = S / 2;                        // slot offset of the odd columns
+  static constexpr int IN_SLOTS = 2 * PH * S;
+  static constexpr int IN_INSTR = (IN_SLOTS + 255) / 256;  // DMA instructions per wave and stage (input)
+  static constexpr int IN_BYTES = IN_INSTR * 256 * 16;
+  static constexpr int BN = 32 * WN;
+  static constexpr int W_BYTES = 16 * 2 * BN * 16;
+  static constexpr int W_INSTR = W_BYTES / 4096;  // (weights)
+  static constexpr int STAGE = IN_BYTES + W_BYTES;
+  static constexpr int L = IN_INSTR + W_INSTR;
+  static constexpr int LA = (L + 1) / 2;  // part A of a stage's DMA (issued in phase 3), the rest in the next phase 0
+  static constexpr int LDS_BYTES = NS * STAGE;
+  static_assert(S % 8 == 4 && S >= PW && HP >= CS, "row stride");
+  static_assert(LDS_BYTES >= 4 * 128 * 32 * 4 && LDS_BYTES <= 160 * 1024, "the epilogue transposes 16 KB per wave through the stage buffers");
+};
+
+template <int WTY, int WTX, int WN>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_wino_kernel(const ConvParams p, const int dil,
+                                                                                                  const int BY, const int BX) {
+  static_assert(WTY * WTX * WN == 4, "4 waves");
+  typedef WinoGeom<WTY, WTX, WN> G;
+  constexpr int NS = G::NS, TH = G::TH, TW = G::TW, PH = G::PH, S = G::S, HP = G::HP, CS = G::CS;
+  constexpr int IN_INSTR = G::IN_INSTR, IN_BYTES = G::IN_BYTES, BN = G::BN, STAGE = G::STAGE, L = G::L, LA = G::LA;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int wn = wave % WN, wt = wave / WN, wty = wt / WTX, wtx = wt % WTX;
+
+  // XCD-aware block order: consecutive blocks (which share input halos) stay on one XCD's L2
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int d = dil;
+  const int bx = bid % BX;
+  int rem = bid / BX;
+  const int by = rem % BY;
+  rem /= BY;
+  const int sx = rem % d;
+  rem /= d;
+  const int sy = rem % d;
+  const int n = rem / d;
+  const int Hs = (p.H - sy + d - 1) / d, Ws = (p.W - sx + d - 1) / d;  // this output sub-lattice's grid
+  const int Y0 = by * 2 * TH, X0 = bx * 2 * TW;                          // first output pixel (sub-lattice coordinates)
+  const int nb = blockIdx.y;
+  // K slice of this workgroup (stages of 8 channels)
+  const int nkg_all = p.Kc >> 3;
+  int kg0 = 0, kg1 = nkg_all;
+  if (p.ksplit > 1) {
+    kg0 = (int)((long)nkg_all * blockIdx.z / p.ksplit);
+    kg1 = (int)((long)nkg_all * (blockIdx.z + 1) / p.ksplit);
+  }
+
+  // ---- per-lane DMA sources (constant over the stages up to the channel offset) ----
+  int in_off[IN_INSTR];
+#pragma unroll
+  for (int i = 0; i < IN_INSTR; ++i) {
+    const int Lx = (i * 4 + wave) * 64 + lane;
+    const int quad = Lx / (PH * S), r2 = Lx - quad * (PH * S);
+    const int row = r2 / S, s = r2 - row * S;
+    const int par = s / HP, cs = s - par * HP;
+    const int col = 2 * cs + par;
+    const int yy = Y0 - 1 + row, xx = X0 - 1 + col;
+    const bool ok = quad < 2 && cs < CS && yy >= 0 && yy < Hs && xx >= 0 && xx < Ws;
+    in_off[i] = ok ? ((n * p.H + sy + d * yy) * p.W + sx + d * xx) * p.ldx + p.x_coff + quad * 4 : -1;
+  }
+  const float* zero = p.zero16;
+  // weights: (position, lane half) pair `pr` is a run of BN * 16 bytes at U + ((kg * 32 + pr) * np + nb * BN) * 4 floats
+  const int np = p.wino_np;
+  const float* ubase = p.wino_u + (size_t)nb * BN * 4;
+  const size_t ustride = (size_t)32 * np * 4;  // floats per stage
+  unsigned w_voff;                             // this lane's byte offset inside a weight DMA instruction
+  if (BN == 64) w_voff = lane * 16;
+  else if (BN == 32) w_voff = (unsigned)((lane >> 5) * np + (lane & 31)) * 16;
+  else w_voff = lane * 16;
+
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  // DMA instructions [i0, i1) of stage kg into ring buffer `buf` (instruction index: input first, then weights)
+  auto issue = [&](int kg, int buf, int i0, int i1) {
+    const unsigned sb = lds0 + buf * STAGE;
+    const int c0 = kg * 8;
+    const float* us = ubase + (size_t)kg * ustride;
+#pragma unroll
+    for (int i = 0; i < L; ++i) {
+      if (i < i0 || i >= i1) continue;
+      if (i < IN_INSTR) {
+        const float* src = in_off[i] >= 0 ? p.x + (in_off[i] + c0) : zero;
+        asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(sb + (i * 4 + wave) * 1024) : "m0");
+      } else {
+        const int w = (i - IN_INSTR) * 4 + wave;  // wave-instruction index of the weight stage (1 KB each)
+        const float* src;
+        if (BN == 64) src = us + (size_t)w * np * 4;
+        else if (BN == 32) src = us + (size_t)(2 * w) * np * 4;
+        else src = us + (size_t)(w >> 1) * np * 4 + (w & 1) * 256;
+        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(w_voff), "s"(src), "s"(sb + IN_BYTES + w * 1024) : "m0");
+      }
+    }
+  };
+
+  floatx16 acc[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+  const int ty = li >> 3, tx = li & 7;
+  const int a_base = ((lh * PH + 2 * (wty * 4 + ty)) * S + (wtx * 8 + tx)) * 16;  // this lane's patch origin inside an input stage
+  const int b_base = IN_BYTES + (lh * BN + wn * 32 + li) * 16;
+
+  float4 row[4][4];
+  float4 bfr[2][4];
+  auto ld_row = [&](const char* sb, int r) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) row[r][c] = *reinterpret_cast<const float4*>(sb + a_base + (r * S + (c & 1) * HP + (c >> 1)) * 16);
+  };
+  auto ld_bf = [&](const char* sb, int i, int s) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bfr[s][q] = *reinterpret_cast<const float4*>(sb + b_base + (4 * i + q) * (2 * BN * 16));
+  };
+  auto comp = [](const float4& v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); };
+
+  const int nkg = kg1 - kg0;
+  if (nkg > 0) {
+    issue(kg0, 0, 0, L);
+    if (nkg > 1) issue(kg0 + 1, 1, 0, L);
+    if (nkg > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    ld_row(smem, 0);
+    ld_row(smem, 2);
+    ld_bf(smem, 0, 0);
+  }
+
+  int buf = 0;
+  for (int k = 0; k < nkg; ++k) {
+    const char* sb = smem + buf * STAGE;
+    const int b1 = buf + 1 == NS ? 0 : buf + 1, b2 = b1 + 1 == NS ? 0 : b1 + 1;
+    const char* sbn = smem + b1 * STAGE;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      // ---- LDS reads of the next phase, DMA parts ----
+      if (i == 0) {
+        ld_row(sb, 1);
+        ld_bf(sb, 1, 1);
+        if (k > 0 && k + 1 < nkg) issue(kg0 + k + 1, b1, LA, L);  // part B of the stage whose part A went out in the previous phase 3
+      } else if (i == 1) {
+        ld_bf(sb, 2, 0);
+      } else if (i == 2) {
+        ld_row(sb, 3);
+        ld_bf(sb, 3, 1);
+      } else {
+        ld_row(sbn, 0);
+        ld_row(sbn, 2);
+        ld_bf(sbn, 0, 0);
+        if (k + 2 < nkg) issue(kg0 + k + 2, b2, 0, LA);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- phase i: position row i.  t = B^T d row i: d0 - d2, d1 + d2, d2 - d1, d1 - d3 ----
+      constexpr int RA[4] = {0, 1, 2, 1}, RB[4] = {2, 2, 1, 3};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float t[4], v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float a = comp(row[RA[i]][c], j), b = comp(row[RB[i]][c], j);
+          t[c] = i == 1 ? a + b : a - b;
+        }
+        v[0] = t[0] - t[2];
+        v[1] = t[1] + t[2];
+        v[2] = t[2] - t[1];
+        v[3] = t[1] - t[3];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          acc[4 * i + q] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[q], comp(bfr[i & 1][q], j), acc[4 * i + q], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (i == 2) {  // stage k + 1 is in LDS for every wave; the buffer of stage k - 1 is free
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+    }
+    buf = b1;
+  }
+
+  // ---- output transform Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1], through LDS so that a lane leaves with four channels ----
+  __syncthreads();  // (every wave has read its last fragments: the stage buffers are free)
+  float* xp = reinterpret_cast<float*>(smem) + wave * (128 * 32);  // [tile pixel 128][channel 32] of this wave
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;  // tile of the wave's 4 x 8 block held by accumulator register r
+    float s[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      s[i][0] = acc[i * 4 + 0][r] + acc[i * 4 + 1][r] + acc[i * 4 + 2][r];
+      s[i][1] = acc[i * 4 + 1][r] - acc[i * 4 + 2][r] - acc[i * 4 + 3][r];
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      xp[(m * 4 + b) * 32 + li] = s[0][b] + s[1][b] + s[2][b];      // pixel (a = 0, b)
+      xp[(m * 4 + 2 + b) * 32 + li] = s[1][b] - s[2][b] - s[3][b];  // pixel (a = 1, b)
+    }
+  }
+  __builtin_amdgcn_wave_barrier();  // same wave: LDS serves its instructions in order, only the compiler must not reorder
+  const bool slab = p.ksplit > 1;
+  const bool vec = slab ? ((reinterpret_cast<uintptr_t>(p.partial) & 15) == 0 && (p.ldp & 3) == 0) : epilogue4_out_ok(p);
+  const int c4 = (lane & 7) * 4, n4 = nb * BN + wn * 32 + c4;
+  const long slab_off = (long)blockIdx.z * p.N * p.H * p.W * p.ldp;
+#pragma unroll 1
+  for (int k = 0; k < 16; ++k) {
+    const int P = k * 8 + (lane >> 3);
+    const int m = P >> 2, a = (P >> 1) & 1, b = P & 1;
+    const int oy = Y0 + 2 * (wty * 4 + (m >> 3)) + a, ox = X0 + 2 * (wtx * 8 + (m & 7)) + b;
+    const float4 v = *reinterpret_cast<const float4*>(&xp[P * 32 + c4]);
+    if (oy >= Hs || ox >= Ws) continue;
+    const int off = (n * p.H + sy + d * oy) * p.W + sx + d * ox;
+    if (slab) {
+      float* dst = p.partial + (slab_off + (long)off * p.ldp + n4);
+      if (vec) {
+        if (n4 < p.ldp) *reinterpret_cast<float4*>(dst) = v;
+      } else {
+        if (n4 < p.ldp) dst[0] = v.x;
+        if (n4 + 1 < p.ldp) dst[1] = v.y;
+        if (n4 + 2 < p.ldp) dst[2] = v.z;
+        if (n4 + 3 < p.ldp) dst[3] = v.w;
+      }
+      continue;
+    }
+    if (vec) {
+      if (n4 < p.Cout) conv_epilogue4(p, off, n4, v);
+    } else {
+      if (n4 < p.Cout) conv_epilogue(p, off, n4, v.x);
+      if (n4 + 1 < p.Cout) conv_epilogue(p, off, n4 + 1, v.y);
+      if (n4 + 2 < p.Cout) conv_epilogue(p, off, n4 + 2, v.z);
+      if (n4 + 3 < p.Cout) conv_epilogue(p, off, n4 + 3, v.w);
+    }
+  }
+}
+
+// ---- weight transform: U = G g G^T, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1] -------------------------------------------------------
+// element e of dst [Kc / 8][16][2][np = j.ldw][4] from the HWIO source [9][R = Cin][C = Cout]; mode 7: K = input channels (gap map of
+// the slab padding), N = output channels; mode 8 (backward-data): K = output channels, N = input channels, taps mirrored
+__device__ float wino_pack_elem(const PackJob& j, const float* __restrict__ src, const float* __restrict__ gamma, float bn_c, long e) {
+  const int jj = (int)(e & 3);
+  const long r0 = e >> 2;
+  const int n = (int)(r0 % j.ldw);
+  const long r1 = r0 / j.ldw;
+  const int kh = (int)(r1 & 1), pos = (int)((r1 >> 1) & 15), kg = (int)(r1 >> 5);
+  const int k = kg * 8 + kh * 4 + jj;
+  int ks = k;
+  if (k >= j.k_split) ks = (k < j.k_split + j.k_gap) ? -1 : k - j.k_gap;
+  const int ci = j.mode == 7 ? ks : n, co = j.mode == 7 ? n : ks;
+  if (ci < 0 || ci >= j.R || co < 0 || co >= j.C) return 0.f;
+  const float Gm[4][3] = {{1.f, 0.f, 0.f}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0.f, 0.f, 1.f}};
+  const int pi = pos >> 2, pj = pos & 3;
+  float val = 0.f;
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const int ky = j.mode == 7 ? a : 2 - a, kx = j.mode == 7 ? b : 2 - b;
+      val += Gm[pi][a] * Gm[pj][b] * src[((long)(ky * 3 + kx) * j.R + ci) * j.C + co];
+    }
+  if (gamma) val *= gamma[co] * bn_c;
+  return val;
+}
+__global__ __launch_bounds__(256) void wino_pack_kernel(const PackJob j, const float* __restrict__ src, float* __restrict__ dst) {
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < j.total; e += (long)gridDim.x * 256) dst[e] = wino_pack_elem(j, src, nullptr, 1.f, e);
+}
+int launch_wino_pack(const float* src, float* dst, int R, int C, int Kc, int np, int k_split, int k_gap, int transposed, hipStream_t stream) {
+  PackJob j;
+  memset(&j, 0, sizeof(j));
+  j.T = 9; j.R = R; j.C = C; j.Kc = Kc; j.ldw = np; j.k_split = k_split; j.k_gap = k_gap;
+  j.mode = transposed ? 8 : 7; j.total = (long)(Kc / 8) * 16 * 2 * np * 4; j.gamma_off = -1;
+  int nb = (int)((j.total + 255) / 256);
+  if (nb > 2048) nb = 2048;
+  UDET_LAUNCH(wino_pack_kernel, dim3(nb), dim3(256), 0, stream, j, src, dst);
+  UDET_HIP(hipGetLastError());
+  return UDET_OK;
+}
+// from PACKED weights [tap][Kc][ldw] + the launch's tap table: widx_at[a * 3 + b] is the packed tap at offset ((a-1) d, (b-1) d)
+struct WinoTapMap { int w[9]; };
+__global__ __launch_bounds__(256) void wino_from_packed_kernel(const float* __restrict__ wp, int Kc, int ldw, WinoTapMap tm, float* __restrict__ dst,
+                                                               int np, long total) {
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int jj = (int)(e & 3);
+    const long r0 = e >> 2;
+    const int n = (int)(r0 % np);
+    const long r1 = r0 / np;
+    const int kh = (int)(r1 & 1), pos = (int)((r1 >> 1) & 15), kg = (int)(r1 >> 5);
+    const int k = kg * 8 + kh * 4 + jj;
+    float val = 0.f;
+    if (n < ldw && k < Kc) {
+      const float Gm[4][3] = {{1.f, 0.f, 0.f}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0.f, 0.f, 1.f}};
+      const int pi = pos >> 2, pj = pos & 3;
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) val += Gm[pi][a] * Gm[pj][b] * wp[((long)tm.w[a * 3 + b] * Kc + k) * ldw + n];
+    }
+    dst[e] = val;
+  }
+}
+int launch_wino_from_packed(const ConvParams& p, float* dst, int np, hipStream_t stream) {
+  int d = 0;
+  WinoTapMap tm;
+  if (!conv_wino_geometry(p, &d, tm.w)) {
+    set_error("wino: the launch is not a 3x3 stride-1 convolution");
+    return UDET_ERR_UNSUPPORTED;
+  }
+  const long total = (long)(p.Kc / 8) * 16 * 2 * np * 4;
+  int nb = (int)((total + 255) / 256);
+  if (nb > 2048) nb = 2048;
+  UDET_LAUNCH(wino_from_packed_kernel, dim3(nb), dim3(256), 0, stream, p.wp, p.Kc, p.ldw, tm, dst, np, total);
+  UDET_HIP(hipGetLastError());
+  return UDET_OK;
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------------------
+int conv_wino_np(int cout) { return cout > 64 ? round_up(cout, 128) : (cout > 32 ? 64 : 32); }
+size_t conv_wino_floats(int Kc, int cout) { return (size_t)(Kc / 8) * 16 * 2 * conv_wino_np(cout) * 4; }
+
+// the launch's taps are the 3x3 grid {-d, 0, d}^2 of a stride-1 convolution onto the input grid
+bool conv_wino_geometry(const ConvParams& p, int* dil, int widx_at[9]) {
+  if (p.ntaps != 9 || p.ncls == 4 || p.up_shift != 0) return false;
+  if (p.isy != 1 || p.isx != 1 || p.osy != 1 || p.osx != 1 || p.ooy != 0 || p.oox != 0) return false;
+  if (p.OH != p.H || p.OW != p.W || p.OHq != p.OH || p.OWq != p.OW) return false;
+  int d = 0;
+  for (int t = 0; t < 9; ++t) {
+    const int a = p.taps[t].dy < 0 ? -p.taps[t].dy : p.taps[t].dy;
+    if (a > d) d = a;
+  }
+  if (d < 1) return false;
+  for (int i = 0; i < 9; ++i) widx_at[i] = -1;
+  for (int t = 0; t < 9; ++t) {
+    const int dy = p.taps[t].dy, dx = p.taps[t].dx;
+    if (dy % d != 0 || dx % d != 0) return false;
+    const int a = dy / d + 1, b = dx / d + 1;
+    if (a < 0 || a > 2 || b < 0 || b > 2 || widx_at[a * 3 + b] >= 0) return false;
+    widx_at[a * 3 + b] = p.taps[t].widx;
+  }
+  *dil = d;
+  return true;
+}
+bool conv_wino_ok(const ConvParams& p) {
+  int d, w[9];
+  if (p.f16 || p.xa != nullptr || p.wino_u == nullptr || p.zero16 == nullptr) return false;
+  if ((reinterpret_cast<uintptr_t>(p.zero16) | reinterpret_cast<uintptr_t>(p.wino_u) | reinterpret_cast<uintptr_t>(p.x)) & 15) return false;
+  if (p.Kc < 8 || p.Kc % 8 != 0 || p.ldx % 4 != 0 || p.x_coff % 4 != 0) return false;
+  if (p.wino_np < 32 || p.wino_np % 32 != 0 || p.wino_np < p.Cout) return false;
+  if ((long)p.N * p.H * p.W * (long)(p.ldx > p.ldy ? p.ldx : p.ldy) >= (1L << 31)) return false;  // 32-bit element offsets
+  return conv_wino_geometry(p, &d, w);
+}
+static int variant_bn(int v) { return v == 0 ? 64 : 32; }
+bool conv_wino_variant_ok(const ConvParams& p, int v) {
+  if (v < 0 || v > 1) return false;
+  const int bn = variant_bn(v);
+  if (p.wino_np % bn != 0) return false;
+  return p.Cout > bn / 2 || bn == 32;  // (a block twice as wide as the layer only multiplies zeros)
+}
+static void variant_blocks(const ConvParams& p, int v, int d, int* BY, int* BX) {
+  const int th = 8, tw = v == 1 ? 16 : 8;  // tiles per workgroup
+  const int Hs = (p.H + d - 1) / d, Ws = (p.W + d - 1) / d;
+  *BY = (Hs + 2 * th - 1) / (2 * th);
+  *BX = (Ws + 2 * tw - 1) / (2 * tw);
+}
+long conv_wino_workgroups(const ConvParams& p, int v) {
+  int d, w[9], BY, BX;
+  if (!conv_wino_geometry(p, &d, w)) return 0;
+  variant_blocks(p, v, d, &BY, &BX);
+  return (long)p.N * d * d * BY * BX * ((p.Cout + variant_bn(v) - 1) / variant_bn(v));
+}
+int conv_wino_max_ksplit(const ConvParams& p, int v) {
+  (void)v;
+  if (!p.partial) return 1;
+  int ks = (p.Kc / 8) / 6;  // >= 6 stages per slice
+  if (ks > 16) ks = 16;
+  const size_t per_split = (size_t)p.N * p.H * p.W * ((p.Cout + 3) & ~3);
+  while (ks > 1 && per_split * ks > p.partial_cap) --ks;
+  return ks < 1 ? 1 : ks;
+}
+int launch_splitk_second_pass(const ConvParams& p, hipStream_t stream);
+
+template <int WTY, int WTX, int WN>
+static int launch_variant(const ConvParams& p, int d, int BY, int BX, hipStream_t stream) {
+  typedef WinoGeom<WTY, WTX, WN> G;
+  auto kern = conv_wino_kernel<WTY, WTX, WN>;
+  static std::once_flag once;
+  static hipError_t attr = hipSuccess;
+  std::call_once(once, [&]() { attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES); });
+  UDET_HIP(attr);
+  dim3 grid(p.N * d * d * BY * BX, (p.Cout + G::BN - 1) / G::BN, p.ksplit > 1 ? p.ksplit : 1);
+  UDET_LAUNCH(kern, grid, dim3(256), G::LDS_BYTES, stream, p, d, BY, BX);
+  UDET_HIP(hipGetLastError());
+  return UDET_OK;
+}
+int launch_conv_wino(ConvParams& p, int variant, int ks, hipStream_t stream) {
+  int d, w[9], BY, BX;
+  if (!conv_wino_ok(p) || !conv_wino_geometry(p, &d, w) || !conv_wino_variant_ok(p, variant)) {
+    set_error("wino: launch not eligible (variant %d)", variant);
+    return UDET_ERR_UNSUPPORTED;
+  }
+  variant_blocks(p, variant, d, &BY, &BX);
+  const int cap = conv_wino_max_ksplit(p, variant);
+  p.ksplit = ks > cap ? cap : (ks < 1 ? 1 : ks);
+  p.fold = 0; p.tail_full = 0; p.tail_ks = 0; p.tail_prow0 = 0;
+  p.ncls = 1;
+  if (p.ksplit > 1) p.ldp = (p.Cout + 3) & ~3;
+  int rc;
+  if (variant == 0) rc = launch_variant<2, 1, 2>(p, d, BY, BX, stream);
+  else rc = launch_variant<2, 2, 1>(p, d, BY, BX, stream);
+  if (rc != UDET_OK) return rc;
+  if (p.ksplit > 1) return launch_splitk_second_pass(p, stream);
+  return UDET_OK;
+}
+
+}  // namespace udet
