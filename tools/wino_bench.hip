@@ -231,7 +231,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 // phase 3 of stage k and phase 0 of stage k + 1, and has until the next barrier to land.
 // ABL (ablation bits): 1 no DMA after the prologue, 2 no MFMA, 4 no input transform, 8 no LDS fragment reads in the loop
 // ---------------------------------------------------------------------------------------------------------------------------
-template <int WTY, int WTX, int WN, int ABL>
+// SCHED: 0 = the compiler interleaves VALU / MFMA freely inside a phase; 2 = runs of 4 MFMAs (one channel component), the 8 VALU of the
+// next component between the runs; 3 = all 32 VALU of the phase first, then 16 MFMAs back to back
+template <int WTY, int WTX, int WN, int ABL, int SCHED = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino2_kernel(const WinoParams p) {
   static_assert(WTY * WTX * WN == 4, "4 waves");
   constexpr int NS = 3;
@@ -385,9 +387,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       __builtin_amdgcn_sched_barrier(0);
       // ---- phase i: position row i ----
       constexpr int RA[4] = {0, 1, 2, 1}, RB[4] = {2, 2, 1, 3};  // t_i = d[RA] (+/-) d[RB]: d0-d2, d1+d2, d2-d1, d1-d3
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float t[4], v[4];
+      auto vcalc = [&](int j, float (&v)[4]) {
+        float t[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           const float a = comp(row[RA[i]][c], j), b = comp(row[RB[i]][c], j);
@@ -401,14 +402,268 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
           v[2] = t[2] - t[1];
           v[3] = t[1] - t[3];
         }
+      };
+      auto mrun = [&](int j, const float (&v)[4]) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           if (ABL & 2) acc[4 * i + q][j] += v[q] * comp(bfr[i & 1][q], j);
           else acc[4 * i + q] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[q], comp(bfr[i & 1][q], j), acc[4 * i + q], 0, 0, 0);
         }
+      };
+      if (SCHED == 3) {
+        float vv[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vcalc(j, vv[j]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mrun(j, vv[j]);
+      } else if (SCHED == 4) {  // as 3, but the four components of ONE accumulator back to back (dependent chain: result forwarding)
+        float vv[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vcalc(j, vv[j]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            acc[4 * i + q] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[j][q], comp(bfr[i & 1][q], j), acc[4 * i + q], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+      } else if (SCHED == 2) {
+        float vv[4][4];
+        vcalc(0, vv[0]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          mrun(j, vv[j]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (j < 3) vcalc(j + 1, vv[j + 1]);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          float v[4];
+          vcalc(j, v);
+          mrun(j, v);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       if (i == 2) {  // stage kg + 1 is in LDS for everybody; stage kg - 1's buffer is free
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+    }
+    buf = b1;
+  }
+
+  const int co = nb * BN + wn * 32 + li;
+  const float bias = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+    const int oy = Y0 + 2 * (wty * 4 + (m >> 3)), ox = X0 + 2 * (wtx * 8 + (m & 7));
+    float s[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      s[i][0] = acc[i * 4 + 0][r] + acc[i * 4 + 1][r] + acc[i * 4 + 2][r];
+      s[i][1] = acc[i * 4 + 1][r] - acc[i * 4 + 2][r] - acc[i * 4 + 3][r];
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const float y0 = s[0][b] + s[1][b] + s[2][b];
+      const float y1 = s[1][b] - s[2][b] - s[3][b];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int yy = oy + a, xx = ox + b;
+        if (yy < Hs && xx < Ws && co < p.Cout) {
+          float v = (a ? y1 : y0) + bias;
+          v = v > 0.f ? v : v * p.alpha;
+          p.y[((size_t)(n * p.H + sy + d * yy) * p.W + sx + d * xx) * p.ldy + p.y_coff + co] = v;
+        }
+      }
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// v3: v2's pipeline with every non-MFMA instruction placed by hand.  One wave per SIMD issues in order: a ds_read_b128 or an
+// LDS-DMA instruction holds the issue port for tens of cycles, so a clump of them (v2: 8-12 reads and 5-6 DMAs at the head of a
+// phase) drains the matrix pipe.  Here a phase is 16 slots = [<= 1 LDS read of the next phase] [<= 1 DMA] [1-5 VALU of the input
+// transform] [1 MFMA], fenced by sched_barrier so hipcc keeps the order.  Input DMAs use the saddr form with a per-lane byte offset
+// and an EXEC mask of the lanes inside the image (the halo / pad slots of all three buffers are zeroed once): no VALU per DMA.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int WTY, int WTX, int WN, int ABL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void wino3_kernel(const WinoParams p) {
+  static_assert(WTY * WTX * WN == 4, "4 waves");
+  constexpr int NS = 3;
+  constexpr int TH = 4 * WTY, TW = 8 * WTX;
+  constexpr int PH = 2 * TH + 2, PW = 2 * TW + 2;
+  constexpr int CS = PW / 2;
+  constexpr int S = row_slots(PW);
+  constexpr int HP = S / 2;
+  constexpr int IN_SLOTS = 2 * PH * S;
+  constexpr int IN_INSTR = (IN_SLOTS + 255) / 256;
+  constexpr int IN_BYTES = IN_INSTR * 256 * 16;
+  constexpr int BN = 32 * WN;
+  constexpr int W_BYTES = 16 * 2 * BN * 16;
+  constexpr int W_INSTR = W_BYTES / 4096;
+  constexpr int STAGE = IN_BYTES + W_BYTES;
+  constexpr int L = IN_INSTR + W_INSTR;
+  static_assert(L <= 12, "DMA slots: 4 in phase 3, 4 in phase 0, 4 in phase 1");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int wn = wave % WN, wt = wave / WN, wty = wt / WTX, wtx = wt % WTX;
+
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int d = p.dil;
+  const int bx = bid % p.BX;
+  int rem = bid / p.BX;
+  const int by = rem % p.BY;
+  rem /= p.BY;
+  const int sx = rem % d;
+  rem /= d;
+  const int sy = rem % d;
+  const int n = rem / d;
+  const int Hs = (p.H - sy + d - 1) / d, Ws = (p.W - sx + d - 1) / d;
+  const int Y0 = by * 2 * TH, X0 = bx * 2 * TW;
+  const int nb = blockIdx.y;
+
+  unsigned in_voff[IN_INSTR];            // byte offset of this lane's 16 bytes from p.x + channel offset
+  unsigned long long in_mask[IN_INSTR];  // lanes inside the image
+#pragma unroll
+  for (int i = 0; i < IN_INSTR; ++i) {
+    const int Lx = (i * 4 + wave) * 64 + lane;
+    const int quad = Lx / (PH * S), r2 = Lx - quad * (PH * S);
+    const int row = r2 / S, s = r2 - row * S;
+    const int par = s / HP, cs = s - par * HP;
+    const int col = 2 * cs + par;
+    const int yy = Y0 - 1 + row, xx = X0 - 1 + col;
+    const bool ok = quad < 2 && cs < CS && yy >= 0 && yy < Hs && xx >= 0 && xx < Ws;
+    in_voff[i] = ok ? (unsigned)(((n * p.H + sy + d * yy) * p.W + sx + d * xx) * p.ldx + p.x_coff + quad * 4) * 4u : 0u;
+    in_mask[i] = __ballot(ok);
+    if (!ok) {  // never written by the DMA: zero once, in every ring buffer
+#pragma unroll
+      for (int b = 0; b < NS; ++b) *reinterpret_cast<float4*>(smem + b * STAGE + Lx * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  __syncthreads();
+  const float* ubase0 = p.u + (size_t)nb * (W_BYTES / 4);
+  const size_t ustride = (size_t)gridDim.y * (W_BYTES / 4);
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned lane16 = lane * 16;
+  // one DMA instruction `i` of stage kg into buffer buf
+  auto dma = [&](int kg, int buf, int i) {
+    const unsigned sb = lds0 + buf * STAGE;
+    if (i < IN_INSTR) {
+      const float* base = p.x + kg * 8;
+      asm volatile("s_mov_b32 m0, %2\n\ts_mov_b64 exec, %3\n\tglobal_load_lds_dwordx4 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(in_voff[i]), "s"(base),
+                   "s"(sb + (i * 4 + wave) * 1024), "s"(in_mask[i])
+                   : "m0");
+    } else {
+      const int w = i - IN_INSTR;
+      const float* us = ubase0 + (size_t)kg * ustride + (w * 4 + wave) * 256;
+      asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane16), "s"(us), "s"(sb + IN_BYTES + (w * 4 + wave) * 1024) : "m0");
+    }
+  };
+
+  floatx16 acc[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+  const int ty = li >> 3, tx = li & 7;
+  const int a_base = ((lh * PH + 2 * (wty * 4 + ty)) * S + (wtx * 8 + tx)) * 16;
+  const int b_base = IN_BYTES + (lh * BN + wn * 32 + li) * 16;
+
+  float4 row[4][4];
+  float4 bfr[2][4];
+  auto ld_row1 = [&](const char* sb, int r, int c) {
+    if (!(ABL & 8)) row[r][c] = *reinterpret_cast<const float4*>(sb + a_base + (r * S + (c & 1) * HP + (c >> 1)) * 16);
+  };
+  auto ld_bf1 = [&](const char* sb, int i, int s, int q) {
+    if (!(ABL & 8)) bfr[s][q] = *reinterpret_cast<const float4*>(sb + b_base + (4 * i + q) * (2 * BN * 16));
+  };
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) row[r][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bfr[s][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto comp = [](const float4& v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); };
+
+  const int nkg = p.nkg;
+#pragma unroll
+  for (int i = 0; i < L; ++i) dma(0, 0, i);
+  if (nkg > 1) {
+#pragma unroll
+    for (int i = 0; i < L; ++i) dma(1, 1, i);
+  }
+  if (nkg > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int c = 0; c < 4; ++c) { ld_row1(smem, 0, c); ld_row1(smem, 2, c); ld_bf1(smem, 0, 0, c); }
+
+  int buf = 0;
+  for (int kg = 0; kg < nkg; ++kg) {
+    const char* sb = smem + buf * STAGE;
+    const int b1 = buf + 1 == NS ? 0 : buf + 1, b2 = b1 + 1 == NS ? 0 : b1 + 1;
+    const char* sbn = smem + b1 * STAGE;
+    const bool dma_bc = !(ABL & 1) && kg > 0 && kg + 1 < nkg;  // parts B / C of stage kg + 1 (part A went out in the previous phase 3)
+    const bool dma_a = !(ABL & 1) && kg + 2 < nkg;             // part A of stage kg + 2
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      constexpr int RA[4] = {0, 1, 2, 1}, RB[4] = {2, 2, 1, 3};
+      float t[4];
+#pragma unroll
+      for (int sl = 0; sl < 16; ++sl) {
+        const int j = sl >> 2, q = sl & 3;
+        // (1) one LDS read of the next phase
+        if (i == 0) {
+          if (sl < 4) ld_row1(sb, 1, sl);
+          else if (sl < 8) ld_bf1(sb, 1, 1, sl - 4);
+        } else if (i == 1) {
+          if (sl < 4) ld_bf1(sb, 2, 0, sl);
+        } else if (i == 2) {
+          if (sl < 4) ld_row1(sb, 3, sl);
+          else if (sl < 8) ld_bf1(sb, 3, 1, sl - 4);
+        } else {
+          if (sl < 4) ld_row1(sbn, 0, sl);
+          else if (sl < 8) ld_row1(sbn, 2, sl - 4);
+          else if (sl < 12) ld_bf1(sbn, 0, 0, sl - 8);
+        }
+        // (2) one DMA instruction: part A (0..3) in phase 3 slots 12..15, B (4..7) in phase 0 slots 8..11, C (8..11) in phase 1 slots 4..7
+        if (i == 3 && sl >= 12 && sl - 12 < L) { if (dma_a) dma(kg + 2, b2, sl - 12); }
+        if (i == 0 && sl >= 8 && sl < 12 && sl - 4 < L) { if (dma_bc) dma(kg + 1, b1, sl - 4); }
+        if (i == 1 && sl >= 4 && sl < 8 && sl + 4 < L) { if (dma_bc) dma(kg + 1, b1, sl + 4); }
+        // (3) input transform of this slot's operand
+        if (q == 0) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float a = comp(row[RA[i]][c], j), b = comp(row[RB[i]][c], j);
+            t[c] = (ABL & 4) ? a : (i == 1 ? a + b : a - b);
+          }
+        }
+        const float v = (ABL & 4) ? t[q] : (q == 0 ? t[0] - t[2] : (q == 1 ? t[1] + t[2] : (q == 2 ? t[2] - t[1] : t[1] - t[3])));
+        // (4) the multiplication
+        if (ABL & 2) acc[4 * i + q][j] += v * comp(bfr[i & 1][q], j);
+        else acc[4 * i + q] = __builtin_amdgcn_mfma_f32_32x32x2f32(v, comp(bfr[i & 1][q], j), acc[4 * i + q], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (i == 2) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -495,7 +750,7 @@ __global__ void ref_conv_kernel(const float* __restrict__ x, int ldx, const floa
 
 struct Shape { const char* name; int N, H, W, Cin, Cout, d; };
 
-template <int WTY, int WTX, int WN, int NS, int V2 = 0, int ABL = 0>
+template <int WTY, int WTX, int WN, int NS, int V2 = 0, int ABL = 0, int SCHED = 0>
 static float run(const Shape& s, const float* x, int ldx, const float* w, const float* bias, float* y, const float* zero, int reps, float* u_buf) {
   constexpr int TH = 4 * WTY, TW = 8 * WTX, BN = 32 * WN;
   WinoParams p;
@@ -513,7 +768,7 @@ static float run(const Shape& s, const float* x, int ldx, const float* w, const 
   constexpr int IN_BYTES = ((2 * PH * S + 255) / 256) * 256 * 16;
   constexpr int STAGE = IN_BYTES + 16 * 2 * BN * 16;
   const int shmem = NS * STAGE;
-  auto kern = V2 ? wino2_kernel<WTY, WTX, WN, ABL> : wino_kernel<WTY, WTX, WN, NS>;
+  auto kern = V2 == 3 ? wino3_kernel<WTY, WTX, WN, ABL> : (V2 ? wino2_kernel<WTY, WTX, WN, ABL, SCHED> : wino_kernel<WTY, WTX, WN, NS>);
   CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, shmem));
   dim3 grid(s.N * s.d * s.d * p.BY * p.BX, nnb);
   hipEvent_t e0, e1;
@@ -527,7 +782,7 @@ static float run(const Shape& s, const float* x, int ldx, const float* w, const 
   CHECK(hipEventSynchronize(e1));
   float ms = 0.f;
   CHECK(hipEventElapsedTime(&ms, e0, e1));
-  printf("    %s<%d,%d,%d,%d> abl %d grid %dx%d lds %d KB S=%d: ", V2 ? "v2" : "v1", WTY, WTX, WN, NS, ABL, grid.x, grid.y, shmem / 1024, S);
+  printf("    %s<%d,%d,%d,%d> sched %d abl %d grid %dx%d lds %d KB S=%d: ", V2 == 3 ? "v3" : (V2 ? "v2" : "v1"), WTY, WTX, WN, NS, SCHED, ABL, grid.x, grid.y, shmem / 1024, S);
   return ms * 1e3f / reps;
 }
 
@@ -573,9 +828,13 @@ int main(int argc, char** argv) {
       printf("%8.1f us  %6.1f TFLOP/s (direct-equivalent)  max|diff| %.2e / scale %.2e\n", us, gflop / us * 1e3, md, mr);
       CHECK(hipMemset(y, 0, ny * 4));
     };
-    report(run<2, 1, 2, 3>(s, x, ldx, w, b, y, zero, reps, u));
     report(run<2, 1, 2, 3, 1>(s, x, ldx, w, b, y, zero, reps, u));
-    report(run<2, 2, 1, 3, 1>(s, x, ldx, w, b, y, zero, reps, u));
+    report(run<2, 1, 2, 3, 1, 0, 3>(s, x, ldx, w, b, y, zero, reps, u));
+    report(run<2, 1, 2, 3, 3>(s, x, ldx, w, b, y, zero, reps, u));
+    report(run<2, 2, 1, 3, 3>(s, x, ldx, w, b, y, zero, reps, u));
+    report(run<2, 1, 2, 3, 3, 1>(s, x, ldx, w, b, y, zero, reps, u));
+    report(run<2, 1, 2, 3, 3, 8>(s, x, ldx, w, b, y, zero, reps, u));
+    report(run<2, 1, 2, 3, 3, 9>(s, x, ldx, w, b, y, zero, reps, u));
     if (getenv("WINO_ABL")) {
       report(run<2, 1, 2, 3, 1, 1>(s, x, ldx, w, b, y, zero, reps, u));
       report(run<2, 1, 2, 3, 1, 2>(s, x, ldx, w, b, y, zero, reps, u));

@@ -25,7 +25,6 @@ int launch_splitk_second_pass(const ConvParams& p, hipStream_t stream);  // conv
 int launch_wino_pack(const float* src, float* dst, int R, int C, int Kc, int np, int k_split, int k_gap, int transposed, hipStream_t stream);
 // U straight from PACKED weights [tap][Kc][ldw] and the launch's own tap table (single-operator launches, tests)
 int launch_wino_from_packed(const ConvParams& p, float* dst, int np, hipStream_t stream);
-__device__ float wino_pack_elem(const PackJob& j, const float* __restrict__ src, const float* __restrict__ gamma, float bn_c, long e);
 void conv_debug_f16(int on);  // fp16 multiplication in the single-operator launches (plans carry udet_config.conv_fp16)
 int conv_debug_f16_on();
 int conv_last_config();

@@ -6,6 +6,7 @@
 
 #include "common.h"
 #include "conv_host.h"
+#include "wino_pack.h"
 
 namespace udet {
 
@@ -147,6 +148,10 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
   if (j.mode == 2) {
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < j.total; e += (long)gridDim.x * 256)
       dst[e] = gamma ? src[e] * (gamma[e] * bn_c) + wsrc[j.beta_off + e] : src[e];
+    return;
+  }
+  if (j.mode == 7 || j.mode == 8) {  // Winograd U = G g G^T (conv_wino.hip)
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < j.total; e += (long)gridDim.x * 256) dst[e] = wino_pack_elem(j, src, gamma, bn_c, e);
     return;
   }
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < j.total; e += (long)gridDim.x * 256) {

@@ -1419,7 +1419,8 @@ bool tune_compare(const float* a, const float* b, size_t n, hipStream_t stream, 
 static uint64_t conv_key(const ConvParams& p) {
   const int f[] = {p.N, p.H, p.W, p.up_shift, p.Kc, p.Cout, p.ntaps, p.ncls, p.OHq, p.OWq, p.isy, p.osy, p.xa ? 1 : 0,
                    p.ldx, p.ldy, p.accumulate, p.res ? 1 : 0, p.y2 ? 1 : 0, p.partial ? 1 : 0, p.cls_tap[1], p.uo ? 1 : 0, p.f16 ? 1 : 0, p.kreal,
-                   p.wino_u ? p.wino_np : 0};
+                   p.wino_u ? p.wino_np : 0, p.ntaps > 0 ? p.taps[0].dy : 0, p.ntaps > 0 ? p.taps[0].dx : 0};  // (first tap: the dilation -- it
+                                                                                         // decides what the Winograd sub-lattices look like)
   uint64_t h = 1469598103934665603ull;
   for (int v : f) { h ^= (uint64_t)(uint32_t)v; h *= 1099511628211ull; }
   return h;

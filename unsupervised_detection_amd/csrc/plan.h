@@ -51,6 +51,10 @@ struct Layer {
   // NN x2 upsample + 3x3 convolution as four 2x2 convolutions on the low-resolution grid (one per output parity class, weights of
   // taps that read the same low-resolution pixel pre-added): [16 = class*4 + tap][Kc][ldw] and its transpose for backward-data
   size_t wu_off = 0, wuT_off = 0;
+  // Winograd F(2x2,3x3) operands of the 3x3 stride-1 layers (conv_wino.hip): U = G g G^T for the forward pass and, trainable nets,
+  // for the backward-data pass (mirrored taps, K = output channels); 0: the layer is not eligible
+  size_t wino_off = 0, winoT_off = 0;
+  int wino_np = 0, winoT_np = 0;
   // tensors
   int x = -1, x_coff = 0, y = -1, y_coff = 0;
   int res = -1, res_coff = 0, y2 = -1;

@@ -470,6 +470,17 @@ Plan* plan_build(const Config& cfg) {
       L.wu_off = off; off = align64(off + (size_t)16 * L.Kc * L.ldw);
       L.wuT_off = off; off = align64(off + (size_t)16 * L.KcT * L.ldwT);
     }
+    // Winograd operands: 3x3 stride-1 layers whose K extent is whole 8-channel stages (the tuner decides per shape whether the family runs)
+    if (L.kh == 3 && L.kw == 3 && L.stride == 1 && !L.up && !L.transposed && !L.col2im && L.cout >= 16 && L.H * L.W >= 512) {
+      if (L.Kc % 8 == 0) {
+        L.wino_np = conv_wino_np(L.cout);
+        L.wino_off = off; off = align64(off + conv_wino_floats(L.Kc, L.cout));
+      }
+      if (trainable && L.KcT % 8 == 0 && L.cin >= 16) {
+        L.winoT_np = conv_wino_np(L.cin);
+        L.winoT_off = off; off = align64(off + conv_wino_floats(L.KcT, L.cin));
+      }
+    }
   };
   for (auto& L : P->pwc) place(L, false);
   for (auto& L : P->gen) place(L, true);
@@ -494,10 +505,10 @@ Plan* plan_build(const Config& cfg) {
     P->seg_off[net] = off;
     off = align64(off + 4 * net_params(net).p.size() + 64);  // two long tables (offset, len) = 4 floats per entry
   }
-  for (int net = 1; net <= 2; ++net) {  // PackJob tables: <= 4 jobs per layer
+  for (int net = 1; net <= 2; ++net) {  // PackJob tables: <= 8 jobs per layer
     const size_t nl = net == NET_GEN ? P->gen.size() : P->rec.size();
     P->jobs_off[net] = off;
-    off = align64(off + 4 * nl * (sizeof(PackJob) / sizeof(float)) + 64);
+    off = align64(off + 8 * nl * (sizeof(PackJob) / sizeof(float)) + 64);
   }
   P->arena_floats = off;
   // UDET_SERIAL=1 (read once, here; documented in include/udet.h next to udet_plan_set_concurrent): every lane collapses onto

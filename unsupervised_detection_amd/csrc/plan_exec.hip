@@ -238,6 +238,7 @@ static int run_fwd(Plan* P, const Layer& L, int N, float* ws, const Lane& ln, si
     p.act = L.act; p.alpha = L.alpha;
     if (L.res >= 0) { p.res = ws + P->buf(L.res).off; p.ldres = P->buf(L.res).ld; p.res_coff = L.res_coff; }
     if (L.y2 >= 0) { p.y2 = ws + P->buf(L.y2).off; p.ldy2 = P->buf(L.y2).ld; p.y2_coff = 0; }
+    if (L.wino_off) { p.wino_u = ws + L.wino_off; p.wino_np = L.wino_np; }
     fill_common(P, p, ws, ln.slot);
     UDET_TRY(launch_conv(p, s));
   }
@@ -283,6 +284,7 @@ static int run_dgrad(Plan* P, const Layer& L, int N, int dy, bool dy_is_du, int 
       p.ua = ws + bua.off; p.ldua = bua.ld; p.ua_coff = dx_coff;
       p.uact = em.act; p.ualpha = em.alpha; p.u_c0 = em.c0; p.u_c1 = em.c1;
     }
+    if (L.winoT_off && !upeff) { p.wino_u = ws + L.winoT_off; p.wino_np = L.winoT_np; }
     fill_common(P, p, ws, ln.slot);
     p.f16_xscale = UDET_F16_GRAD_SCALE;  // the x operand is a gradient
     UDET_TRY(launch_conv(p, s));
@@ -407,6 +409,16 @@ int plan_init_workspace(Plan* P, float* ws, hipStream_t s) {
         jobs.push_back(j);
         j.T = T;
       }
+      if (L.wino_off) {  // Winograd operand of the forward pass: K = input channels with the slab's gap map, N = output channels
+        j.dst_off = (long)L.wino_off; j.R = L.cin; j.C = L.cout; j.Kc = L.Kc; j.ldw = L.wino_np; j.k_split = L.k_split; j.k_gap = L.k_gap;
+        j.mode = 7; j.total = (long)conv_wino_floats(L.Kc, L.cout);
+        jobs.push_back(j);
+      }
+      if (L.winoT_off) {  // ... of the backward-data pass: K = output channels, N = input channels, taps mirrored
+        j.dst_off = (long)L.winoT_off; j.R = L.cin; j.C = L.cout; j.Kc = L.KcT; j.ldw = L.winoT_np; j.k_split = L.KcT; j.k_gap = 0;
+        j.mode = 8; j.total = (long)conv_wino_floats(L.KcT, L.cin);
+        jobs.push_back(j);
+      }
       // bias (BN-folded for the generator)
       j.src_off = (long)np.p[L.b_idx].offset; j.dst_off = (long)L.bias_f_off; j.mode = 2; j.total = L.cout;
       jobs.push_back(j);
@@ -431,6 +443,8 @@ static int pack_layer(const Layer& L, const float* w_flat, float* ws, const floa
     UDET_TRY(launch_pack_weights(w, ws + L.wpT_off, T, L.cin, L.cout, L.KcT, L.ldwT, L.KcT, 0, 1, scale, s));
   if (L.col2im)
     UDET_TRY(launch_pack_taps_into_n(w, ws + L.wz_off, T, L.cin, L.cout, L.Kc, L.ldz, L.k_split, L.k_gap, L.transposed ? 1 : 0, s));
+  if (L.wino_off && !trainable)  // (the trainable nets build theirs in the per-step job table, BN folded)
+    UDET_TRY(launch_wino_pack(w, ws + L.wino_off, L.cin, L.cout, L.Kc, L.wino_np, L.k_split, L.k_gap, 0, s));
   return UDET_OK;
 }
 
