@@ -15,6 +15,7 @@
 #include <cstring>
 #include <cmath>
 #include <vector>
+#include <type_traits>
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -701,6 +702,274 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// v4: TWO waves per SIMD.  v2 / v3 showed what one wave per SIMD pays for: every ds_read_b128 and every DMA instruction the wave
+// issues costs the matrix pipe ~60 idle cycles (it cannot be hidden behind the wave's own MFMAs, however it is placed).  Here a
+// workgroup is 8 waves: waves 0-3 ("role 0") own position rows 1 and 2 of their 32-tile x 32-channel block, waves 4-7 ("role 1")
+// rows 0 and 3 -- 8 accumulators = 128 registers per wave, so two waves share a SIMD and one multiplies while the other reads.
+// Row i of B^T d needs patch rows {0,2} {1,2} {2,1} {1,3}: role 0 reads rows 1, 2 only (both of its phases), role 1 all four.
+// A stage is two phases of 16 MFMAs per wave; the hand-over barrier sits between them.  The output transform adds the roles'
+// partial column sums through LDS once, in the epilogue: Y0 = s0 + (s1 + s2), Y1 = (s1 - s2) - s3.
+// ---------------------------------------------------------------------------------------------------------------------------
+template <int WTY, int WTX, int WN, int ABL>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void wino4_kernel(const WinoParams p) {
+  static_assert(WTY * WTX * WN == 4, "4 wave tiles");
+  constexpr int NS = 3;
+  constexpr int TH = 4 * WTY, TW = 8 * WTX;
+  constexpr int PH = 2 * TH + 2, PW = 2 * TW + 2;
+  constexpr int CS = PW / 2;
+  constexpr int S = row_slots(PW);
+  constexpr int HP = S / 2;
+  constexpr int IN_SLOTS = 2 * PH * S;
+  constexpr int IN_INSTR = (IN_SLOTS + 255) / 256;  // input DMA instructions per role-0 wave
+  constexpr int IN_BYTES = IN_INSTR * 256 * 16;
+  constexpr int BN = 32 * WN;
+  constexpr int W_BYTES = 16 * 2 * BN * 16;
+  constexpr int NW = W_BYTES / 1024;                // weight DMA wave-instructions per stage
+  constexpr int PER = (IN_INSTR * 4 + NW + 7) / 8;  // target per wave
+  constexpr int W0 = PER > IN_INSTR ? PER - IN_INSTR : 0;  // weight instructions per role-0 wave
+  constexpr int W1 = (NW - 4 * W0) / 4;                    // ... per role-1 wave
+  static_assert(W1 >= 0 && 4 * W0 + 4 * W1 == NW, "weight split");
+  constexpr int STAGE = IN_BYTES + W_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int role = wave >> 2, sub = wave & 3;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wn = sub % WN, wt = sub / WN, wty = wt / WTX, wtx = wt % WTX;
+
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int d = p.dil;
+  const int bx = bid % p.BX;
+  int rem = bid / p.BX;
+  const int by = rem % p.BY;
+  rem /= p.BY;
+  const int sx = rem % d;
+  rem /= d;
+  const int sy = rem % d;
+  const int n = rem / d;
+  const int Hs = (p.H - sy + d - 1) / d, Ws = (p.W - sx + d - 1) / d;
+  const int Y0 = by * 2 * TH, X0 = bx * 2 * TW;
+  const int nb = blockIdx.y;
+
+  unsigned in_voff[IN_INSTR];
+  unsigned long long in_mask[IN_INSTR];
+#pragma unroll
+  for (int i = 0; i < IN_INSTR; ++i) {
+    const int Lx = (i * 4 + sub) * 64 + lane;
+    const int quad = Lx / (PH * S), r2 = Lx - quad * (PH * S);
+    const int row = r2 / S, s = r2 - row * S;
+    const int par = s / HP, cs = s - par * HP;
+    const int col = 2 * cs + par;
+    const int yy = Y0 - 1 + row, xx = X0 - 1 + col;
+    const bool ok = quad < 2 && cs < CS && yy >= 0 && yy < Hs && xx >= 0 && xx < Ws;
+    in_voff[i] = ok ? (unsigned)(((n * p.H + sy + d * yy) * p.W + sx + d * xx) * p.ldx + p.x_coff + quad * 4) * 4u : 0u;
+    in_mask[i] = __ballot(ok);
+    if (!ok && role == 0) {
+#pragma unroll
+      for (int b = 0; b < NS; ++b) *reinterpret_cast<float4*>(smem + b * STAGE + Lx * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  __syncthreads();
+  const float* ubase0 = p.u + (size_t)nb * (W_BYTES / 4);
+  const size_t ustride = (size_t)gridDim.y * (W_BYTES / 4);
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned lane16 = lane * 16;
+  auto dma_in = [&](int kg, int buf, int i) {
+    const float* base = p.x + kg * 8;
+    asm volatile("s_mov_b32 m0, %2\n\ts_mov_b64 exec, %3\n\tglobal_load_lds_dwordx4 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(in_voff[i]), "s"(base),
+                 "s"(lds0 + buf * STAGE + (i * 4 + sub) * 1024), "s"(in_mask[i])
+                 : "m0");
+  };
+  auto dma_w = [&](int kg, int buf, int w) {  // w: wave-instruction index of the weight stage
+    const float* us = ubase0 + (size_t)kg * ustride + w * 256;
+    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane16), "s"(us), "s"(lds0 + buf * STAGE + IN_BYTES + w * 1024) : "m0");
+  };
+  // this wave's DMA instructions [i0, i1) of a stage (role 0: input first, then its weights; role 1: weights)
+  auto dma_part = [&](auto ROLE, int kg, int buf, int i0, int i1) {
+    constexpr int R = decltype(ROLE)::value;
+    constexpr int LR = R == 0 ? IN_INSTR + W0 : W1;
+#pragma unroll
+    for (int i = 0; i < LR; ++i) {
+      if (i < i0 || i >= i1) continue;
+      if (R == 0) {
+        if (i < IN_INSTR) dma_in(kg, buf, i);
+        else dma_w(kg, buf, (i - IN_INSTR) * 4 + sub);
+      } else {
+        dma_w(kg, buf, 4 * W0 + i * 4 + sub);
+      }
+    }
+  };
+
+  floatx16 acc[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+  const int ty = li >> 3, tx = li & 7;
+  const int a_base = ((lh * PH + 2 * (wty * 4 + ty)) * S + (wtx * 8 + tx)) * 16;
+  const int b_base = IN_BYTES + (lh * BN + wn * 32 + li) * 16;
+  auto ld_row = [&](const char* sb, int r, float4 (&dst)[4]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (!(ABL & 8)) dst[c] = *reinterpret_cast<const float4*>(sb + a_base + (r * S + (c & 1) * HP + (c >> 1)) * 16);
+  };
+  auto ld_bf = [&](const char* sb, int i, float4 (&dst)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (!(ABL & 8)) dst[q] = *reinterpret_cast<const float4*>(sb + b_base + (4 * i + q) * (2 * BN * 16));
+  };
+  auto comp = [](const float4& v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); };
+  const int nkg = p.nkg;
+
+  auto body = [&](auto ROLE) {
+    constexpr int R = decltype(ROLE)::value;
+    constexpr int LR = R == 0 ? IN_INSTR + W0 : W1;
+    constexpr int LA = (LR + 1) / 2;
+    constexpr int I0 = R == 0 ? 1 : 0, I1 = R == 0 ? 2 : 3;  // position rows of phase 0 / phase 1
+    float4 ra[4], rb[4];   // role 0: patch rows 1, 2; role 1: rows 0, 2 (phase 0)
+    float4 rc[4], rd[4];   // role 1: rows 1, 3 (phase 1)
+    float4 bf0[4], bf1[4];
+    float v1[4][4];        // role 0: phase 1's operands, formed during phase 0 from the same two rows
+    float zc = 0.5f;
+    asm volatile("" : "+v"(zc));
+#pragma unroll
+    for (int c = 0; c < 4; ++c) ra[c] = rb[c] = rc[c] = rd[c] = bf0[c] = bf1[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    dma_part(ROLE, 0, 0, 0, LR);
+    if (nkg > 1) dma_part(ROLE, 1, 1, 0, LR);
+    if (nkg > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LR) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    ld_row(smem, R == 0 ? 1 : 0, ra);
+    ld_row(smem, 2, rb);
+    ld_bf(smem, I0, bf0);
+    int buf = 0;
+    for (int kg = 0; kg < nkg; ++kg) {
+      const char* sb = smem + buf * STAGE;
+      const int b1 = buf + 1 == NS ? 0 : buf + 1, b2 = b1 + 1 == NS ? 0 : b1 + 1;
+      const char* sbn = smem + b1 * STAGE;
+      // ---------------- phase 0 ----------------
+      if (R == 1) { ld_row(sb, 1, rc); ld_row(sb, 3, rd); }
+      ld_bf(sb, I1, bf1);
+      if (!(ABL & 1) && kg > 0 && kg + 1 < nkg) dma_part(ROLE, kg + 1, b1, LA, LR);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float t[4], v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float a = (ABL & 16) ? zc : comp(ra[c], j), b = (ABL & 16) ? zc : comp(rb[c], j);
+          t[c] = R == 0 ? a + b : a - b;  // row 1: d1 + d2; row 0: d0 - d2
+        }
+        v[0] = t[0] - t[2]; v[1] = t[1] + t[2]; v[2] = t[2] - t[1]; v[3] = t[1] - t[3];
+        if (R == 0) {  // row 2: d2 - d1, kept for phase 1
+          float u[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) u[c] = (ABL & 16) ? zc : comp(rb[c], j) - comp(ra[c], j);
+          v1[j][0] = u[0] - u[2]; v1[j][1] = u[1] + u[2]; v1[j][2] = u[2] - u[1]; v1[j][3] = u[1] - u[3];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (ABL & 2) acc[q][j] += v[q] * comp(bf0[q], j);
+          else acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[q], (ABL & 16) ? zc : comp(bf0[q], j), acc[q], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (ABL & 16) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) asm volatile("" ::"v"(ra[c].x), "v"(rb[c].x), "v"(bf0[c].x), "v"(ra[c].w), "v"(rb[c].w), "v"(bf0[c].w));
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // stage kg + 1 is in LDS for every wave; the buffer of stage kg - 1 is free
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      // ---------------- phase 1 ----------------
+      ld_row(sbn, R == 0 ? 1 : 0, ra);
+      ld_row(sbn, 2, rb);
+      ld_bf(sbn, I0, bf0);
+      if (!(ABL & 1) && kg + 2 < nkg) dma_part(ROLE, kg + 2, b2, 0, LA);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v[4];
+        if (R == 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = v1[j][q];
+        } else {
+          float t[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) t[c] = (ABL & 16) ? zc : comp(rc[c], j) - comp(rd[c], j);  // row 3: d1 - d3
+          v[0] = t[0] - t[2]; v[1] = t[1] + t[2]; v[2] = t[2] - t[1]; v[3] = t[1] - t[3];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (ABL & 2) acc[4 + q][j] += v[q] * comp(bf1[q], j);
+          else acc[4 + q] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[q], (ABL & 16) ? zc : comp(bf1[q], j), acc[4 + q], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (ABL & 16) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) asm volatile("" ::"v"(rc[c].x), "v"(rd[c].x), "v"(bf1[c].x), "v"(rc[c].w), "v"(rd[c].w), "v"(bf1[c].w));
+      }
+      buf = b1;
+    }
+  };
+  if (role == 0) body(std::integral_constant<int, 0>());
+  else body(std::integral_constant<int, 1>());
+
+  // ---- output transform: column sums of the own rows, the roles' halves meet in LDS ----
+  __syncthreads();
+  float* exch = reinterpret_cast<float*>(smem) + sub * (16 * 4 * 64);  // [r][4][lane]
+  float s[2][2][16];  // [own row 0/1][b][r]
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      s[h][0][r] = acc[h * 4 + 0][r] + acc[h * 4 + 1][r] + acc[h * 4 + 2][r];
+      s[h][1][r] = acc[h * 4 + 1][r] - acc[h * 4 + 2][r] - acc[h * 4 + 3][r];
+    }
+  if (role == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      exch[(r * 4 + 0) * 64 + lane] = s[0][0][r];  // s0[b]
+      exch[(r * 4 + 1) * 64 + lane] = s[0][1][r];
+      exch[(r * 4 + 2) * 64 + lane] = s[1][0][r];  // s3[b]
+      exch[(r * 4 + 3) * 64 + lane] = s[1][1][r];
+    }
+  }
+  __syncthreads();
+  if (role == 1) return;
+  const int co = nb * BN + wn * 32 + li;
+  const float bias = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+    const int oy = Y0 + 2 * (wty * 4 + (m >> 3)), ox = X0 + 2 * (wtx * 8 + (m & 7));
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const float s0 = exch[(r * 4 + b) * 64 + lane], s3 = exch[(r * 4 + 2 + b) * 64 + lane];
+      const float y0 = s0 + (s[0][b][r] + s[1][b][r]);
+      const float y1 = (s[0][b][r] - s[1][b][r]) - s3;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const int yy = oy + a, xx = ox + b;
+        if (yy < Hs && xx < Ws && co < p.Cout) {
+          float v = (a ? y1 : y0) + bias;
+          v = v > 0.f ? v : v * p.alpha;
+          p.y[((size_t)(n * p.H + sy + d * yy) * p.W + sx + d * xx) * p.ldy + p.y_coff + co] = v;
+        }
+      }
+    }
+  }
+}
+
 // U = G g G^T, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1];  layout [kg][nb][pos][half][BN][4]
 __global__ void wino_weights_kernel(const float* __restrict__ w, float* __restrict__ u, int Cin, int Cout, int nkg, int nnb, int BN) {
   const long total = (long)nkg * nnb * 16 * 2 * BN * 4;
@@ -768,21 +1037,22 @@ static float run(const Shape& s, const float* x, int ldx, const float* w, const 
   constexpr int IN_BYTES = ((2 * PH * S + 255) / 256) * 256 * 16;
   constexpr int STAGE = IN_BYTES + 16 * 2 * BN * 16;
   const int shmem = NS * STAGE;
-  auto kern = V2 == 3 ? wino3_kernel<WTY, WTX, WN, ABL> : (V2 ? wino2_kernel<WTY, WTX, WN, ABL, SCHED> : wino_kernel<WTY, WTX, WN, NS>);
+  auto kern = V2 == 4 ? wino4_kernel<WTY, WTX, WN, ABL> : V2 == 3 ? wino3_kernel<WTY, WTX, WN, ABL> : (V2 ? wino2_kernel<WTY, WTX, WN, ABL, SCHED> : wino_kernel<WTY, WTX, WN, NS>);
   CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, shmem));
   dim3 grid(s.N * s.d * s.d * p.BY * p.BX, nnb);
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));
-  for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(kern, grid, dim3(256), shmem, 0, p);
+  const dim3 block(V2 == 4 ? 512 : 256);
+  for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(kern, grid, block, shmem, 0, p);
   CHECK(hipGetLastError());
   CHECK(hipEventRecord(e0, 0));
-  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, grid, dim3(256), shmem, 0, p);
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(kern, grid, block, shmem, 0, p);
   CHECK(hipEventRecord(e1, 0));
   CHECK(hipEventSynchronize(e1));
   float ms = 0.f;
   CHECK(hipEventElapsedTime(&ms, e0, e1));
-  printf("    %s<%d,%d,%d,%d> sched %d abl %d grid %dx%d lds %d KB S=%d: ", V2 == 3 ? "v3" : (V2 ? "v2" : "v1"), WTY, WTX, WN, NS, SCHED, ABL, grid.x, grid.y, shmem / 1024, S);
+  printf("    %s<%d,%d,%d,%d> sched %d abl %d grid %dx%d lds %d KB S=%d: ", V2 == 4 ? "v4" : V2 == 3 ? "v3" : (V2 ? "v2" : "v1"), WTY, WTX, WN, NS, SCHED, ABL, grid.x, grid.y, shmem / 1024, S);
   return ms * 1e3f / reps;
 }
 
@@ -828,13 +1098,14 @@ int main(int argc, char** argv) {
       printf("%8.1f us  %6.1f TFLOP/s (direct-equivalent)  max|diff| %.2e / scale %.2e\n", us, gflop / us * 1e3, md, mr);
       CHECK(hipMemset(y, 0, ny * 4));
     };
-    report(run<2, 1, 2, 3, 1>(s, x, ldx, w, b, y, zero, reps, u));
     report(run<2, 1, 2, 3, 1, 0, 3>(s, x, ldx, w, b, y, zero, reps, u));
-    report(run<2, 1, 2, 3, 3>(s, x, ldx, w, b, y, zero, reps, u));
-    report(run<2, 2, 1, 3, 3>(s, x, ldx, w, b, y, zero, reps, u));
-    report(run<2, 1, 2, 3, 3, 1>(s, x, ldx, w, b, y, zero, reps, u));
-    report(run<2, 1, 2, 3, 3, 8>(s, x, ldx, w, b, y, zero, reps, u));
-    report(run<2, 1, 2, 3, 3, 9>(s, x, ldx, w, b, y, zero, reps, u));
+    report(run<2, 1, 2, 3, 4>(s, x, ldx, w, b, y, zero, reps, u));
+    report(run<2, 2, 1, 3, 4>(s, x, ldx, w, b, y, zero, reps, u));
+    report(run<2, 1, 2, 3, 4, 1>(s, x, ldx, w, b, y, zero, reps, u));
+    report(run<2, 1, 2, 3, 4, 8>(s, x, ldx, w, b, y, zero, reps, u));
+    report(run<2, 1, 2, 3, 4, 9>(s, x, ldx, w, b, y, zero, reps, u));
+    report(run<2, 1, 2, 3, 4, 16>(s, x, ldx, w, b, y, zero, reps, u));
+    report(run<2, 1, 2, 3, 4, 17>(s, x, ldx, w, b, y, zero, reps, u));
     if (getenv("WINO_ABL")) {
       report(run<2, 1, 2, 3, 1, 1>(s, x, ldx, w, b, y, zero, reps, u));
       report(run<2, 1, 2, 3, 1, 2>(s, x, ldx, w, b, y, zero, reps, u));

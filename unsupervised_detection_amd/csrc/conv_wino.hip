@@ -104,8 +104,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     kg1 = (int)((long)nkg_all * (blockIdx.z + 1) / p.ksplit);
   }
 
-  // ---- per-lane DMA sources (constant over the stages up to the channel offset) ----
-  int in_off[IN_INSTR];
+  // ---- per-lane DMA sources (constant over the stages up to the channel offset): byte offset from p.x + an EXEC mask of the lanes
+  // inside the image.  The slots of the other lanes (halo beyond the border, row padding) are never written: zeroed once, in
+  // every ring buffer -- no address select per DMA, the stage's channel offset rides in the scalar base
+  unsigned in_voff[IN_INSTR];
+  unsigned long long in_mask[IN_INSTR];
 #pragma unroll
   for (int i = 0; i < IN_INSTR; ++i) {
     const int Lx = (i * 4 + wave) * 64 + lane;
@@ -115,9 +118,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int col = 2 * cs + par;
     const int yy = Y0 - 1 + row, xx = X0 - 1 + col;
     const bool ok = quad < 2 && cs < CS && yy >= 0 && yy < Hs && xx >= 0 && xx < Ws;
-    in_off[i] = ok ? ((n * p.H + sy + d * yy) * p.W + sx + d * xx) * p.ldx + p.x_coff + quad * 4 : -1;
+    in_voff[i] = ok ? (unsigned)(((n * p.H + sy + d * yy) * p.W + sx + d * xx) * p.ldx + p.x_coff + quad * 4) * 4u : 0u;
+    in_mask[i] = __ballot(ok);
+    if (!ok) {
+#pragma unroll
+      for (int b = 0; b < NS; ++b) *reinterpret_cast<float4*>(smem + b * STAGE + Lx * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
-  const float* zero = p.zero16;
+  __syncthreads();
   // weights: (position, lane half) pair `pr` is a run of BN * 16 bytes at U + ((kg * 32 + pr) * np + nb * BN) * 4 floats
   const int np = p.wino_np;
   const float* ubase = p.wino_u + (size_t)nb * BN * 4;
@@ -137,8 +145,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int i = 0; i < L; ++i) {
       if (i < i0 || i >= i1) continue;
       if (i < IN_INSTR) {
-        const float* src = in_off[i] >= 0 ? p.x + (in_off[i] + c0) : zero;
-        asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(sb + (i * 4 + wave) * 1024) : "m0");
+        asm volatile("s_mov_b32 m0, %2\n\ts_mov_b64 exec, %3\n\tglobal_load_lds_dwordx4 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(in_voff[i]), "s"(p.x + c0),
+                     "s"(sb + (i * 4 + wave) * 1024), "s"(in_mask[i])
+                     : "m0");
       } else {
         const int w = (i - IN_INSTR) * 4 + wave;  // wave-instruction index of the weight stage (1 KB each)
         const float* src;
@@ -211,22 +220,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
       __builtin_amdgcn_sched_barrier(0);
       // ---- phase i: position row i.  t = B^T d row i: d0 - d2, d1 + d2, d2 - d1, d1 - d3 ----
       constexpr int RA[4] = {0, 1, 2, 1}, RB[4] = {2, 2, 1, 3};
+      // (the phase's 32 transform additions first, then its 16 MFMAs back to back: measured 7 % faster than letting hipcc interleave
+      // them -- tools/wino_bench.hip, profiles/r04_wino_proto_sched.txt)
+      float vv[4][4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float t[4], v[4];
+        float t[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           const float a = comp(row[RA[i]][c], j), b = comp(row[RB[i]][c], j);
           t[c] = i == 1 ? a + b : a - b;
         }
-        v[0] = t[0] - t[2];
-        v[1] = t[1] + t[2];
-        v[2] = t[2] - t[1];
-        v[3] = t[1] - t[3];
+        vv[j][0] = t[0] - t[2];
+        vv[j][1] = t[1] + t[2];
+        vv[j][2] = t[2] - t[1];
+        vv[j][3] = t[1] - t[3];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          acc[4 * i + q] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[q], comp(bfr[i & 1][q], j), acc[4 * i + q], 0, 0, 0);
-      }
+          acc[4 * i + q] = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[j][q], comp(bfr[i & 1][q], j), acc[4 * i + q], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);
       if (i == 2) {  // stage k + 1 is in LDS for every wave; the buffer of stage k - 1 is free
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
