@@ -2,7 +2,8 @@
 """Benchmark of the adversarial_learner hot path on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+  (N>1: one process per GPU -- either under a launcher, python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+   127.0.0.1 ... bench.py --gpus N ..., or plainly as above: without WORLD_SIZE in the environment the script starts that launcher itself)
 
 One step = PWC-Net flow + mask-generator fwd + 3x recover fwd + generator-loss backward + recover-loss backward +
 both clipped-Adam updates on 4 DAVIS-480p-shaped synthetic frame pairs per GPU (BASELINE.json configs[1]/[2]).
@@ -166,9 +167,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d --master-addr 127.0.0.1 "
-                             "--master-port 29500 bench.py --gpus %d ..." % (args.gpus, args.gpus))
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, the command the module
+            # docstring shows) and hand their output / exit code through -- rank 0 of the children prints the one JSON line
+            import socket
+            import subprocess
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                port = so.getsockname()[1]
+            env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+                   "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+            return subprocess.run(cmd, env=env).returncode
         raise SystemExit(f"--gpus {args.gpus} != WORLD_SIZE {world}")
     # UDET_BENCH_ONE_GPU=1 (testing aid for a 1-GPU box): every rank uses cuda:0 and the collectives run over gloo, which
     # exercises the multi-process control flow of this script; the numbers of such a run mean nothing.
@@ -189,7 +199,7 @@ def main():
     from unsupervised_detection_amd import weights as W
     from unsupervised_detection_amd._ffi import lib
     from unsupervised_detection_amd.engine import BOTH, Engine, EngineConfig
-    from unsupervised_detection_amd.trainer import TrainState, allreduce_mean_, train_step
+    from unsupervised_detection_amd.trainer import TrainState, exchange_alone, train_step
 
     extra_streams = [torch.cuda.Stream() for _ in range(args.extra_streams)]
     for s_ in extra_streams:
@@ -281,13 +291,14 @@ def main():
     losses = eng.losses()
     stage("timed region done")
 
-    # the gradient exchange alone (the only collective of the step), timed after the headline region
+    # the gradient exchange alone, timed after the headline region: the SAME two collectives a BOTH step issues (recover gradients on
+    # the communication stream, generator gradients on the compute stream, the compute stream then waits) with nothing to hide behind
     allreduce_ms = None
     if world > 1:
         barrier()
         t0 = time.perf_counter()
         for _ in range(10):
-            allreduce_mean_(st.g_all)
+            exchange_alone(st)
         barrier()
         ar = torch.tensor([(time.perf_counter() - t0) / 10 * 1e3], device="cuda", dtype=torch.float64)
         dist.all_reduce(ar, op=dist.ReduceOp.MAX)
@@ -308,7 +319,8 @@ def main():
         exchange = {"ms_per_step_without_exchange": round(ms_noex, 3), "exchange_exposed_ms": round(exposed, 4),
                     "overlap_hidden_ms": round(max(0.0, allreduce_ms - exposed), 4),
                     "how": "recover gradients reduced on a communication stream behind udet_stream_wait_grads (under the rest of the "
-                           "generator-loss pass), generator gradients after the backward; hidden = allreduce_ms - exposed"}
+                           "generator-loss pass), generator gradients after the backward; allreduce_ms = those two collectives alone "
+                           "(same streams, nothing to overlap with); hidden = allreduce_ms - exposed"}
 
     # the reference's own schedule (adversarial_learner.py:383-398 with iter_gen=3 / iter_rec=1): a 4-step cycle
     # = 16 pairs, 4 forwards, 1 recover-loss backward, 3 generator-loss backwards.  Reported beside the headline number.

@@ -306,7 +306,7 @@ int udet_plan_set_concurrent(udet_plan* plan, int on);
 /* Lane placement.  ROCm maps every stream of a process onto one of GPU_MAX_HW_QUEUES (default 4) hardware queues when the stream is
  * created, and two streams on one queue execute in submission order -- which lanes of a plan share a queue changes the step time by up
  * to 20 % and depends on every other stream the process (PyTorch's pool, RCCL) created before.  A plan therefore owns candidate
- * streams (eight; up to 32 are drawn while fewer than three independent queues have been found) and, the first time it is driven from a given caller stream, probes (a 40 us spin kernel on one stream, an empty kernel on
+ * streams (eight; up to 32 are drawn while fewer than three independent queues have been found) and, the first time it is driven from a given caller stream, probes (a 200 us spin kernel on one stream, an empty kernel on
  * the other) which candidates run concurrently with the caller's stream and with each other, then lays its six lanes out on
  * four independent queues: {0 = the caller's stream, 2} {1} {3} {4, 5}; with fewer independent queues lanes are merged.  That first
  * call synchronises the device once (~3 ms).  udet_plan_lane_queues places the lanes for `stream` if that has not happened yet and
@@ -314,6 +314,13 @@ int udet_plan_set_concurrent(udet_plan* plan, int on);
  * queues in use (4 on a default runtime), < 0 on error.  Do not raise GPU_MAX_HW_QUEUES: above four queues a cross-stream dependency
  * costs 79 us instead of 12 (profiles/r03_hop_bench.txt). */
 int udet_plan_lane_queues(udet_plan* plan, void* stream, int* queue);
+/* The same layout without the timing probe, for a host that knows its streams: side_streams[0..n-1] (n = 0..3, created by the host
+ * and kept alive as long as the plan is driven from `stream`) are taken to sit on n distinct hardware queues, none of them `stream`'s;
+ * lanes {1} {3} {4, 5} go to them in that order (fewer streams: merged exactly as a probe that finds fewer queues would).  Replaces
+ * any placement the plan holds for `stream`.  A probe is a ~200 us spin kernel against an empty kernel, repeated up to three times
+ * when it sees no overlap (a positive result is proof, a negative one may be a slow host or a GPU shared with another process);
+ * a deployment that cannot tolerate that heuristic pins. */
+int udet_plan_pin_lanes(udet_plan* plan, void* stream, void* const* side_streams, int n);
 
 #ifdef __cplusplus
 }

@@ -34,3 +34,20 @@ def test_two_ranks_complete_and_report_once():
     assert ex is not None and ex["ms_per_step_without_exchange"] > 0 and ex["overlap_hidden_ms"] >= 0
     assert out["ms_per_step_median"] > 0 and out["ms_per_step_p95"] >= out["ms_per_step_median"] and out["resident_batches"] >= 4
     assert out["roofline"]["frac_step"] > 0
+
+
+def test_gpus_flag_without_a_launcher_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (how a driver calls the N = 1 form) re-executes itself under
+    torch.distributed.run: exactly one JSON line, from rank 0 of the children."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(UDET_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--cycles", "0", "--no-cpu-baseline",
+           "--ensemble-frames", "0"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 8 and out["allreduce_ms"] > 0

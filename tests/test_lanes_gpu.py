@@ -4,7 +4,11 @@ on four independent queues whatever the process did earlier."""
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+import os
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif("GPU_MAX_HW_QUEUES" in os.environ, reason="the layout asserted here is that of ROCm's default of four hardware "
+                                 "queues; GPU_MAX_HW_QUEUES is exported")]
 
 LAYOUT = [0, 1, 0, 2, 3, 3]  # {caller's stream, lane 2} {1} {3} {4, 5}
 
@@ -77,3 +81,41 @@ print(json.dumps({"n": n, "q": q, "same": bool(torch.equal(wg, wg0) and torch.eq
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["n"] == 2 and out["q"] == [0, 1, 0, 1, 1, 1] and out["same"]
+
+
+def test_pinned_layout_needs_no_probe():
+    """udet_plan_pin_lanes: the host names the side streams; fewer than three merge lanes exactly like a probe that finds fewer queues."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    eng = small_engine()
+    side = [torch.cuda.Stream() for _ in range(3)]
+    eng.pin_lanes(side)
+    assert eng.lane_queues() == (4, LAYOUT)
+    eng.pin_lanes(side[:1])
+    assert eng.lane_queues() == (2, [0, 1, 0, 1, 1, 1])
+    eng.pin_lanes([])
+    assert eng.lane_queues() == (1, [0] * 6)
+    with pytest.raises(Exception):
+        eng.pin_lanes([side[0], side[0]])
+
+
+def test_probe_finds_four_queues_while_another_process_keeps_the_gpu_busy():
+    """A second process saturates the GPU with long kernels while this one places its lanes: a probe that sees no overlap is repeated
+    (lanes.hip), so the layout is still the four-queue one."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import subprocess
+    import sys
+    import time
+    busy = subprocess.Popen([sys.executable, "-c", "import torch, time\na = torch.rand(4096, 4096, device='cuda')\nt = time.time()\n"
+                             "print('up', flush=True)\nwhile time.time() - t < 25:\n    b = a @ a\n    torch.cuda.synchronize()\n"],
+                            stdout=subprocess.PIPE, text=True, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    try:
+        assert busy.stdout.readline().strip() == "up"
+        time.sleep(0.5)
+        for _ in range(3):
+            eng = small_engine()
+            assert eng.lane_queues() == (4, LAYOUT)
+    finally:
+        busy.kill()
+        busy.wait()

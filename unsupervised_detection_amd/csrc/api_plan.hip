@@ -61,7 +61,12 @@ int udet_plan_lane_queues(udet_plan* h, void* stream, int* queue) {
   if (!h || !queue) { set_error("plan_lane_queues: null argument"); return UDET_ERR_ARG; }
   return plan_lane_queues(h->p, (hipStream_t)stream, queue);
 }
+int udet_plan_pin_lanes(udet_plan* h, void* stream, void* const* side_streams, int n) {
+  if (!h || (n > 0 && !side_streams)) { set_error("plan_pin_lanes: null argument"); return UDET_ERR_ARG; }
+  return plan_pin_lanes(h->p, (hipStream_t)stream, reinterpret_cast<hipStream_t const*>(side_streams), n);
+}
 long udet_fp16_overflow_count(udet_plan* h) {
+  if (!h) return 0;
   (void)plan_check_overflow(h->p, true);  // (the error text stays in udet_last_error; the count is the answer here)
   return h->p->ovf_skipped;
 }

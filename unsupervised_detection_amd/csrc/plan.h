@@ -165,6 +165,7 @@ int plan_apply(Plan* P, int net, float* w, float* g, float* m, float* v, float* 
 // fp16 mode: reports (once) an optimizer update that was dropped because its gradients were not finite; wait: synchronise first
 int plan_check_overflow(Plan* P, bool wait);
 int plan_lane_queues(Plan* P, hipStream_t s, int* queue);  // places the lanes for `s` if necessary; returns the queues in use
+int plan_pin_lanes(Plan* P, hipStream_t main, hipStream_t const* streams, int n);  // host-provided layout for `main` (no probe)
 enum { PROF_CONV_FWD = 0, PROF_CONV_DGRAD = 1, PROF_CONV_WGRAD = 2, PROF_WARP = 3, PROF_CORR = 4, PROF_NCAT = 5 };
 void prof_begin(Plan* P, int cat, double flops, double bytes, hipStream_t s, const char* name = "");
 void prof_end(Plan* P, hipStream_t s);

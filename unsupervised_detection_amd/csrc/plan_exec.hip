@@ -102,6 +102,30 @@ static const Plan::Placement& place_lanes(Plan* P, hipStream_t main) {
   P->placed = (int)P->placements.size() - 1;
   return P->placements[P->placed];
 }
+// the host pins the layout for `main`: `n` (0..3) streams it knows to sit on distinct hardware queues, distinct from main's -- no probe
+int plan_pin_lanes(Plan* P, hipStream_t main, hipStream_t const* streams, int n) {
+  if (n < 0 || n > 3) { set_error("plan_pin_lanes: 0..3 side streams"); return UDET_ERR_ARG; }
+  for (int i = 0; i < n; ++i) {
+    if (!streams[i] || streams[i] == main) { set_error("plan_pin_lanes: side streams must be non-null and differ from the caller's"); return UDET_ERR_ARG; }
+    for (int j = 0; j < i; ++j)
+      if (streams[j] == streams[i]) { set_error("plan_pin_lanes: duplicate side stream"); return UDET_ERR_ARG; }
+  }
+  Plan::Placement pl;
+  pl.main = main;
+  pl.nqueues = n + 1;
+  const int q1 = n > 0 ? 1 : 0, q3 = n > 1 ? (n > 2 ? 2 : 1) : q1, q4 = n > 2 ? 3 : (n > 1 ? 2 : q1);
+  const int queue[Plan::NLANE] = {0, q1, 0, q3, q4, q4};  // (the layout of place_lanes)
+  for (int i = 0; i < Plan::NLANE; ++i) {
+    pl.queue[i] = queue[i];
+    pl.lane[i] = queue[i] == 0 ? main : streams[queue[i] - 1];
+  }
+  for (size_t k = 0; k < P->placements.size(); ++k)
+    if (P->placements[k].main == main) { P->placements[k] = pl; P->placed = (int)k; return UDET_OK; }
+  if (P->placements.size() >= 16) { P->placements.clear(); P->placed = -1; }
+  P->placements.push_back(pl);
+  P->placed = (int)P->placements.size() - 1;
+  return UDET_OK;
+}
 static Lane lane_of(Plan* P, hipStream_t main, int i) {
   if (i == 0 || !P->concurrent || P->profiling) return Lane{main, 0};
   return Lane{place_lanes(P, main).lane[i], i};

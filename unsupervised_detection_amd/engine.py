@@ -33,6 +33,8 @@ lib.udet_plan_set_concurrent.restype = c_i
 lib.udet_plan_set_concurrent.argtypes = [c_p, c_i]
 lib.udet_plan_lane_queues.restype = c_i
 lib.udet_plan_lane_queues.argtypes = [c_p, c_p, ctypes.POINTER(c_i)]
+lib.udet_plan_pin_lanes.restype = c_i
+lib.udet_plan_pin_lanes.argtypes = [c_p, c_p, ctypes.POINTER(c_p), c_i]
 lib.udet_fp16_overflow_count.restype = ctypes.c_long
 lib.udet_fp16_overflow_count.argtypes = [c_p]
 lib.udet_get_adam_step.restype = ctypes.c_long
@@ -237,6 +239,14 @@ class Engine:
         if n < 0:
             check(n)
         return n, [int(v) for v in q]
+
+    def pin_lanes(self, side_streams):
+        """Pin the plan's lane layout for the current stream to up to three torch streams the caller knows to sit on distinct hardware
+        queues (include/udet.h: udet_plan_pin_lanes) -- no timing probe.  The streams are kept alive by this engine."""
+        side_streams = list(side_streams)
+        arr = (c_p * max(1, len(side_streams)))(*[s.cuda_stream for s in side_streams])
+        check(lib.udet_plan_pin_lanes(self._h, self._stream(), arr, len(side_streams)))
+        self._pinned_streams = getattr(self, "_pinned_streams", []) + side_streams
 
     def fp16_overflow_count(self) -> int:
         """conv_fp16 plans: optimizer updates dropped so far because their gradients were not finite (synchronises)."""

@@ -2,7 +2,7 @@
 
 One process per GPU.  Every op of the path is per-sample except the two batch means of the losses
 (models/adversarial_learner.py:167-172,184,191), so grad(global batch B*R) = mean_r grad(local batch B):
-the only exchange is one all-reduce(avg) over the flat gradient buffer(s) of the step (RCCL over xGMI when
+the only exchange is the all-reduce(avg) of the flat gradient buffer(s) the step computed (RCCL over xGMI when
 the process group backend is "nccl"; gloo in the CPU tests of the host logic), followed by the identical
 clip / escape-noise / Adam on every rank (noise from a counter-based stream keyed by (seed, step, index))."""
 from __future__ import annotations
@@ -22,9 +22,9 @@ class TrainState:
         self.w_pwc = (w_pwc if w_pwc is not None else W.init_flat(W.NET_PWC, seed)).to(dev)
         self.w_gen = (w_gen if w_gen is not None else W.init_flat(W.NET_GEN, seed)).to(dev)
         self.w_rec = (w_rec if w_rec is not None else W.init_flat(W.NET_REC, seed)).to(dev)
-        # both gradient buffers are views of ONE allocation (the recover part starts on a 256-byte boundary), so that a
-        # step that computes both gradients exchanges them in a single all-reduce: the payload (19.4 MB) is
-        # latency-dominated on xGMI, one collective costs less than two
+        # both gradient buffers are views of ONE allocation (the recover part starts on a 256-byte boundary).  A step that computes
+        # both gradients still exchanges them in TWO collectives (_exchange_gradients): the recover gradients are final long before
+        # the generator-loss pass ends, so their all-reduce runs on a communication stream under the rest of that pass
         n_gen, n_rec = self.w_gen.numel(), self.w_rec.numel()
         off_rec = (n_gen + 63) // 64 * 64
         self.g_all = torch.zeros(off_rec + n_rec, dtype=torch.float32, device=dev)
@@ -124,6 +124,26 @@ def _exchange_gradients(st: TrainState, which: int, group):
         done = comm.record_event()        #  pass is already enqueued and keeps running on the device)
     allreduce_mean_(st.g_gen, group)
     main.wait_event(done)  # the optimizer applies follow on the compute stream
+
+
+def exchange_alone(st: TrainState, group=None):
+    """The collectives of a which=BOTH step with nothing to overlap with (bench.py: `allreduce_ms`): g_rec on the communication
+    stream, g_gen on the compute stream, the compute stream then waits -- the streams and the order of _exchange_gradients; the
+    communication stream starts behind the compute stream instead of behind the recover-gradient event."""
+    import torch.distributed as dist
+    if group is False or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    e = st.engine
+    comm = getattr(st, "_comm_stream", None)
+    if comm is None:
+        comm = st._comm_stream = torch.cuda.Stream(device=e.device)
+    main = torch.cuda.current_stream(e.device)
+    comm.wait_stream(main)
+    with torch.cuda.stream(comm):
+        allreduce_mean_(st.g_rec, group)
+        done = comm.record_event()
+    allreduce_mean_(st.g_gen, group)
+    main.wait_event(done)
 
 
 def train_step(st: TrainState, img1, img2, which: int = BOTH, group=None, next_pair=None):
