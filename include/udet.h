@@ -184,9 +184,14 @@ typedef struct {
                               * reductions and the optimizer stay fp32.  Not a reference capability: parity tolerance 2e-2.
                               * Overflow guard: a gradient operand beyond 16 (65504 / 4096) becomes inf in fp16 and reaches the
                               * flat gradient buffer as inf / NaN; udet_apply counts the non-finite gradient values on the
-                              * device and DROPS the update when there are any (weights / Adam slots untouched); the next call
-                              * on the plan that finds the count returns UDET_ERR_OVERFLOW once (udet_fp16_overflow_count
-                              * synchronises and returns the number of dropped updates). */
+                              * device and DROPS the update when there are any (weights / Adam slots untouched); the next
+                              * forward / backward call on the plan that finds the count returns UDET_ERR_OVERFLOW -- once per
+                              * report, BEFORE it enqueues anything, so the caller simply re-issues the call (what
+                              * trainer.train_step does, counting the event) -- and udet_fp16_overflow_count synchronises and
+                              * returns the number of dropped updates.  No report is lost when the host never synchronises:
+                              * udet_apply consumes the report of the network's previous apply before it re-uses the slot.
+                              * The shared Adam step count advances for a dropped update too (the host cannot know at enqueue
+                              * time): one bias-correction step is skipped. */
 } udet_config;
 
 int udet_plan_create(const udet_config* cfg, udet_plan** out);

@@ -192,3 +192,36 @@ def test_fp16_overflow_is_detected_and_the_update_dropped():
         eng.forward(i1, i2, 3)
     assert eng.fp16_overflow_count() >= 1
     eng.forward(i1, i2, 3)                                       # reported once: the plan keeps working
+
+
+def test_fp16_overflow_reports_survive_a_host_that_never_synchronises():
+    """step k + 1's apply re-uses the pinned report slot of step k's.  Three overflowing steps enqueued back to back without
+    a host synchronisation must all be booked (the counter says six dropped updates: three per network), and the trainer's step re-issues
+    the call that finds a report instead of aborting."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from unsupervised_detection_amd import weights as W
+    from unsupervised_detection_amd.engine import BOTH, Engine, EngineConfig
+    from unsupervised_detection_amd.trainer import TrainState, train_step
+    eng = Engine(EngineConfig(batch_size=1, in_height=128, in_width=192, img_height=64, img_width=128, conv_fp16=True))
+    st = TrainState(eng, seed=5)
+    tab = {n: (o, int(torch.tensor(s).prod())) for n, s, o in W.param_table(W.NET_REC)}
+    for name in ("FlownetS/deconv2/weights", "FlownetS/deconv1/weights", "FlownetS/flow1/weights"):
+        o, c = tab[name]
+        st.w_rec[o:o + c] *= 3.0e3
+    eng.pack_trainable(st.w_gen, st.w_rec)
+    before = st.w_rec.clone()
+    g = torch.Generator().manual_seed(3)
+    i1 = (torch.rand(1, 128, 192, 3, generator=g) - 0.5).cuda()
+    i2 = (torch.rand(1, 128, 192, 3, generator=g) - 0.5).cuda()
+    for _ in range(3):  # no synchronisation in between: OverflowError raised by a later step's first call is absorbed by train_step
+        train_step(st, i1, i2, BOTH)
+    # (synchronises) every dropped update was booked: the generator's gradients pass through the blown-up recover net as well
+    assert eng.fp16_overflow_count() == 6
+    assert torch.equal(st.w_rec, before)
+    assert getattr(st, "overflow_skipped", 0) >= 1   # the trainer saw (and survived) at least one report
+    try:
+        eng.forward(i1, i2, 3)                       # whatever is still unreported is reported once ...
+    except OverflowError:
+        pass
+    eng.forward(i1, i2, 3)                           # ... and then the plan is quiet

@@ -136,12 +136,17 @@ struct Plan {
   hipEvent_t ovf_ev[3] = {nullptr, nullptr, nullptr};
   bool ovf_pending[3] = {false, false, false};
   long ovf_skipped = 0;          // optimizer updates dropped so far
+  int ovf_report_values = 0, ovf_report_nets = 0;  // dropped updates no call has reported yet (non-finite values, network bits)
   bool pwc_packed = false;
   int add_buf(const std::string& name, int n, int h, int w, int ld);
   const Buf& buf(int id) const { return bufs[id]; }
   int bid(const std::string& name) const;
 };
 
+// offsets (floats) inside the plan's small region; registered as named views by plan_build
+#define UDET_SMALL_NOISE 256   // noise_flag
+#define UDET_SMALL_OVF 300     // fp16_overflow: int[2 nets][2] = {non-finite values of the last apply, running total}
+#define UDET_SMALL_SUMS 1024   // loss_sums
 Plan* plan_build(const Config& cfg);
 
 // execution (all asynchronous on `s`)

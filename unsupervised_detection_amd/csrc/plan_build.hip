@@ -522,8 +522,8 @@ Plan* plan_build(const Config& cfg) {
   }
   if (P->cand.empty()) P->concurrent = false;
   // views into the small region (read by the host wrapper)
-  struct { const char* n; int a, d; size_t o; } views[4] = {{"losses", 1, 8, 0}, {"loss_coef", B, 4, 16}, {"noise_flag", 1, 2, 256},
-                                                            {"loss_sums", B, 5, 1024}};
+  struct { const char* n; int a, d; size_t o; } views[5] = {{"losses", 1, 8, 0}, {"loss_coef", B, 4, 16}, {"noise_flag", 1, 2, UDET_SMALL_NOISE},
+                                                            {"fp16_overflow", 2, 2, UDET_SMALL_OVF}, {"loss_sums", B, 5, UDET_SMALL_SUMS}};
   for (auto& v : views) {
     const int id = P->add_buf(v.n, v.a, 1, 1, v.d);
     P->bufs[id].off = P->small_off + v.o;

@@ -662,7 +662,7 @@ int plan_losses(Plan* P, float* ws, hipStream_t s) {
   float* sm = ws + P->small_off;
   const long HW = (long)c.img_h * c.img_w;
   return launch_losses(ws + P->buf(P->bid("flow")).off, ws + P->buf(P->bid("mask")).off, ws + P->buf(P->bid("pred")).off, HW,
-                       c.batch, c.cbn, c.epsilon, (float)(c.img_w * c.img_h * c.batch), sm + 8192, sm, sm + 16, sm + 1024, s);
+                       c.batch, c.cbn, c.epsilon, (float)(c.img_w * c.img_h * c.batch), sm + 8192, sm, sm + 16, sm + UDET_SMALL_SUMS, s);
 }
 
 // join the pending prefetch and move its staging buffers into "flow" / "image"
@@ -893,6 +893,7 @@ int plan_backward(Plan* P, int which, const float* w_gen, const float* w_rec, fl
 }
 
 // ------------------------------------------------------------ optimizer ----
+static int overflow_consume(Plan* P, int net, bool wait);
 int plan_apply(Plan* P, int net, float* w, float* g, float* m, float* v, float* ws, hipStream_t s) {
   if (net != NET_GEN && net != NET_REC) {
     set_error("apply: net must be 1 (generator) or 2 (recover)");
@@ -904,14 +905,15 @@ int plan_apply(Plan* P, int net, float* w, float* g, float* m, float* v, float* 
   const float* flag = nullptr;
   if (net == NET_GEN) {  // can_change=True (adversarial_learner.py:224-228)
     const long* tab = reinterpret_cast<const long*>(ws + P->seg_off[net]);
-    UDET_TRY(launch_grad_absmean(g, tab, tab + np.p.size(), (int)np.p.size(), sm + 2048, 1e-5f, sm + 256, s));
-    flag = sm + 256;
+    UDET_TRY(launch_grad_absmean(g, tab, tab + np.p.size(), (int)np.p.size(), sm + 2048, 1e-5f, sm + UDET_SMALL_NOISE, s));
+    flag = sm + UDET_SMALL_NOISE;
   }
-  const long t = ++P->adam_t;  // ONE optimizer object: beta powers advance on every apply (:216)
+  const long t = ++P->adam_t;  // ONE optimizer object: beta powers advance on every apply (:216) -- also for an update the fp16 overflow guard
+                               // drops on the device (the host cannot know at enqueue time; one missed bias-correction step)
   const double lr_t = (double)c.lr * sqrt(1.0 - pow((double)c.beta2, (double)t)) / (1.0 - pow((double)c.beta1, (double)t));
   const int* skip = nullptr;
   if (c.conv_fp16) {  // overflow guard of the static fp16 gradient scale (see Plan::ovf_host)
-    int* cnt = reinterpret_cast<int*>(sm + 300) + 2 * (net - 1);  // {this apply, running total}
+    int* cnt = reinterpret_cast<int*>(sm + UDET_SMALL_OVF) + 2 * (net - 1);  // {this apply, running total}; view "fp16_overflow"
     UDET_TRY(launch_nonfinite_count(g, (long)np.total, cnt, s));
     skip = cnt;
   }
@@ -920,6 +922,10 @@ int plan_apply(Plan* P, int net, float* w, float* g, float* m, float* v, float* 
   if (c.conv_fp16) {
     if (!P->ovf_host) UDET_HIP(hipHostMalloc(reinterpret_cast<void**>(&P->ovf_host), 4 * sizeof(int), hipHostMallocDefault));
     if (!P->ovf_ev[net]) UDET_HIP(hipEventCreateWithFlags(&P->ovf_ev[net], hipEventDisableTiming));
+    // the pinned slot and the event are about to be re-used: a report of this network's PREVIOUS apply that no call has looked at yet
+    // (a host that never synchronises enqueues step k + 1's apply before step k's has run) is consumed first -- that apply is at
+    // least one whole step old, the wait is normally over already
+    UDET_TRY(overflow_consume(P, net, true));
     UDET_HIP(hipMemcpyAsync(P->ovf_host + 2 * (net - 1), skip, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
     UDET_HIP(hipEventRecord(P->ovf_ev[net], s));
     P->ovf_pending[net] = true;
@@ -927,20 +933,26 @@ int plan_apply(Plan* P, int net, float* w, float* g, float* m, float* v, float* 
   return UDET_OK;
 }
 
+// looks at the pending report of `net` (wait: block until its apply has run; otherwise only if it has) and books a dropped update
+static int overflow_consume(Plan* P, int net, bool wait) {
+  if (!P->ovf_pending[net]) return UDET_OK;
+  if (wait) UDET_HIP(hipEventSynchronize(P->ovf_ev[net]));
+  else if (hipEventQuery(P->ovf_ev[net]) != hipSuccess) return UDET_OK;  // still in flight: looked at by a later call
+  P->ovf_pending[net] = false;
+  const int n = P->ovf_host[2 * (net - 1)];
+  if (n > 0) { P->ovf_report_values += n; P->ovf_report_nets |= net; ++P->ovf_skipped; }
+  return UDET_OK;
+}
+
 int plan_check_overflow(Plan* P, bool wait) {
   if (!P->cfg.conv_fp16) return UDET_OK;
-  int bad = 0, which = 0;
-  for (int net = 1; net <= 2; ++net) {
-    if (!P->ovf_pending[net]) continue;
-    if (wait) UDET_HIP(hipEventSynchronize(P->ovf_ev[net]));
-    else if (hipEventQuery(P->ovf_ev[net]) != hipSuccess) continue;  // still in flight: reported by a later call
-    P->ovf_pending[net] = false;
-    const int n = P->ovf_host[2 * (net - 1)];
-    if (n > 0) { bad += n; which |= net; ++P->ovf_skipped; }
-  }
-  if (!bad) return UDET_OK;
+  for (int net = 1; net <= 2; ++net) UDET_TRY(overflow_consume(P, net, wait));
+  if (!P->ovf_report_values) return UDET_OK;
+  const int bad = P->ovf_report_values, which = P->ovf_report_nets;
+  P->ovf_report_values = 0;
+  P->ovf_report_nets = 0;
   set_error("fp16 mode: %d non-finite gradient value(s) in the %s gradients -- a gradient operand times 4096 overflowed fp16 (|dU| > 16); "
-            "the optimizer update of that step was NOT applied (weights and Adam slots unchanged)", bad,
+            "the optimizer update(s) concerned were NOT applied (weights and Adam slots unchanged)", bad,
             which == 3 ? "generator and recover" : (which == 1 ? "generator" : "recover"));
   return UDET_ERR_OVERFLOW;
 }

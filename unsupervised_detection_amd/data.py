@@ -172,6 +172,8 @@ class Davis2016Reader(object):
         self.num_threads, self.device = num_threads, device
         self.rank, self.world = int(shard[0]), max(1, int(shard[1]))
         assert 0 <= self.rank < self.world, "shard = (rank, world)"
+        # the ranks' rows are disjoint only if every rank shuffles the pair table with the SAME generator: no OS entropy here
+        assert self.world == 1 or seed is not None, "a sharded reader (world > 1) needs an explicit seed, the same on every rank"
         self.order_rng = np.random.default_rng(seed)  # identical on every rank: the shuffle of the pair table
         # one rank: a single stream for everything (as before); several: per-rank draws beside the shared shuffle
         self.rng = self.order_rng if self.world == 1 else np.random.default_rng(None if seed is None else seed + 1 + self.rank)

@@ -158,6 +158,20 @@ def train_step(st: TrainState, img1, img2, which: int = BOTH, group=None, next_p
     # re-layout of whichever network the PREVIOUS steps updated (every forward reads both networks, so a recover step right
     # after a generator step must see the new generator too)
     flush_weights(st)
+
+    def call(fn, *a):
+        # conv_fp16 plans: a forward / backward call that finds an overflow report of an EARLIER optimizer update (dropped on the device,
+        # weights untouched) raises before it enqueues anything (include/udet.h, udet_config.conv_fp16).  Like a skipped step of dynamic
+        # loss scaling: count it, say so, and issue the call again -- training continues on the unchanged weights.
+        for _ in range(4):
+            try:
+                return fn(*a)
+            except OverflowError as ex:
+                st.overflow_skipped = getattr(st, "overflow_skipped", 0) + 1
+                import sys
+                print("[udet] fp16 overflow: an optimizer update was dropped (%d so far): %s" % (st.overflow_skipped, ex), file=sys.stderr)
+        return fn(*a)
+
     if getattr(st, "_prefetched", None) is not None:
         p1, p2 = st._prefetched
         if p1.data_ptr() != img1.data_ptr() or p2.data_ptr() != img2.data_ptr():
@@ -167,14 +181,14 @@ def train_step(st: TrainState, img1, img2, which: int = BOTH, group=None, next_p
         if next_pair is not None:  # fork the next pair's PWC flow here: it then overlaps this step's forward as well
             e.prefetch_flow(next_pair[0], next_pair[1])
             st._prefetched = (next_pair[0], next_pair[1])
-        e.forward_in_place(3)
+        call(e.forward_in_place, 3)
     else:
-        e.forward(img1, img2, 3)
+        call(e.forward, img1, img2, 3)
         if next_pair is not None:
             e.prefetch_flow(next_pair[0], next_pair[1])
             st._prefetched = (next_pair[0], next_pair[1])
     # one call: with BOTH the two backward passes run concurrently on the plan's side streams (udet_backward)
-    e.backward(which, st.w_gen, st.w_rec, st.g_gen, st.g_rec)
+    call(e.backward, which, st.w_gen, st.w_rec, st.g_gen, st.g_rec)
     _exchange_gradients(st, which, group)
     if which & GEN:
         e.apply(W.NET_GEN, st.w_gen, st.g_gen, st.m_gen, st.v_gen)
