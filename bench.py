@@ -154,7 +154,7 @@ def main():
                     "after the headline region; 0 skips that extra measurement")
     ap.add_argument("--ensemble-frames", type=int, default=12, help="frames of the configs[3] ensemble workload timed after the headline "
                     "region (extra field `ensemble`); 0 skips it")
-    ap.add_argument("--pmc-json", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_pmc_step.json"),
+    ap.add_argument("--pmc-json", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_pmc_step.json"),
                     help="PMC counters of whole steps collected offline with tools/pmc_step.py (separate rocprofv3 --pmc passes); fills "
                          "roofline.traffic with the convolution kernels' HBM bytes per step")
     args = ap.parse_args()
@@ -401,7 +401,7 @@ def main():
         if args.pmc_json and os.path.exists(args.pmc_json):
             with open(args.pmc_json) as f:
                 pmc = json.load(f)
-            conv = ("conv_igemm", "conv_tile", "conv_thin", "conv_wgrad", "wgrad_reduce", "conv_splitk_epilogue", "tap_gather", "bn_dot", "bn_finish")
+            conv = ("conv_igemm", "conv_wino", "conv_tile", "conv_thin", "conv_wgrad", "wgrad_reduce", "conv_splitk_epilogue", "tap_gather", "bn_dot", "bn_finish")
             fam = [k for k in pmc.get("kernel_families", []) if any(c in k["kernel"] for c in conv)]
             if "traffic_bytes_per_launch" in pmc:  # tools/pmc_report.py: one launch
                 traffic = pmc["traffic_bytes_per_launch"]
@@ -443,6 +443,12 @@ def main():
                     "frac_on_bracket_time": round(exe_flops / (conv_bracket_ms * 1e-3) / 1e12 / peak_tf, 4) if conv_bracket_ms > 0 else None,
                     "top_launch": top_launch}
         hbm = {}
+        pmc_wcv = None
+        if args.pmc_json and os.path.exists(args.pmc_json):
+            with open(args.pmc_json) as f:
+                pj = json.load(f)
+            if "warp_cost_volume_MB_per_step" in pj:  # tools/pmc_step.py (round 4 on): the fused kernel's dispatches, whatever their rank
+                pmc_wcv = pj
         p = prof["cost_volume"]
         if p["ms"] > 0:
             gbs = p["bytes"] / (p["ms"] * 1e-3) / 1e9
@@ -450,6 +456,12 @@ def main():
                                                  "pyramid level)",
                                        "alg_MB_per_step": round(p["bytes"] / 1e6, 2), "ms_per_step": round(p["ms"], 4), "launches": int(p["groups"]),
                                        "achieved_GBs": round(gbs, 1), "frac_of_8TBs": round(gbs / PEAK_HBM_GBS, 4)}
+            if pmc_wcv is not None:
+                w = hbm["warp_cost_volume"]
+                w["traffic"] = int(pmc_wcv["warp_cost_volume_MB_per_step"] * 1e6)  # PMC: FETCH_SIZE x 2 + WRITE_SIZE, bytes per step
+                w["traffic_over_algorithmic"] = round(w["traffic"] / max(p["bytes"], 1.0), 3)
+                w["traffic_per_level"] = pmc_wcv["warp_cost_volume_dispatches_of_one_step"]
+                w["traffic_source"] = os.path.relpath(args.pmc_json, os.path.dirname(os.path.abspath(__file__)))
             big = max((l for l in layers if l[0] == 4), key=lambda l: l[4], default=None)
             if big is not None and big[2] > 0:
                 hbm["warp_cost_volume"]["largest_launch"] = {"level": big[1], "alg_MB": round(big[4], 2), "ms": round(big[2], 4),

@@ -102,7 +102,18 @@ def main():
                                              "write_MB": round(e.get("WRITE_SIZE", 0.0) * 1024 / 1e6, 2), "mfma_pipe_busy_frac": mfma_busy(e),
                                              "effective_clock_GHz": clock_ghz(e)}
                                             for e in top],
-           "kernel_families": families[:30]}
+           "kernel_families": families[:30],
+           # the HBM-bound kernels of the north star are reported whatever their rank: every family of the fused warp + cost-volume
+           # kernel, and each of its dispatches of one step (one per pyramid level, level 6 first) with its own bytes and duration
+           "warp_cost_volume_families": [f for f in families if "warp_cost_volume" in f["kernel"] or f["kernel"].startswith(("warp_kernel", "cost_volume_kernel"))],
+           "warp_cost_volume_dispatches_of_one_step": [{"kernel": e["kernel"], "us": round(e["dur_us"], 1),
+                                                        "fetch_MB_x2": round(e.get("FETCH_SIZE", 0.0) * 2048 / 1e6, 3),
+                                                        "write_MB": round(e.get("WRITE_SIZE", 0.0) * 1024 / 1e6, 3),
+                                                        "hbm_MB": round(traffic(e) / 1e6, 3),
+                                                        "GBs": round(traffic(e) / (e["dur_us"] * 1e-6) / 1e9, 1) if e["dur_us"] > 0 else None}
+                                                       for e in last if "warp_cost_volume" in e["kernel"]]}
+    wcv = rep["warp_cost_volume_dispatches_of_one_step"]
+    rep["warp_cost_volume_MB_per_step"] = round(sum(d["hbm_MB"] for d in wcv), 3)
     with open(a.out, "w") as f:
         json.dump(rep, f, indent=1)
     print(json.dumps(rep, indent=1)[:6000])
