@@ -382,7 +382,8 @@ def main():
     if os.path.exists(dump):
         with open(dump) as f:
             # category, layer, kernel ms (sum of the launches' own start -> stop times), algorithmic GFLOP, MB[, bracket ms, kernels]
-            layers = [(int(r[0]), r[1], float(r[2]), float(r[3]), float(r[4])) for r in csv.reader(f)]
+            # (last column, round 4 on: GFLOP the matrix pipe really issues -- a Winograd launch multiplies 16 / 36 of its direct form)
+            layers = [(int(r[0]), r[1], float(r[2]), float(r[3]), float(r[4]), float(r[8]) if len(r) > 8 else float(r[3])) for r in csv.reader(f)]
         if not keep:
             os.remove(dump)
 
@@ -396,6 +397,8 @@ def main():
         # calls is evaluated once (identical input), not three times -- the kernel-efficiency numerator
         exe_flops = sum(l[3] for l in layers if l[0] < 3) * 1e9 or alg_flops
         achieved = exe_flops / (conv_ms * 1e-3) / 1e12
+        mfma_flops = sum(l[5] for l in layers if l[0] < 3) * 1e9 or exe_flops
+        wino = [l for l in layers if l[0] < 3 and l[5] < l[3] * 0.99]
         top = max((l for l in layers if l[0] < 3), key=lambda l: l[3], default=None)
         traffic, traffic_source = None, None
         if args.pmc_json and os.path.exists(args.pmc_json):
@@ -416,7 +419,8 @@ def main():
                           "frac": round(top_tf / (2500.0 if args.fp16_convs else PEAK_FP32_MFMA_TFLOPS), 4)}
         peak_tf = 2500.0 if args.fp16_convs else PEAK_FP32_MFMA_TFLOPS  # dense MFMA peak of the multiplication dtype (MI355X_MICROARCH.md)
         roofline = {"bound": "mfma",
-                    "kernel": "conv_igemm_dma_kernel / conv_igemm_kernel / conv_tile_kernel / conv_wgrad_kernel (v_mfma_f32_32x32x2_f32, "
+                    "kernel": "conv_igemm_dma_kernel / conv_igemm_kernel / conv_wino_kernel (fused Winograd F(2x2,3x3), 3x3 stride-1 layers) / "
+                              "conv_tile_kernel / conv_wgrad_kernel (v_mfma_f32_32x32x2_f32, "
                               "16x16x4 for <=16 output channels; conv_thin_* direct kernels for the 2-channel heads): every convolution "
                               "launch of one step, executed serially; duration = "
                               "the launch's own start -> stop HIP events (carried by its dispatch packet on the launch stream: the "
@@ -431,6 +435,14 @@ def main():
                                  "layers as four 2x2 convolutions: 16 of 36 tap products) -- `achieved_algorithmic` / `frac_algorithmic` divide "
                                  "the reference graph's 871.78 GFLOP by the same time",
                     "executed_gflop_per_step": round(exe_flops / 1e9, 2), "alg_gflop_per_step": round(alg_flops / 1e9, 2),
+                    # Winograd F(2x2,3x3) launches (conv_wino_kernel) are credited with the multiply-adds of the DIRECT convolution they
+                    # replace (the reference's algorithm: `achieved` / `frac` above); what the matrix pipe itself issues is 16 / 36 of
+                    # that for those launches -- the pipe-occupancy view of the same time:
+                    "winograd": {"launch_groups_per_step": len(wino), "ms_per_step_serial": round(sum(l[2] for l in wino), 3),
+                                 "direct_equivalent_gflop": round(sum(l[3] for l in wino), 2),
+                                 "achieved_direct_equivalent": round(sum(l[3] for l in wino) / max(sum(l[2] for l in wino), 1e-9), 2)},
+                    "mfma_issued_gflop_per_step": round(mfma_flops / 1e9, 2),
+                    "frac_mfma_issued": round(mfma_flops / (conv_ms * 1e-3) / 1e12 / peak_tf, 4),
                     "achieved_algorithmic": round(alg_flops / (conv_ms * 1e-3) / 1e12, 2),
                     "frac_algorithmic": round(alg_flops / (conv_ms * 1e-3) / 1e12 / peak_tf, 4),
                     # HBM bytes from PMC counters are collected offline (tools/pmc_step.py, separate rocprofv3 --pmc passes, summaries

@@ -211,7 +211,7 @@ int udet_profile_end(udet_plan* h, double* out, int ncat, void* stream) {
   g_launch_sink = nullptr;
   UDET_HIP(hipStreamSynchronize((hipStream_t)stream));
   for (int i = 0; i < ncat * 5; ++i) out[i] = 0.0;
-  FILE* dump = nullptr;  // UDET_PROF_DUMP=<file>: one CSV line per launch group (category,name,kernel ms,GFLOP,MB,bracket ms,kernels,each kernel's us)
+  FILE* dump = nullptr;  // UDET_PROF_DUMP=<file>: one CSV line per launch group (category,name,kernel ms,GFLOP,MB,bracket ms,kernels,each kernel's us,GFLOP the matrix pipe issues)
   if (const char* path = getenv("UDET_PROF_DUMP")) dump = fopen(path, "a");
   for (auto* r : P->prof) {
     float wall = 0.f;
@@ -229,8 +229,8 @@ int udet_profile_end(udet_plan* h, double* out, int ncat, void* stream) {
     }
     if (r->sink.n == 0) kern = wall;  // (a group whose launches did not go through the sink)
     if (dump)
-      fprintf(dump, "%d,%s,%.4f,%.4f,%.4f,%.4f,%d,%s\n", r->cat, r->name.c_str(), kern, r->flops * 1e-9, r->bytes * 1e-6, wall, r->sink.n,
-              each.c_str());
+      fprintf(dump, "%d,%s,%.4f,%.4f,%.4f,%.4f,%d,%s,%.4f\n", r->cat, r->name.c_str(), kern, r->flops * 1e-9, r->bytes * 1e-6, wall, r->sink.n,
+              each.c_str(), r->flops * r->mfma_scale * 1e-9);
     if (r->cat < ncat) {
       out[r->cat * 5 + 0] += 1.0;
       out[r->cat * 5 + 1] += kern;

@@ -121,6 +121,7 @@ struct Plan {
   // optional per-category timing with HIP events on the launch stream (bench.py roofline)
   struct ProfRec {
     int cat; double flops, bytes; hipEvent_t a, b; std::string name;
+    double mfma_scale = 1.0;  // multiplications the launch really issues / those of the direct form (Winograd F(2x2,3x3): 16 / 36)
     enum { MAXK = 16 };
     hipEvent_t kev[2 * MAXK];  // start / stop pairs of the kernels launched inside the group
     LaunchSink sink;

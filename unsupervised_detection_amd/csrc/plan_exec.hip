@@ -265,6 +265,7 @@ static int run_fwd(Plan* P, const Layer& L, int N, float* ws, const Lane& ln, si
     if (L.wino_off) { p.wino_u = ws + L.wino_off; p.wino_np = L.wino_np; }
     fill_common(P, p, ws, ln.slot);
     UDET_TRY(launch_conv(p, s));
+    if (P->profiling && (conv_last_config() & 0xff) == 9) P->prof.back()->mfma_scale = 4.0 / 9.0;
   }
   prof_end(P, s);
   return UDET_OK;
@@ -312,6 +313,7 @@ static int run_dgrad(Plan* P, const Layer& L, int N, int dy, bool dy_is_du, int 
     fill_common(P, p, ws, ln.slot);
     p.f16_xscale = UDET_F16_GRAD_SCALE;  // the x operand is a gradient
     UDET_TRY(launch_conv(p, s));
+    if (P->profiling && (conv_last_config() & 0xff) == 9) P->prof.back()->mfma_scale = 4.0 / 9.0;
   }
   prof_end(P, s);
   return UDET_OK;
