@@ -235,7 +235,8 @@ def test_conv_kernel_families(ops, force_conv, family, case):
     assert (dx - gx.float()).abs().max() < 2e-4 * max(1.0, float(gx.abs().max()))
 
 
-# Winograd F(2x2,3x3) family (conv_wino.hip; bit 25 of the forced tile, low bits = variant 0: 64 tiles x 64 channels, 1: 128 x 32):
+# Winograd F(2x2,3x3) family (conv_wino.hip; bit 25 of the forced tile, low bits = variant: bit 0 64 tiles x 64 channels / 128 x 32,
+# bit 1 the four-wave / the eight-wave kernel):
 # n, h, w, cin, cout, dilation
 WINO_CASES = [
     (1, 32, 64, 64, 64, 1),     # whole blocks
@@ -247,7 +248,7 @@ WINO_CASES = [
 ]
 
 
-@pytest.mark.parametrize("variant,ks", [(0, 1), (1, 1), (0, 3), (1, 2)])
+@pytest.mark.parametrize("variant,ks", [(0, 1), (1, 1), (0, 3), (1, 2), (2, 1), (3, 1), (2, 2), (3, 3)])
 @pytest.mark.parametrize("case", WINO_CASES)
 def test_conv_winograd_family(ops, force_conv, variant, ks, case):
     """3x3 stride-1 convolutions and their backward-data pass through the fused Winograd kernel (forward: pack mode 7 layout built

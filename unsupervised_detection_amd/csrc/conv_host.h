@@ -11,7 +11,8 @@ bool conv_thin_k_ok(const ConvParams& p);
 int launch_conv_thin_n(const ConvParams& p, hipStream_t stream);
 int launch_conv_thin_k(const ConvParams& p, hipStream_t stream);
 // Winograd F(2x2,3x3) family (conv_wino.hip): eligibility (3x3 taps of uniform dilation, stride 1, Kc % 8 == 0, p.wino_u set), the
-// launch (variant: 0 = 64 tiles x 64 channels per workgroup, 1 = 128 tiles x 32 channels; ks K slices through the split-K slabs)
+// launch (variant bit 0: 0 = 64 tiles x 64 channels per workgroup, 1 = 128 tiles x 32 channels; bit 1: the eight-wave form, two waves
+// per SIMD; ks K slices through the split-K slabs)
 // and the weight transform (mode 7 / 8 of PackJob) as a one-off launch
 bool conv_wino_geometry(const ConvParams& p, int* dil, int widx_at[9]);
 bool conv_wino_ok(const ConvParams& p);

@@ -1189,7 +1189,7 @@ void conv_force_config(int bm, int bn, int ks) {
   // bit 20: split-K through the second launch, bit 21: split-K folded into the last-arriving workgroup;
   // bit 22 / 23: LDS-DMA with a 3 / 4 stage ring; bit 24: the direct 2-channel-head kernels (conv_thin.hip) where a launch is eligible
   g_force_fold = (bm >> 20) & 1 ? 0 : ((bm >> 21) & 1 ? 1 : -1);
-  // bit 25: the Winograd F(2x2,3x3) family (conv_wino.hip) where a launch is eligible; bm & 0xffff = variant (0: 64 tiles x 64 channels, 1: 128 x 32)
+  // bit 25: the Winograd F(2x2,3x3) family (conv_wino.hip) where a launch is eligible; bm & 0xffff = variant (bit 0: 64 tiles x 64 channels / 128 x 32, bit 1: four / eight waves)
   g_force_ws = (bm >> 16) & 1 ? 0 : ((bm >> 17) & 1 ? 2 : ((bm >> 18) & 1 ? 3 : ((bm >> 19) & 1 ? 6 : ((bm >> 22) & 1 ? 4 : ((bm >> 23) & 1 ? 5 : ((bm >> 24) & 1 ? 7 : ((bm >> 25) & 1 ? 9 : -1)))))));
 }
 
@@ -1544,7 +1544,7 @@ static ConvCfg tune_cfg_impl(ConvParams& p, hipStream_t stream) {
     if (ms < (a < b ? a : b) * 0.97f) { a = b = ms; best = d; }
   }
   if (conv_wino_ok(p)) {  // Winograd F(2x2,3x3): 2.25x fewer multiplications; K slices where the tiles do not fill the chip
-    for (int v = 0; v < 2; ++v) {
+    for (int v = 0; v < 4; ++v) {  // (bit 0: tile shape, bit 1: four / eight waves)
       if (!conv_wino_variant_ok(p, v)) continue;
       const long wgs = conv_wino_workgroups(p, v);
       const int cap = conv_wino_max_ksplit(p, v);
@@ -1658,7 +1658,7 @@ int launch_conv(ConvParams& p, hipStream_t stream) {
     for (auto& t : TILES) tile = tile || (c.bm == t[0] && c.bn == t[1]);
     if (c.ws == 3) tile = (c.bm == 4 || c.bm == 8) && (c.bn == 16 || c.bn == 32);
     if (c.ws == 7 || c.ws == 8) tile = true;  // (the direct 2-channel kernels carry no tile; eligibility is re-checked below)
-    if (c.ws == 9) tile = c.bm == 0 || c.bm == 1;  // (Winograd: bm carries the variant; eligibility is re-checked below)
+    if (c.ws == 9) tile = c.bm >= 0 && c.bm <= 3;  // (Winograd: bm carries the variant; eligibility is re-checked below)
     if (!tile || c.ws < 0 || c.ws > 9) {
       c = heuristic_cfg(p);
     } else {
@@ -1713,9 +1713,9 @@ int launch_conv(ConvParams& p, hipStream_t stream) {
       }
       if (g_wino_scratch && launch_wino_from_packed(p, g_wino_scratch, np9, stream) == UDET_OK) { p.wino_u = g_wino_scratch; p.wino_np = np9; }
     }
-    const int v9 = g_force_bm & 1;
-    if (conv_wino_ok(p) && (conv_wino_variant_ok(p, v9) || conv_wino_variant_ok(p, 1 - v9))) {
-      c.ws = 9; c.bm = conv_wino_variant_ok(p, v9) ? v9 : 1 - v9; c.bn = 0; c.fold = 0; c.tail = 0;
+    const int v9 = g_force_bm & 3;
+    if (conv_wino_ok(p) && (conv_wino_variant_ok(p, v9) || conv_wino_variant_ok(p, v9 ^ 1))) {
+      c.ws = 9; c.bm = conv_wino_variant_ok(p, v9) ? v9 : (v9 ^ 1); c.bn = 0; c.fold = 0; c.tail = 0;
       if (g_force_ks < 0) c.ks = 1;
     } else if (c.ws == 9) c = heuristic_cfg(p);
   }

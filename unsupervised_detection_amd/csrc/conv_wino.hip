@@ -31,6 +31,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <type_traits>
 
 #include "common.h"
 #include "conv_epilogue.h"
@@ -306,6 +307,284 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Eight-wave form: TWO waves per SIMD.  What one wave per SIMD pays for (tools/wino_bench.hip, profiles/r04_wino_proto_*.txt): every
+// ds_read_b128 and every DMA instruction the wave issues costs the matrix pipe tens of idle cycles that its own MFMAs cannot cover,
+// however the instructions are placed.  Here waves 0-3 ("role 0") own position rows 1 and 2 of their 32-tile x 32-channel block and
+// waves 4-7 ("role 1") rows 0 and 3 -- 8 accumulators = 128 registers per wave, so two waves share a SIMD and one multiplies while the
+// other reads.  Row i of B^T d needs patch rows {0,2} {1,2} {2,1} {1,3}: role 0 reads rows 1 and 2 only (its second phase re-uses
+// the first one's registers: d2 - d1 is formed beside d1 + d2), role 1 all four.  A stage is two phases of 16 MFMAs per wave, the
+// hand-over barrier between them.  The output transform adds the roles' column sums through LDS once, in the epilogue:
+// Y0 = s0 + (s1 + s2), Y1 = (s1 - s2) - s3.  Measured against the four-wave form: dc_conv21 388 vs 404 us, conv2_3 164 vs 177,
+// conv2_4 168 vs 188, dc_conv31 184 vs 202 (prototype, same tiles).
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int WTY, int WTX, int WN>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wino8_kernel(const ConvParams p, const int dil,
+                                                                                                   const int BY, const int BX) {
+  static_assert(WTY * WTX * WN == 4, "4 wave tiles");
+  typedef WinoGeom<WTY, WTX, WN> G;
+  constexpr int NS = G::NS, TH = G::TH, TW = G::TW, PH = G::PH, S = G::S, HP = G::HP, CS = G::CS;
+  constexpr int IN_INSTR = G::IN_INSTR, IN_BYTES = G::IN_BYTES, BN = G::BN, STAGE = G::STAGE;
+  constexpr int NW = G::W_BYTES / 1024;                     // weight DMA wave-instructions per stage
+  constexpr int PER = (IN_INSTR * 4 + NW + 7) / 8;          // DMA instructions per wave aimed at
+  constexpr int W0 = PER > IN_INSTR ? PER - IN_INSTR : 0;   // weight instructions of a role-0 wave (beside its IN_INSTR input ones)
+  constexpr int W1 = (NW - 4 * W0) / 4;                     // ... of a role-1 wave
+  static_assert(W1 >= 0 && 4 * W0 + 4 * W1 == NW, "weight split");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int role = wave >> 2, sub = wave & 3;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wn = sub % WN, wt = sub / WN, wty = wt / WTX, wtx = wt % WTX;
+
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int d = dil;
+  const int bx = bid % BX;
+  int rem = bid / BX;
+  const int by = rem % BY;
+  rem /= BY;
+  const int sx = rem % d;
+  rem /= d;
+  const int sy = rem % d;
+  const int n = rem / d;
+  const int Hs = (p.H - sy + d - 1) / d, Ws = (p.W - sx + d - 1) / d;
+  const int Y0 = by * 2 * TH, X0 = bx * 2 * TW;
+  const int nb = blockIdx.y;
+  const int nkg_all = p.Kc >> 3;
+  int kg0 = 0, kg1 = nkg_all;
+  if (p.ksplit > 1) {
+    kg0 = (int)((long)nkg_all * blockIdx.z / p.ksplit);
+    kg1 = (int)((long)nkg_all * (blockIdx.z + 1) / p.ksplit);
+  }
+  const int nkg = kg1 - kg0;
+
+  // input DMA of the role-0 waves: per-lane byte offsets + EXEC masks, halo / pad slots zeroed once (see conv_wino_kernel)
+  unsigned in_voff[IN_INSTR];
+  unsigned long long in_mask[IN_INSTR];
+#pragma unroll
+  for (int i = 0; i < IN_INSTR; ++i) {
+    const int Lx = (i * 4 + sub) * 64 + lane;
+    const int quad = Lx / (PH * S), r2 = Lx - quad * (PH * S);
+    const int row = r2 / S, s = r2 - row * S;
+    const int par = s / HP, cs = s - par * HP;
+    const int col = 2 * cs + par;
+    const int yy = Y0 - 1 + row, xx = X0 - 1 + col;
+    const bool ok = quad < 2 && cs < CS && yy >= 0 && yy < Hs && xx >= 0 && xx < Ws;
+    in_voff[i] = ok ? (unsigned)(((n * p.H + sy + d * yy) * p.W + sx + d * xx) * p.ldx + p.x_coff + quad * 4) * 4u : 0u;
+    in_mask[i] = __ballot(ok);
+    if (!ok && role == 0) {
+#pragma unroll
+      for (int b = 0; b < NS; ++b) *reinterpret_cast<float4*>(smem + b * STAGE + Lx * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  __syncthreads();
+  const int np = p.wino_np;
+  const float* ubase = p.wino_u + (size_t)nb * BN * 4;
+  const size_t ustride = (size_t)32 * np * 4;  // floats per stage
+  const unsigned w_voff = BN == 32 ? (unsigned)((lane >> 5) * np + (lane & 31)) * 16 : (unsigned)lane * 16;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  auto dma_in = [&](int kg, int buf, int i) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_mov_b64 exec, %3\n\tglobal_load_lds_dwordx4 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(in_voff[i]), "s"(p.x + kg * 8),
+                 "s"(lds0 + buf * STAGE + (i * 4 + sub) * 1024), "s"(in_mask[i])
+                 : "m0");
+  };
+  auto dma_w = [&](int kg, int buf, int w) {  // w: wave-instruction index of the weight stage (1 KB each)
+    const float* us = ubase + (size_t)kg * ustride + (BN == 64 ? (size_t)w * np * 4 : (size_t)(2 * w) * np * 4);
+    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(w_voff), "s"(us), "s"(lds0 + buf * STAGE + IN_BYTES + w * 1024) : "m0");
+  };
+  // this wave's DMA instructions [i0, i1) of a stage (role 0: input first, then its weights; role 1: weights)
+  auto dma_part = [&](auto ROLE, int kg, int buf, int i0, int i1) {
+    constexpr int R = decltype(ROLE)::value;
+    constexpr int LR = R == 0 ? IN_INSTR + W0 : W1;
+#pragma unroll
+    for (int i = 0; i < LR; ++i) {
+      if (i < i0 || i >= i1) continue;
+      if (R == 0) {
+        if (i < IN_INSTR) dma_in(kg, buf, i);
+        else dma_w(kg, buf, (i - IN_INSTR) * 4 + sub);
+      } else {
+        dma_w(kg, buf, 4 * W0 + i * 4 + sub);
+      }
+    }
+  };
+
+  floatx16 acc[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+  const int ty = li >> 3, tx = li & 7;
+  const int a_base = ((lh * PH + 2 * (wty * 4 + ty)) * S + (wtx * 8 + tx)) * 16;
+  const int b_base = IN_BYTES + (lh * BN + wn * 32 + li) * 16;
+  auto ld_row = [&](const char* sb, int r, float4 (&dst)[4]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dst[c] = *reinterpret_cast<const float4*>(sb + a_base + (r * S + (c & 1) * HP + (c >> 1)) * 16);
+  };
+  auto ld_bf = [&](const char* sb, int i, float4 (&dst)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dst[q] = *reinterpret_cast<const float4*>(sb + b_base + (4 * i + q) * (2 * BN * 16));
+  };
+  auto comp = [](const float4& v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); };
+
+  auto body = [&](auto ROLE) {
+    constexpr int R = decltype(ROLE)::value;
+    constexpr int LR = R == 0 ? IN_INSTR + W0 : W1;
+    constexpr int LA = (LR + 1) / 2;
+    constexpr int I0 = R == 0 ? 1 : 0, I1 = R == 0 ? 2 : 3;  // position rows of phase 0 / phase 1
+    float4 ra[4], rb[4];  // role 0: patch rows 1, 2; role 1: rows 0, 2 (phase 0)
+    float4 rc[4], rd[4];  // role 1: rows 1, 3 (phase 1)
+    float4 bf0[4], bf1[4];
+    float v1[4][4];       // role 0: phase 1's operands, formed during phase 0 from the same two rows
+#pragma unroll
+    for (int c = 0; c < 4; ++c) ra[c] = rb[c] = rc[c] = rd[c] = bf0[c] = bf1[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (nkg > 0) dma_part(ROLE, kg0, 0, 0, LR);
+    if (nkg > 1) dma_part(ROLE, kg0 + 1, 1, 0, LR);
+    if (nkg > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LR) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    ld_row(smem, R == 0 ? 1 : 0, ra);
+    ld_row(smem, 2, rb);
+    ld_bf(smem, I0, bf0);
+    int buf = 0;
+    for (int k = 0; k < nkg; ++k) {
+      const char* sb = smem + buf * STAGE;
+      const int b1 = buf + 1 == NS ? 0 : buf + 1, b2 = b1 + 1 == NS ? 0 : b1 + 1;
+      const char* sbn = smem + b1 * STAGE;
+      // ---------------- phase 0 ----------------
+      if (R == 1) { ld_row(sb, 1, rc); ld_row(sb, 3, rd); }
+      ld_bf(sb, I1, bf1);
+      if (k > 0 && k + 1 < nkg) dma_part(ROLE, kg0 + k + 1, b1, LA, LR);  // (part A of that stage went out in the previous phase 1)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float t[4], v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float a = comp(ra[c], j), b = comp(rb[c], j);
+          t[c] = R == 0 ? a + b : a - b;  // row 1: d1 + d2; row 0: d0 - d2
+        }
+        v[0] = t[0] - t[2]; v[1] = t[1] + t[2]; v[2] = t[2] - t[1]; v[3] = t[1] - t[3];
+        if (R == 0) {  // row 2: d2 - d1, kept for phase 1
+          float u[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) u[c] = comp(rb[c], j) - comp(ra[c], j);
+          v1[j][0] = u[0] - u[2]; v1[j][1] = u[1] + u[2]; v1[j][2] = u[2] - u[1]; v1[j][3] = u[1] - u[3];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[q], comp(bf0[q], j), acc[q], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // stage k + 1 is in LDS for every wave; the buffer of stage k - 1 is free
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      // ---------------- phase 1 ----------------
+      ld_row(sbn, R == 0 ? 1 : 0, ra);
+      ld_row(sbn, 2, rb);
+      ld_bf(sbn, I0, bf0);
+      if (k + 2 < nkg) dma_part(ROLE, kg0 + k + 2, b2, 0, LA);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v[4];
+        if (R == 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = v1[j][q];
+        } else {
+          float t[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) t[c] = comp(rc[c], j) - comp(rd[c], j);  // row 3: d1 - d3
+          v[0] = t[0] - t[2]; v[1] = t[1] + t[2]; v[2] = t[2] - t[1]; v[3] = t[1] - t[3];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[4 + q] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[q], comp(bf1[q], j), acc[4 + q], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      buf = b1;
+    }
+  };
+  if (role == 0) body(std::integral_constant<int, 0>());
+  else body(std::integral_constant<int, 1>());
+
+  // ---- output transform: column sums of the own position rows; the roles' halves meet in LDS ([r][4][lane] per wave tile) ----
+  __syncthreads();
+  float* xp = reinterpret_cast<float*>(smem) + sub * (128 * 32);  // 16 KB per wave tile: the exchange, then the transposing store
+  float s[2][2][16];                                              // [own row 0 / 1][b][r]
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      s[h][0][r] = acc[h * 4 + 0][r] + acc[h * 4 + 1][r] + acc[h * 4 + 2][r];
+      s[h][1][r] = acc[h * 4 + 1][r] - acc[h * 4 + 2][r] - acc[h * 4 + 3][r];
+    }
+  if (role == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      xp[(r * 4 + 0) * 64 + lane] = s[0][0][r];  // s0[b]
+      xp[(r * 4 + 1) * 64 + lane] = s[0][1][r];
+      xp[(r * 4 + 2) * 64 + lane] = s[1][0][r];  // s3[b]
+      xp[(r * 4 + 3) * 64 + lane] = s[1][1][r];
+    }
+  }
+  __syncthreads();
+  if (role == 1) return;
+  float yv[16][4];  // [r][pixel a * 2 + b]
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const float s0 = xp[(r * 4 + b) * 64 + lane], s3 = xp[(r * 4 + 2 + b) * 64 + lane];
+      yv[r][b] = s0 + (s[0][b][r] + s[1][b][r]);
+      yv[r][2 + b] = (s[0][b][r] - s[1][b][r]) - s3;
+    }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;  // tile of the wave's 4 x 8 block held by accumulator register r
+#pragma unroll
+    for (int q = 0; q < 4; ++q) xp[(m * 4 + q) * 32 + li] = yv[r][q];
+  }
+  __builtin_amdgcn_wave_barrier();  // same wave: LDS serves its instructions in order, only the compiler must not reorder
+  const bool slab = p.ksplit > 1;
+  const bool vec = slab ? ((reinterpret_cast<uintptr_t>(p.partial) & 15) == 0 && (p.ldp & 3) == 0) : epilogue4_out_ok(p);
+  const int c4 = (lane & 7) * 4, n4 = nb * BN + wn * 32 + c4;
+  const long slab_off = (long)blockIdx.z * p.N * p.H * p.W * p.ldp;
+#pragma unroll 1
+  for (int k = 0; k < 16; ++k) {
+    const int P = k * 8 + (lane >> 3);
+    const int m = P >> 2, a = (P >> 1) & 1, b = P & 1;
+    const int oy = Y0 + 2 * (wty * 4 + (m >> 3)) + a, ox = X0 + 2 * (wtx * 8 + (m & 7)) + b;
+    const float4 v = *reinterpret_cast<const float4*>(&xp[P * 32 + c4]);
+    if (oy >= Hs || ox >= Ws) continue;
+    const int off = (n * p.H + sy + d * oy) * p.W + sx + d * ox;
+    if (slab) {
+      float* dst = p.partial + (slab_off + (long)off * p.ldp + n4);
+      if (vec) {
+        if (n4 < p.ldp) *reinterpret_cast<float4*>(dst) = v;
+      } else {
+        if (n4 < p.ldp) dst[0] = v.x;
+        if (n4 + 1 < p.ldp) dst[1] = v.y;
+        if (n4 + 2 < p.ldp) dst[2] = v.z;
+        if (n4 + 3 < p.ldp) dst[3] = v.w;
+      }
+      continue;
+    }
+    if (vec) {
+      if (n4 < p.Cout) conv_epilogue4(p, off, n4, v);
+    } else {
+      if (n4 < p.Cout) conv_epilogue(p, off, n4, v.x);
+      if (n4 + 1 < p.Cout) conv_epilogue(p, off, n4 + 1, v.y);
+      if (n4 + 2 < p.Cout) conv_epilogue(p, off, n4 + 2, v.z);
+      if (n4 + 3 < p.Cout) conv_epilogue(p, off, n4 + 3, v.w);
+    }
+  }
+}
+
 // ---- weight transform: U = G g G^T, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1] -------------------------------------------------------
 __global__ __launch_bounds__(256) void wino_pack_kernel(const PackJob j, const float* __restrict__ src, float* __restrict__ dst) {
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < j.total; e += (long)gridDim.x * 256) dst[e] = wino_pack_elem(j, src, nullptr, 1.f, e);
@@ -394,15 +673,15 @@ bool conv_wino_ok(const ConvParams& p) {
   if ((long)p.N * p.H * p.W * (long)(p.ldx > p.ldy ? p.ldx : p.ldy) >= (1L << 31)) return false;  // 32-bit element offsets
   return conv_wino_geometry(p, &d, w);
 }
-static int variant_bn(int v) { return v == 0 ? 64 : 32; }
+static int variant_bn(int v) { return (v & 1) == 0 ? 64 : 32; }  // bit 0: tile shape, bit 1: the eight-wave form
 bool conv_wino_variant_ok(const ConvParams& p, int v) {
-  if (v < 0 || v > 1) return false;
+  if (v < 0 || v > 3) return false;
   const int bn = variant_bn(v);
   if (p.wino_np % bn != 0) return false;
   return p.Cout > bn / 2 || bn == 32;  // (a block twice as wide as the layer only multiplies zeros)
 }
 static void variant_blocks(const ConvParams& p, int v, int d, int* BY, int* BX) {
-  const int th = 8, tw = v == 1 ? 16 : 8;  // tiles per workgroup
+  const int th = 8, tw = (v & 1) ? 16 : 8;  // tiles per workgroup
   const int Hs = (p.H + d - 1) / d, Ws = (p.W + d - 1) / d;
   *BY = (Hs + 2 * th - 1) / (2 * th);
   *BX = (Ws + 2 * tw - 1) / (2 * tw);
@@ -424,16 +703,16 @@ int conv_wino_max_ksplit(const ConvParams& p, int v) {
 }
 int launch_splitk_second_pass(const ConvParams& p, hipStream_t stream);
 
-template <int WTY, int WTX, int WN>
+template <int WTY, int WTX, int WN, bool EIGHT>
 static int launch_variant(const ConvParams& p, int d, int BY, int BX, hipStream_t stream) {
   typedef WinoGeom<WTY, WTX, WN> G;
-  auto kern = conv_wino_kernel<WTY, WTX, WN>;
+  auto kern = EIGHT ? conv_wino8_kernel<WTY, WTX, WN> : conv_wino_kernel<WTY, WTX, WN>;
   static std::once_flag once;
   static hipError_t attr = hipSuccess;
   std::call_once(once, [&]() { attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES); });
   UDET_HIP(attr);
   dim3 grid(p.N * d * d * BY * BX, (p.Cout + G::BN - 1) / G::BN, p.ksplit > 1 ? p.ksplit : 1);
-  UDET_LAUNCH(kern, grid, dim3(256), G::LDS_BYTES, stream, p, d, BY, BX);
+  UDET_LAUNCH(kern, grid, dim3(EIGHT ? 512 : 256), G::LDS_BYTES, stream, p, d, BY, BX);
   UDET_HIP(hipGetLastError());
   return UDET_OK;
 }
@@ -450,8 +729,10 @@ int launch_conv_wino(ConvParams& p, int variant, int ks, hipStream_t stream) {
   p.ncls = 1;
   if (p.ksplit > 1) p.ldp = (p.Cout + 3) & ~3;
   int rc;
-  if (variant == 0) rc = launch_variant<2, 1, 2>(p, d, BY, BX, stream);
-  else rc = launch_variant<2, 2, 1>(p, d, BY, BX, stream);
+  if (variant == 0) rc = launch_variant<2, 1, 2, false>(p, d, BY, BX, stream);
+  else if (variant == 1) rc = launch_variant<2, 2, 1, false>(p, d, BY, BX, stream);
+  else if (variant == 2) rc = launch_variant<2, 1, 2, true>(p, d, BY, BX, stream);
+  else rc = launch_variant<2, 2, 1, true>(p, d, BY, BX, stream);
   if (rc != UDET_OK) return rc;
   if (p.ksplit > 1) return launch_splitk_second_pass(p, stream);
   return UDET_OK;
