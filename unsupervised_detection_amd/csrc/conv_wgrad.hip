@@ -40,12 +40,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, in
 
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N, li = lane & 31, lh = lane >> 5;
-  const int mt = blockIdx.x / co_tiles;
-  const int m0 = mt * BM, co0 = (blockIdx.x - mt * co_tiles) * BN;
+  // XCD-aware order: the (M tile, N tile) workgroups of ONE pixel slice read the same dU rows and the same (tap-shifted) X rows; as
+  // consecutive hardware ids they were dealt round-robin to the eight XCDs and every L2 fetched the slice for itself (PMC, round 4:
+  // 5.4 GB per step for 1.1 GB of operands).  Each XCD now walks whole slices: logical id = slice * tiles + tile.
+  int bx, by;
+  {
+    const int nx = gridDim.x, nwg = nx * gridDim.y, h = blockIdx.x + nx * blockIdx.y;
+    const int q = nwg >> 3, r = nwg & 7, xcd = h & 7, idx = h >> 3;
+    const int l = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    by = l / nx;
+    bx = l - by * nx;
+  }
+  const int mt = bx / co_tiles;
+  const int m0 = mt * BM, co0 = (bx - mt * co_tiles) * BN;
   const int OHW = p.OH * p.OW;
   const int Q = p.N * OHW;
   const int nchunks = (Q + BKP - 1) / BKP;
-  const int c_begin = (int)((long)nchunks * blockIdx.y / nsplit), c_end = (int)((long)nchunks * (blockIdx.y + 1) / nsplit);
+  const int c_begin = (int)((long)nchunks * by / nsplit), c_end = (int)((long)nchunks * (by + 1) / nsplit);
   const int Hs = p.H >> p.up_shift, Ws = p.W >> p.up_shift;
   const int cout4 = (p.Cout + 3) & ~3;
 
@@ -174,7 +185,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, in
 
   // partial[split][Mpad][ldn] (+ bias partials pb[split][ldn]); padding rows / columns are written too (zeros)
   const int ldn = co_tiles * BN;
-  float* dst = p.partial + (size_t)blockIdx.y * p.Mpad * ldn;
+  float* dst = p.partial + (size_t)by * p.Mpad * ldn;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -184,9 +195,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, in
       for (int j = 0; j < TN; ++j) dst[(size_t)m * ldn + co0 + wn * WTN + j * 32 + li] = acc[i][j][r];
     }
   if (p.swapped) {
-    if (co0 == 0 && t < p.Cin4 && p.bias_m >= m0 && p.bias_m < m0 + BM) p.pbias[(size_t)blockIdx.y * ldn + t] = bsum;
+    if (co0 == 0 && t < p.Cin4 && p.bias_m >= m0 && p.bias_m < m0 + BM) p.pbias[(size_t)by * ldn + t] = bsum;
   } else if (bias_wg && t < BN) {
-    p.pbias[((size_t)blockIdx.y * bias_groups + ycl) * ldn + co0 + t] = bsum;
+    p.pbias[((size_t)by * bias_groups + ycl) * ldn + co0 + t] = bsum;
   }
 }
 
@@ -213,12 +224,23 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void conv_wgrad_dma_kernel(co
   const int role = __builtin_amdgcn_readfirstlane(tid >> 8);
   const int t = tid & 255, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave / WAVES_N, wn = wave % WAVES_N, li = lane & 31, lh = lane >> 5;
-  const int mt = blockIdx.x / co_tiles;
-  const int m0 = mt * BM, co0 = (blockIdx.x - mt * co_tiles) * BN;
+  // XCD-aware order: the (M tile, N tile) workgroups of ONE pixel slice read the same dU rows and the same (tap-shifted) X rows; as
+  // consecutive hardware ids they were dealt round-robin to the eight XCDs and every L2 fetched the slice for itself (PMC, round 4:
+  // 5.4 GB per step for 1.1 GB of operands).  Each XCD now walks whole slices: logical id = slice * tiles + tile.
+  int bx, by;
+  {
+    const int nx = gridDim.x, nwg = nx * gridDim.y, h = blockIdx.x + nx * blockIdx.y;
+    const int q = nwg >> 3, r = nwg & 7, xcd = h & 7, idx = h >> 3;
+    const int l = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    by = l / nx;
+    bx = l - by * nx;
+  }
+  const int mt = bx / co_tiles;
+  const int m0 = mt * BM, co0 = (bx - mt * co_tiles) * BN;
   const int OHW = p.OH * p.OW;
   const int Q = p.N * OHW;
   const int nchunks = (Q + BKP - 1) / BKP;
-  const int c_begin = (int)((long)nchunks * blockIdx.y / nsplit), c_end = (int)((long)nchunks * (blockIdx.y + 1) / nsplit);
+  const int c_begin = (int)((long)nchunks * by / nsplit), c_end = (int)((long)nchunks * (by + 1) / nsplit);
   const int Hs = p.H >> p.up_shift, Ws = p.W >> p.up_shift;
   const int cout4 = (p.Cout + 3) & ~3;
 
@@ -386,7 +408,7 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void conv_wgrad_dma_kernel(co
         for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv;
   }
   const int ldn = co_tiles * BN;
-  float* dst = p.partial + (size_t)blockIdx.y * p.Mpad * ldn;
+  float* dst = p.partial + (size_t)by * p.Mpad * ldn;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -396,9 +418,9 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void conv_wgrad_dma_kernel(co
       for (int j = 0; j < TN; ++j) dst[(size_t)m * ldn + co0 + wn * WTN + j * 32 + li] = acc[i][j][r];
     }
   if (p.swapped) {
-    if (co0 == 0 && t < p.Cin4 && p.bias_m >= m0 && p.bias_m < m0 + BM) p.pbias[(size_t)blockIdx.y * ldn + t] = bsum;
+    if (co0 == 0 && t < p.Cin4 && p.bias_m >= m0 && p.bias_m < m0 + BM) p.pbias[(size_t)by * ldn + t] = bsum;
   } else if (bias_wg && t < BN) {
-    p.pbias[((size_t)blockIdx.y * bias_groups + ycl) * ldn + co0 + t] = bsum;
+    p.pbias[((size_t)by * bias_groups + ycl) * ldn + co0 + t] = bsum;
   }
 }
 

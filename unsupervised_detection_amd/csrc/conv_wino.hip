@@ -85,6 +85,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
+  // the N blocks of one tile block are consecutive workgroups of ONE XCD: they read the same input halo out of that XCD's L2
+  // (as blockIdx.y they ran a whole grid apart and the halo came from HBM twice: dc_conv21 338 MB fetched for a 140 MB input)
+  const int NB = (p.Cout + BN - 1) / BN;
+  const int nb = bid % NB;
+  bid /= NB;
   const int d = dil;
   const int bx = bid % BX;
   int rem = bid / BX;
@@ -96,7 +101,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   const int n = rem / d;
   const int Hs = (p.H - sy + d - 1) / d, Ws = (p.W - sx + d - 1) / d;  // this output sub-lattice's grid
   const int Y0 = by * 2 * TH, X0 = bx * 2 * TW;                          // first output pixel (sub-lattice coordinates)
-  const int nb = blockIdx.y;
   // K slice of this workgroup (stages of 8 channels)
   const int nkg_all = p.Kc >> 3;
   int kg0 = 0, kg1 = nkg_all;
@@ -342,6 +346,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
+  // the N blocks of one tile block are consecutive workgroups of ONE XCD: they read the same input halo out of that XCD's L2
+  // (as blockIdx.y they ran a whole grid apart and the halo came from HBM twice: dc_conv21 338 MB fetched for a 140 MB input)
+  const int NB = (p.Cout + BN - 1) / BN;
+  const int nb = bid % NB;
+  bid /= NB;
   const int d = dil;
   const int bx = bid % BX;
   int rem = bid / BX;
@@ -353,7 +362,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   const int n = rem / d;
   const int Hs = (p.H - sy + d - 1) / d, Ws = (p.W - sx + d - 1) / d;
   const int Y0 = by * 2 * TH, X0 = bx * 2 * TW;
-  const int nb = blockIdx.y;
   const int nkg_all = p.Kc >> 3;
   int kg0 = 0, kg1 = nkg_all;
   if (p.ksplit > 1) {
@@ -711,7 +719,7 @@ static int launch_variant(const ConvParams& p, int d, int BY, int BX, hipStream_
   static hipError_t attr = hipSuccess;
   std::call_once(once, [&]() { attr = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES); });
   UDET_HIP(attr);
-  dim3 grid(p.N * d * d * BY * BX, (p.Cout + G::BN - 1) / G::BN, p.ksplit > 1 ? p.ksplit : 1);
+  dim3 grid(p.N * d * d * BY * BX * ((p.Cout + G::BN - 1) / G::BN), 1, p.ksplit > 1 ? p.ksplit : 1);
   UDET_LAUNCH(kern, grid, dim3(EIGHT ? 512 : 256), G::LDS_BYTES, stream, p, d, BY, BX);
   UDET_HIP(hipGetLastError());
   return UDET_OK;
