@@ -23,7 +23,7 @@ import json
 import os
 import shutil
 
-CONV = ("conv_igemm", "conv_tile", "conv_thin", "conv_wgrad", "wgrad_reduce", "conv_splitk_epilogue", "tap_gather", "bn_dot", "bn_finish")
+CONV = ("conv_igemm", "conv_wino", "conv_tile", "conv_thin", "conv_wgrad", "wgrad_reduce", "conv_splitk_epilogue", "tap_gather", "bn_dot", "bn_finish")
 PEAK = 157.3
 
 
