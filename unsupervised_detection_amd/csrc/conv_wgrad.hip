@@ -466,8 +466,93 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradParams p, 
   }
 }
 
-// ---- BN-folded generator layers: dgamma needs sum_{t,ci} W*G per output channel ----
+// ---- BN-folded generator layers in TWO launches behind the GEMM instead of three (reduce 5 us, bn_dot 9 us, bn_finish 4 us on a 57 us
+// GEMM, on the one queue the generator's filter gradients share: profiles/r04_step_ablation.txt): the slab reduction also scales
+// (G * gamma*c) and forms the per-channel dot sum W*G that dgamma needs.  A block owns RB consecutive (tap, ci) rows and all columns:
+// thread (rg = t / CW, co = t % CW) sums the splits of its rows in split order (the numbers wgrad_reduce_kernel<1> produces), stores
+// G * gamma*c, keeps W*G; the blocks' partial dots go to pd[block][co], and a one-block launch adds them in block order.
+// (Measured and dropped: the same in ONE launch, the last-arriving block finalising behind a ticket -- 55 / 36 us instead of 18:
+// device-scope stores / loads of the partial dots cost more than the launch they save.)
 #define BND_SPLIT 16
+#define BNR_MAXBLK 1024
+template <int CW>
+__global__ __launch_bounds__(256) void wgrad_reduce_bn_kernel(const WgradParams p, int ldn, int nsplit, int RB, float* __restrict__ pd) {
+  constexpr int RG = 256 / CW;
+  __shared__ float red[256];
+  const int t = threadIdx.x, co = t % CW, rg = t / CW;
+  const int Mreal = p.ntaps * p.Cin4;
+  const size_t slab = (size_t)p.Mpad * ldn;
+  const int r0 = blockIdx.x * RB;
+  float dot = 0.f;
+  if (co < p.Cout) {
+    const float gs = p.gamma[co] * p.bn_c;
+    for (int m = r0 + rg; m < r0 + RB && m < Mreal; m += RG) {
+      const int tap = m / p.Cin4, ci = m - tap * p.Cin4;
+      if (ci >= p.Cin) continue;
+      const float* src = p.partial + (size_t)m * ldn + co;
+      float s = 0.f;
+      int k = 0;
+      for (; k + 7 < nsplit; k += 8) {
+        float a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = src[(size_t)(k + u) * slab];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += a[u];
+      }
+      for (; k < nsplit; ++k) s += src[(size_t)k * slab];
+      const size_t e = ((size_t)p.taps[tap].widx * p.Cin + ci) * p.Cout + co;
+      dot = fmaf(p.w[e], s, dot);
+      p.dw[e] = s * gs;
+    }
+  }
+  red[t] = dot;
+  __syncthreads();
+  if (rg == 0 && co < p.Cout) {
+    float d = red[co];
+#pragma unroll
+    for (int g = 1; g < RG; ++g) d += red[g * CW + co];
+    pd[(size_t)blockIdx.x * p.Cout + co] = d;
+  }
+}
+// second (last) launch of the BN-folded layers: per channel, the blocks' dots in block order and the bias partials in split order
+__global__ __launch_bounds__(256) void wgrad_bn_finish2_kernel(const WgradParams p, int ldn, int nsplit, int nb, const float* __restrict__ pd) {
+  __shared__ float red[256];
+  const int t = threadIdx.x, cl = t & 31, rg = t >> 5, co = blockIdx.x * 32 + cl;  // 8 thread groups x 32 channels per block
+  const int per = (nb + 7) / 8, b0 = rg * per, b1 = b0 + per < nb ? b0 + per : nb;
+  float d = 0.f;
+  if (co < p.Cout) {
+    int b = b0;
+    for (; b + 11 < b1; b += 12) {
+      float a[12];
+#pragma unroll
+      for (int u = 0; u < 12; ++u) a[u] = pd[(size_t)(b + u) * p.Cout + co];
+#pragma unroll
+      for (int u = 0; u < 12; ++u) d += a[u];
+    }
+    for (; b < b1; ++b) d += pd[(size_t)b * p.Cout + co];
+  }
+  red[t] = d;
+  __syncthreads();
+  if (rg == 0 && co < p.Cout) {
+    float dsum = red[cl];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) dsum += red[g * 32 + cl];
+    float S = 0.f;
+    int k = 0;
+    for (; k + 7 < nsplit; k += 8) {
+      float a[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a[u] = p.pbias[(size_t)(k + u) * ldn + co];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) S += a[u];
+    }
+    for (; k < nsplit; ++k) S += p.pbias[(size_t)k * ldn + co];
+    p.dgamma[co] = p.bn_c * (dsum + p.b[co] * S);
+    p.dbeta[co] = S;
+    p.db[co] = p.gamma[co] * p.bn_c * S;
+  }
+}
+// the separate form (single-operator launches with the class-structured / operand-swapped views): dgamma's dot sum W*G per output channel
 __global__ __launch_bounds__(256) void bn_dot_kernel(const float* __restrict__ w, const float* __restrict__ g, int R, int C,
                                                      float* __restrict__ pd) {
   __shared__ float red[256];
@@ -536,7 +621,7 @@ int launch_wgrad_up_combine(const float* deff, float* dw, int Cin, int Cout, hip
 size_t wgrad_partial_floats_needed(int T, int Cin, int Cout) {
   // BN dot partials + one split of (bias, filter) partials at the padded tile sizes
   const size_t cin4 = (size_t)((Cin + 3) & ~3), mpad = (T * cin4 + 127) / 128 * 128, ldn = (size_t)(Cout + 127) / 128 * 128;
-  return (size_t)BND_SPLIT * Cout + ldn + mpad * ldn + 64;
+  return (size_t)BNR_MAXBLK * Cout + ldn + mpad * ldn + 64;
 }
 
 static std::unordered_map<uint64_t, int> g_wcache;  // problem shape -> split count | (LDS-DMA variant: 1 / 2 for a 2- / 3-stage ring) << 20
@@ -616,8 +701,8 @@ int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream) {
   const int nchunks = (int)((Q + 31) / 32);
   g.fd_ohw = make_fastdiv((unsigned)(g.OH * g.OW));
   g.fd_ow = make_fastdiv((unsigned)g.OW);
-  float* pd = p.partial;                                 // [BND_SPLIT][Cout]
-  float* base = pd + (size_t)BND_SPLIT * p.Cout;
+  float* pd = p.partial;                                 // [BNR_MAXBLK][Cout]: per-block dot partials of the fused finaliser ([BND_SPLIT][Cout] of bn_dot)
+  float* base = pd + (size_t)BNR_MAXBLK * p.Cout;
   base += (16 - ((uintptr_t)base / sizeof(float)) % 16) % 16;  // keep the slabs 64-byte aligned
   const size_t fixed = (size_t)(base - p.partial);
   const size_t bgroups = p.ycls ? 4 : 1;
@@ -638,6 +723,8 @@ int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream) {
   if (p.ntaps < T) UDET_HIP(hipMemsetAsync(p.dw, 0, wsz * sizeof(float), stream));  // culled taps have zero gradient
   const long total = (long)(Mreal + 1) * g.Cout;
   const bool dma_ok = p.ya == nullptr && p.zero16 != nullptr && !(reinterpret_cast<uintptr_t>(p.zero16) & 15);
+  // BN-folded layers (generator) finish inside the reduction launch when the caller provides a ticket (plans do)
+  const bool fused_bn = p.gamma && !g.swapped && !p.ycls && p.ntaps == T && p.Cout <= 128 && p.db && p.dgamma && p.dbeta && p.w && p.b;
   auto run = [&](int cfg) {
     const int ns = cfg & 0xfffff;
     const int dma = dma_ok ? (cfg >> 20) : 0;
@@ -647,6 +734,19 @@ int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream) {
     if (bn == 128) wgrad_launch<128, 128, 2, 2>(q, m_tiles, co_tiles, ns, dma, stream);
     else if (bn == 64) wgrad_launch<128, 64, 2, 2>(q, m_tiles, co_tiles, ns, dma, stream);
     else wgrad_launch<128, 32, 4, 1>(q, m_tiles, co_tiles, ns, dma, stream);
+    if (fused_bn) {  // reduction + BN finalisation in one launch
+      const int cw = g.Cout > 64 ? 128 : (g.Cout > 32 ? 64 : (g.Cout > 16 ? 32 : 16));
+      int rb = 256 / cw;  // rows per block: ONE element per thread (the reduction is latency-bound: 28 slabs 590 KB apart per element --
+                          // it needs every CU; eight rows per thread on 72 blocks took 30 us instead of 5)
+      while ((Mreal + rb - 1) / rb > BNR_MAXBLK) rb *= 2;
+      const int nb = (Mreal + rb - 1) / rb;
+      if (cw == 128) UDET_LAUNCH(wgrad_reduce_bn_kernel<128>, dim3(nb), dim3(256), 0, stream, q, ldn, ns, rb, pd);
+      else if (cw == 64) UDET_LAUNCH(wgrad_reduce_bn_kernel<64>, dim3(nb), dim3(256), 0, stream, q, ldn, ns, rb, pd);
+      else if (cw == 32) UDET_LAUNCH(wgrad_reduce_bn_kernel<32>, dim3(nb), dim3(256), 0, stream, q, ldn, ns, rb, pd);
+      else UDET_LAUNCH(wgrad_reduce_bn_kernel<16>, dim3(nb), dim3(256), 0, stream, q, ldn, ns, rb, pd);
+      UDET_LAUNCH(wgrad_bn_finish2_kernel, dim3((g.Cout + 31) / 32), dim3(256), 0, stream, q, ldn, ns, nb, pd);
+      return;
+    }
     const int sl = (ns >= 64 && total * 64 <= 262144) ? 64 : ((ns >= 8 && total * 8 <= 262144) ? 8 : 1);
     const long nbl = (total * sl + 255) / 256;
     const int nb = (int)(nbl > 4096 ? 4096 : nbl);
@@ -723,7 +823,7 @@ int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream) {
   UDET_HIP(hipGetLastError());
   int nbw = (int)((wsz + 255) / 256);
   if (nbw > 2048) nbw = 2048;
-  if (p.gamma) {
+  if (p.gamma && !fused_bn) {
     if (!p.db || !p.dgamma || !p.dbeta || !p.w || !p.b) {
       set_error("wgrad: BN finalisation needs db, dgamma, dbeta, w and b");
       return UDET_ERR_ARG;
