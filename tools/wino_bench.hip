@@ -1061,7 +1061,8 @@ int main(int argc, char** argv) {
       {"pwc.dc_conv21", 4, 96, 160, 565, 128, 1}, {"pwc.conv2_1", 4, 96, 160, 243, 128, 1}, {"pwc.conv2_3", 4, 96, 160, 467, 64, 1},
       {"pwc.conv2_4", 4, 96, 160, 531, 32, 1},    {"pwc.dc_conv22", 4, 96, 160, 128, 128, 2}, {"pwc.dc_conv31", 4, 48, 80, 597, 128, 1},
       {"gen.conv5", 4, 48, 96, 128, 128, 1},      {"gen.conv3", 4, 96, 192, 64, 64, 1},     {"odd", 2, 37, 53, 20, 40, 1},
-      {"odd.d3", 1, 41, 50, 36, 70, 3}};
+      {"odd.d3", 1, 41, 50, 36, 70, 3},
+      {"ovh.1stage", 4, 48, 96, 8, 128, 1}, {"ovh.2stage", 4, 48, 96, 16, 128, 1}, {"ovh.4stage", 4, 48, 96, 32, 128, 1}};
   const int reps = 20;
   for (const Shape& s : shapes) {
     bool sel = argc <= 1;
