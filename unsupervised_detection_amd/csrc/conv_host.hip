@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
     return;
   }
   if (j.mode == 7 || j.mode == 8) {  // Winograd U = G g G^T (conv_wino.hip)
-    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < j.total; e += (long)gridDim.x * 256) dst[e] = wino_pack_elem(j, src, gamma, bn_c, e);
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < j.total; e += (long)gridDim.x * 256) wino_pack_item(j, src, gamma, bn_c, dst, e);
     return;
   }
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < j.total; e += (long)gridDim.x * 256) {

@@ -595,13 +595,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
 // ---- weight transform: U = G g G^T, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1] -------------------------------------------------------
 __global__ __launch_bounds__(256) void wino_pack_kernel(const PackJob j, const float* __restrict__ src, float* __restrict__ dst) {
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < j.total; e += (long)gridDim.x * 256) dst[e] = wino_pack_elem(j, src, nullptr, 1.f, e);
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < j.total; e += (long)gridDim.x * 256) wino_pack_item(j, src, nullptr, 1.f, dst, e);
 }
 int launch_wino_pack(const float* src, float* dst, int R, int C, int Kc, int np, int k_split, int k_gap, int transposed, hipStream_t stream) {
   PackJob j;
   memset(&j, 0, sizeof(j));
   j.T = 9; j.R = R; j.C = C; j.Kc = Kc; j.ldw = np; j.k_split = k_split; j.k_gap = k_gap;
-  j.mode = transposed ? 8 : 7; j.total = (long)(Kc / 8) * 16 * 2 * np * 4; j.gamma_off = -1;
+  j.mode = transposed ? 8 : 7; j.total = (long)(Kc / 8) * 2 * np; j.gamma_off = -1;  // work items: (channel group, lane half, column)
   int nb = (int)((j.total + 255) / 256);
   if (nb > 2048) nb = 2048;
   UDET_LAUNCH(wino_pack_kernel, dim3(nb), dim3(256), 0, stream, j, src, dst);

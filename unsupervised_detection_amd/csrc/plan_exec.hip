@@ -437,12 +437,12 @@ int plan_init_workspace(Plan* P, float* ws, hipStream_t s) {
       }
       if (L.wino_off) {  // Winograd operand of the forward pass: K = input channels with the slab's gap map, N = output channels
         j.dst_off = (long)L.wino_off; j.R = L.cin; j.C = L.cout; j.Kc = L.Kc; j.ldw = L.wino_np; j.k_split = L.k_split; j.k_gap = L.k_gap;
-        j.mode = 7; j.total = (long)conv_wino_floats(L.Kc, L.cout);
+        j.mode = 7; j.total = (long)(L.Kc / 8) * 2 * L.wino_np;  // work items (wino_pack.h)
         jobs.push_back(j);
       }
       if (L.winoT_off) {  // ... of the backward-data pass: K = output channels, N = input channels, taps mirrored
         j.dst_off = (long)L.winoT_off; j.R = L.cin; j.C = L.cout; j.Kc = L.KcT; j.ldw = L.winoT_np; j.k_split = L.KcT; j.k_gap = 0;
-        j.mode = 8; j.total = (long)conv_wino_floats(L.KcT, L.cin);
+        j.mode = 8; j.total = (long)(L.KcT / 8) * 2 * L.winoT_np;
         jobs.push_back(j);
       }
       // bias (BN-folded for the generator)
