@@ -678,7 +678,8 @@ bool conv_wino_ok(const ConvParams& p) {
   if ((reinterpret_cast<uintptr_t>(p.zero16) | reinterpret_cast<uintptr_t>(p.wino_u) | reinterpret_cast<uintptr_t>(p.x)) & 15) return false;
   if (p.Kc < 8 || p.Kc % 8 != 0 || p.ldx % 4 != 0 || p.x_coff % 4 != 0) return false;
   if (p.wino_np < 32 || p.wino_np % 32 != 0 || p.wino_np < p.Cout) return false;
-  if ((long)p.N * p.H * p.W * (long)(p.ldx > p.ldy ? p.ldx : p.ldy) >= (1L << 31)) return false;  // 32-bit element offsets
+  // 32-bit element offsets on the output side, 32-bit BYTE offsets (the saddr form of the LDS-DMA) on the input side
+  if ((long)p.N * p.H * p.W * (long)p.ldy >= (1L << 31) || (long)p.N * p.H * p.W * (long)p.ldx >= (1L << 30)) return false;
   return conv_wino_geometry(p, &d, w);
 }
 static int variant_bn(int v) { return (v & 1) == 0 ? 64 : 32; }  // bit 0: tile shape, bit 1: the eight-wave form
