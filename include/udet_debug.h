@@ -17,6 +17,9 @@ void udet_debug_force_conv(int bm, int bn, int ks);
 void udet_debug_conv_fp16(int on);
 /* while on, the first single-op launch of every distinct problem shape times its candidate configurations and caches the winner
  * (what udet_autotune does for a plan); tools/conv_bench.py / wgrad_bench.py use it to measure the tuned kernels stand-alone */
+/* filter gradient: nsplit > 0 pins the number of pixel slices (clamped to the workspace capacity), dma = 0 / 1 / 2 the staging variant
+ * (register-staged / LDS-DMA with a 2- / 3-stage ring; -1: as tuned); nsplit = 0 restores the tuned / heuristic choice */
+void udet_debug_force_wgrad(int nsplit, int dma);
 void udet_debug_set_tuning(int on);
 /* what the most recent convolution launch actually ran: family (0 plain, 1 wave-specialised, 2 LDS-DMA, 3 tile-resident,
  * 6 self-staging LDS-DMA, 7 / 8 direct kernel for two input / two output channels) | tile rows << 8 | split count << 20 | folded split-K << 28 */

@@ -32,7 +32,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default="")
+    ap.add_argument("--nsplit", default="", help="comma-separated pixel-slice counts to pin in turn (udet_debug_force_wgrad); default: the tuned count")
+    ap.add_argument("--dma", type=int, default=-1, help="staging variant pinned with --nsplit: 0 register-staged, 1 / 2 LDS-DMA with a 2- / 3-stage ring")
     a = ap.parse_args()
+    from unsupervised_detection_amd._devel import dbg as _dbg
+    splits = [int(v) for v in a.nsplit.split(",") if v] or [0]
     g = torch.Generator().manual_seed(0)
     if os.environ.get("UDET_WGRAD_TUNE", "1") == "1":
         from unsupervised_detection_amd._devel import dbg
@@ -44,17 +48,21 @@ def main():
         oh, ow = -(-h // s), -(-w // s)
         dy = (torch.rand(n, oh, ow, cout, generator=g) - 0.5).cuda()
         gflop = 2.0 * n * oh * ow * cout * cin * k * k * 1e-9
-        for _ in range(a.reps):
-            ops.conv2d_backward_filter(x, dy, None, (k, k), s, 1, "none", 0.0, False)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(a.reps):
-            ops.conv2d_backward_filter(x, dy, None, (k, k), s, 1, "none", 0.0, False)
-        e1.record()
-        torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) * 1e3 / a.reps
-        print(f"{name:14s} {gflop:7.2f} GF  {us:7.1f} us  {gflop / us * 1e3:6.1f} TF (incl. reduction + python launch overhead)", flush=True)
+        for ns in splits:
+          _dbg.udet_debug_force_wgrad(ns, a.dma)
+          name_ = name if ns == 0 else "%s ns=%d" % (name, ns)
+          for _ in range(a.reps):
+              ops.conv2d_backward_filter(x, dy, None, (k, k), s, 1, "none", 0.0, False)
+          torch.cuda.synchronize()
+          e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+          e0.record()
+          for _ in range(a.reps):
+              ops.conv2d_backward_filter(x, dy, None, (k, k), s, 1, "none", 0.0, False)
+          e1.record()
+          torch.cuda.synchronize()
+          us = e0.elapsed_time(e1) * 1e3 / a.reps
+          print(f"{name_:20s} {gflop:7.2f} GF  {us:7.1f} us  {gflop / us * 1e3:6.1f} TF (incl. reduction + python launch overhead)", flush=True)
+    _dbg.udet_debug_force_wgrad(0, -1)
 
 
 if __name__ == "__main__":

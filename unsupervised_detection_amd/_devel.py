@@ -18,5 +18,7 @@ dbg.udet_debug_last_conv.restype = ctypes.c_int
 dbg.udet_debug_last_conv.argtypes = []
 dbg.udet_debug_conv_fp16.restype = None
 dbg.udet_debug_conv_fp16.argtypes = [ctypes.c_int]
+dbg.udet_debug_force_wgrad.restype = None
+dbg.udet_debug_force_wgrad.argtypes = [ctypes.c_int, ctypes.c_int]
 dbg.udet_debug_set_tuning.restype = None
 dbg.udet_debug_set_tuning.argtypes = [ctypes.c_int]

@@ -38,6 +38,7 @@ void conv_tune_note_reject();
 float* tune_scratch(size_t floats, int which);
 bool tune_compare(const float* a, const float* b, size_t n, hipStream_t stream, float* diff_out, float* scale_out);
 void wgrad_set_tuning(int on);
+void wgrad_force(int nsplit, int dma);  // debug hook: nsplit > 0 pins the split count (clamped to the capacity), dma 0 / 1 / 2 the staging variant (-1: as tuned)
 int wgrad_tuned_shapes();
 void conv_tune_dump(FILE* f);
 void conv_tune_put(unsigned long long key, int bm, int bn, int ks, int ws, int fold, int tail);

@@ -624,6 +624,8 @@ size_t wgrad_partial_floats_needed(int T, int Cin, int Cout) {
   return (size_t)BNR_MAXBLK * Cout + ldn + mpad * ldn + 64;
 }
 
+static int g_force_wsplit = 0, g_force_wdma = -1;  // test / tool hook (libudet_debug.so): pin the split count / staging variant
+void wgrad_force(int nsplit, int dma) { g_force_wsplit = nsplit > 0 ? nsplit : 0; g_force_wdma = dma; }
 static std::unordered_map<uint64_t, int> g_wcache;  // problem shape -> split count | (LDS-DMA variant: 1 / 2 for a 2- / 3-stage ring) << 20
 static std::mutex g_wcache_mu;
 static int g_wtuning = 0;
@@ -818,6 +820,10 @@ int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream) {
       std::lock_guard<std::mutex> l(g_wcache_mu);
       g_wcache[key] = nsplit;
     }
+  }
+  if (g_force_wsplit > 0) {
+    const int ns = g_force_wsplit > cap ? cap : g_force_wsplit;
+    nsplit = ns | ((g_force_wdma >= 0 ? (dma_ok ? g_force_wdma : 0) : (nsplit >> 20)) << 20);
   }
   run(nsplit);
   UDET_HIP(hipGetLastError());

@@ -10,6 +10,7 @@ extern "C" {
 int udet_debug_last_conv(void) { return conv_last_config(); }
 void udet_debug_force_conv(int bm, int bn, int ks) { conv_force_config(bm, bn, ks); }
 void udet_debug_conv_fp16(int on) { conv_debug_f16(on); }
+void udet_debug_force_wgrad(int nsplit, int dma) { wgrad_force(nsplit, dma); }
 void udet_debug_set_tuning(int on) {
   conv_set_tuning(on);
   wgrad_set_tuning(on);
