@@ -181,6 +181,8 @@ struct PackJob {
                                                // 5/6 NN x2 + 3x3 as four 2x2 convolutions (T = 16 = class*4 + tap), forward / transposed
                                                // 7/8 Winograd U = G g G^T of a 3x3 filter, forward / backward-data (taps mirrored, [k=co][n=ci]):
                                                //     dst [Kc / 8][16][2][ldw = wino_np][4] (ConvParams::wino_u)
+                                               // 9/10 recover decoder as four 3x3 convolutions on the ringed low-resolution grid, forward /
+                                               //     backward-data: dst [36][Kc][ldw]; beta_off = row variant * 3 + column variant (conv_host.hip)
 };
 
 // --------------------------------------------------------------- wgrad ----

@@ -136,6 +136,15 @@ int launch_pack_weights(const float* src, float* dst, int T, int R, int C, int K
   return UDET_OK;
 }
 
+// merge matrices of pack modes 9 / 10: [parity][variant: interior, last, last - interior][merged tap a][4x4 tap k]
+__constant__ float UPB_MERGE[2][3][3][4] = {
+    {{{.5f, 0.f, 0.f, 0.f}, {.5f, 1.f, .5f, 0.f}, {0.f, 0.f, .5f, 1.f}},
+     {{.5f, 0.f, 0.f, 0.f}, {.5f, 1.f, 1.f, 0.f}, {0.f, 0.f, 0.f, 0.f}},
+     {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, .5f, 0.f}, {0.f, 0.f, -.5f, -1.f}}},
+    {{{1.f, .5f, 0.f, 0.f}, {0.f, .5f, 1.f, .5f}, {0.f, 0.f, 0.f, .5f}},
+     {{1.f, 1.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}},
+     {{0.f, .5f, 0.f, 0.f}, {0.f, -.5f, -1.f, -.5f}, {0.f, 0.f, 0.f, -.5f}}}};
+
 // All re-layout jobs of one network in ONE launch (blockIdx.y = job): the per-step repack of the trainable weights
 // was ~140 launches of ~3 us.  BN (inference, moving stats 0/1) is folded on the fly: scale = gamma*c,
 // bias' = b*gamma*c + beta.
@@ -148,6 +157,54 @@ __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restric
   if (j.mode == 2) {
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < j.total; e += (long)gridDim.x * 256)
       dst[e] = gamma ? src[e] * (gamma[e] * bn_c) + wsrc[j.beta_off + e] : src[e];
+    return;
+  }
+  if (j.mode == 9 || j.mode == 10) {
+    // Recover decoder (legacy bilinear x2 + 4x4 SAME convolution) as four 3x3 convolutions on the ringed low-resolution grid: merged
+    // weights W~[cls][a][b] = sum_kl Ry[a][k] Rx[b][l] w[k][l], T = 36 = class * 9 + a * 3 + b, class (py, px).  Ry / Rx are the merge
+    // matrices of the row / column parity, in the variant the job names (j.beta_off = row variant * 3 + column variant):
+    //   0 interior  E = [1/2 0 0 0; 1/2 1 1/2 0; 0 0 1/2 1]   O = [1 1/2 0 0; 0 1/2 1 1/2; 0 0 0 1/2]
+    //   1 last low-resolution row / column  E = [1/2 0 0 0; 1/2 1 1 0; 0]   O = [1 1 0 0; 0; 0]      2: last - interior
+    // mode 9: dst [36][k = ci (gap map)][n = co]; mode 10 (backward-data): dst [36][k = co][n = ci]
+    // One work item per (k, n): its sixteen 4x4 taps are read once and merged separably (rows, then columns) into the 36 outputs.
+    const int rv = (int)(j.beta_off / 3), cv = (int)(j.beta_off % 3);
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < j.total; e += (long)gridDim.x * 256) {
+      const int n = (int)(e % j.ldw), k = (int)(e / j.ldw);
+      int ks = k;
+      if (k >= j.k_split) ks = (k < j.k_split + j.k_gap) ? -1 : k - j.k_gap;
+      const int ci = j.mode == 9 ? ks : n, co = j.mode == 9 ? n : ks;
+      const bool real = ci >= 0 && ci < j.R && co >= 0 && co < j.C;
+      float w[4][4];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int ll = 0; ll < 4; ++ll) w[kk][ll] = real ? src[((long)(kk * 4 + ll) * j.R + ci) * j.C + co] : 0.f;
+      const long plane = (long)j.Kc * j.ldw;
+#pragma unroll
+      for (int py = 0; py < 2; ++py) {
+        float t1[3][4];  // rows merged
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int ll = 0; ll < 4; ++ll) {
+            float v = 0.f;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) v += UPB_MERGE[py][rv][a][kk] * w[kk][ll];
+            t1[a][ll] = v;
+          }
+#pragma unroll
+        for (int px = 0; px < 2; ++px)
+#pragma unroll
+          for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int bb = 0; bb < 3; ++bb) {
+              float v = 0.f;
+#pragma unroll
+              for (int ll = 0; ll < 4; ++ll) v += UPB_MERGE[px][cv][bb][ll] * t1[a][ll];
+              dst[(long)((py * 2 + px) * 9 + a * 3 + bb) * plane + e] = v;
+            }
+      }
+    }
     return;
   }
   if (j.mode == 7 || j.mode == 8) {  // Winograd U = G g G^T (conv_wino.hip)

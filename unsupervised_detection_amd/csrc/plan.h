@@ -55,6 +55,12 @@ struct Layer {
   // for the backward-data pass (mirrored taps, K = output channels); 0: the layer is not eligible
   size_t wino_off = 0, winoT_off = 0;
   int wino_np = 0, winoT_np = 0;
+  // Recover decoder levels 1-3 ("up-conv algebra", plan_exec.hip): legacy bilinear x2 + 4x4 convolution as four 3x3 convolutions on the
+  // ringed low-resolution source `xhat`.  Forward weight sets per OUTPUT region {interior, last row, last column, corner}; backward-data
+  // sets {interior, (last - interior) rows, (last - interior) columns, both} (transposed)
+  bool upb = false;
+  int xhat = -1, src = -1;   // ringed source [N, h + 2, w + 2, ld] / the source it is built from
+  size_t wupb_off[4] = {0, 0, 0, 0}, wupbT_off[4] = {0, 0, 0, 0};
   // tensors
   int x = -1, x_coff = 0, y = -1, y_coff = 0;
   int res = -1, res_coff = 0, y2 = -1;

@@ -396,6 +396,18 @@ Plan* plan_build(const Config& cfg) {
         Layer L = mk_layer(NET_REC, d.name, S("FlownetS/%s/weights", d.name), S("FlownetS/%s/biases", d.name), 4, d.cin, d.cout, 1,
                            1, ACT_LEAKY, 0.2f);
         L.x = r; L.y = concat[k]; L.y_coff = 0; L.Kc = ldsrc; L.H = hs[k]; L.W = wsz[k];
+        // levels 1-3 (exact x2, source at least 4x4, fp32): four 3x3 convolutions on the ringed low-resolution source instead of the
+        // 4x4 convolution over the up-sampled tensor (9 of 16 tap products; plan_exec.hip).  The filter gradient keeps the up-sampled form.
+        if (k <= 3 && !cfg.conv_fp16 && hs[k] == 2 * hs[k + 1] && wsz[k] == 2 * wsz[k + 1] && hs[k + 1] >= 4 && wsz[k + 1] >= 4) {
+          L.upb = true;
+          L.src = src;
+          L.xhat = P->add_buf(S("rec.p%d", k + 1), N, hs[k + 1] + 2, wsz[k + 1] + 2, ldsrc);
+          P->add_buf(S("rec.d.p%d", k + 1), N, hs[k + 1] + 2, wsz[k + 1] + 2, ldsrc);
+          const int kct = round_up(d.cout, 8);
+          P->add_buf(S("rec.d.sr%d", k), N, 2, wsz[k], kct);  // last two rows / columns / corner of dU (backward-data corrections)
+          P->add_buf(S("rec.d.sc%d", k), N, hs[k], 2, kct);
+          P->add_buf(S("rec.d.sx%d", k), N, 2, 2, kct);
+        }
         P->rec.push_back(L);
       }
       if (k < 5) {
@@ -470,6 +482,11 @@ Plan* plan_build(const Config& cfg) {
       L.wu_off = off; off = align64(off + (size_t)16 * L.Kc * L.ldw);
       L.wuT_off = off; off = align64(off + (size_t)16 * L.KcT * L.ldwT);
     }
+    if (L.upb)
+      for (int r = 0; r < 4; ++r) {
+        L.wupb_off[r] = off; off = align64(off + (size_t)36 * L.Kc * L.ldw);
+        L.wupbT_off[r] = off; off = align64(off + (size_t)36 * L.KcT * L.ldwT);
+      }
     // Winograd operands: 3x3 stride-1 layers whose K extent is whole 8-channel stages (the tuner decides per shape whether the family runs)
     if (L.kh == 3 && L.kw == 3 && L.stride == 1 && !L.up && !L.transposed && !L.col2im && L.cout >= 16 && L.H * L.W >= 512) {
       if (L.Kc % 8 == 0) {
@@ -505,10 +522,10 @@ Plan* plan_build(const Config& cfg) {
     P->seg_off[net] = off;
     off = align64(off + 4 * net_params(net).p.size() + 64);  // two long tables (offset, len) = 4 floats per entry
   }
-  for (int net = 1; net <= 2; ++net) {  // PackJob tables: <= 8 jobs per layer
+  for (int net = 1; net <= 2; ++net) {  // PackJob tables: <= 8 jobs per layer (+ 8 for each of the three up-conv decoder levels: inside the slack)
     const size_t nl = net == NET_GEN ? P->gen.size() : P->rec.size();
     P->jobs_off[net] = off;
-    off = align64(off + 8 * nl * (sizeof(PackJob) / sizeof(float)) + 64);
+    off = align64(off + (8 * nl + 32) * (sizeof(PackJob) / sizeof(float)) + 64);
   }
   P->arena_floats = off;
   // UDET_SERIAL=1 (read once, here; documented in include/udet.h next to udet_plan_set_concurrent): every lane collapses onto
