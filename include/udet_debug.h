@@ -20,6 +20,9 @@ void udet_debug_conv_fp16(int on);
 /* filter gradient: nsplit > 0 pins the number of pixel slices (clamped to the workspace capacity), dma = 0 / 1 / 2 the staging variant
  * (register-staged / LDS-DMA with a 2- / 3-stage ring; -1: as tuned); nsplit = 0 restores the tuned / heuristic choice */
 void udet_debug_force_wgrad(int nsplit, int dma);
+/* plans created after this call: the recover decoder's backward-data pass takes the low-resolution ("up-conv algebra") form on every
+ * level whose source has at least `v` pixels (batch included); v < 0 restores the default of 8192.  Tests use 0 on small plans. */
+void udet_debug_upb_min_pixels(long v);
 void udet_debug_set_tuning(int on);
 /* what the most recent convolution launch actually ran: family (0 plain, 1 wave-specialised, 2 LDS-DMA, 3 tile-resident,
  * 6 self-staging LDS-DMA, 7 / 8 direct kernel for two input / two output channels) | tile rows << 8 | split count << 20 | folded split-K << 28 */

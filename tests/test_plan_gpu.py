@@ -26,13 +26,20 @@ class Cfg(O.Flags):
     img_height, img_width, batch_size = 64, 128, 2
 
 
-@pytest.fixture(scope="module")
-def env():
+# "decoder-lowres-backward": the recover decoder's low-resolution ("up-conv algebra") form for the backward-data pass of levels 1-3 as
+# well -- a plan of this size would take it for the forward pass only (plan_build.hip: too few source pixels to be worth it)
+@pytest.fixture(scope="module", params=["default", "decoder-lowres-backward"])
+def env(request):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from unsupervised_detection_amd import weights as W
+    from unsupervised_detection_amd._devel import dbg
     from unsupervised_detection_amd.engine import Engine, EngineConfig
-    eng = Engine(EngineConfig(batch_size=2, in_height=128, in_width=192, img_height=64, img_width=128))
+    dbg.udet_debug_upb_min_pixels(0 if request.param == "decoder-lowres-backward" else -1)
+    try:
+        eng = Engine(EngineConfig(batch_size=2, in_height=128, in_width=192, img_height=64, img_width=128))
+    finally:
+        dbg.udet_debug_upb_min_pixels(-1)
     pp, pg, pr = _perturbed(O.pwc_param_specs(), 11), _perturbed(O.generator_param_specs(), 12), _perturbed(O.recover_param_specs(), 13)
     flat = {"pwc": W.from_dict(pp, W.NET_PWC).cuda(), "gen": W.from_dict(pg, W.NET_GEN).cuda(), "rec": W.from_dict(pr, W.NET_REC).cuda()}
     eng.pack_pwc(flat["pwc"])

@@ -20,5 +20,7 @@ dbg.udet_debug_conv_fp16.restype = None
 dbg.udet_debug_conv_fp16.argtypes = [ctypes.c_int]
 dbg.udet_debug_force_wgrad.restype = None
 dbg.udet_debug_force_wgrad.argtypes = [ctypes.c_int, ctypes.c_int]
+dbg.udet_debug_upb_min_pixels.restype = None
+dbg.udet_debug_upb_min_pixels.argtypes = [ctypes.c_long]
 dbg.udet_debug_set_tuning.restype = None
 dbg.udet_debug_set_tuning.argtypes = [ctypes.c_int]

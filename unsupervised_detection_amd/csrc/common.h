@@ -91,6 +91,15 @@ inline FastDiv make_fastdiv(unsigned d) {
 }
 __device__ __forceinline__ unsigned fdiv(unsigned n, const FastDiv& f) { return f.d == 1 ? n : (__umulhi(n, f.mul) >> f.sh); }
 
+// One segment of a segmented launch (ConvParams::nseg): a sub-grid of the output with its own tap list
+struct ConvSeg {
+  int oy, ox;   // output pixel of the segment's quotient pixel (0, 0)
+  int h, w;     // quotient pixels; pixel (qy, qx) writes (oy + qy * osy, ox + qx * osx)
+  int prow0;    // row of the segment's first pixel in the launch's flat row space (split-K slabs); filled by launch_conv
+  FastDiv fd_hw, fd_w;  // filled by launch_conv
+};
+#define UDET_MAX_SEGS 16
+
 struct ConvParams {
   // A operand (input activations / output-gradients), NHWC with channel stride ldx
   const float* x;
@@ -118,6 +127,16 @@ struct ConvParams {
   // (ooy,oox) as given.
   int ncls;
   int cls_tap[5];
+  // Segmented launch (nseg > 0): instead of the parity classes of ONE quotient grid the launch covers nseg <= 16 output sub-grids, each
+  // with its own taps [seg_tap[s], seg_tap[s + 1]) of the DEVICE table tap_tab (offsets relative to the segment's own quotient pixels;
+  // widx may address several weight sets laid out back to back behind wp).  Inside the kernels a segment is handled exactly like a
+  // class; isy / osy are shared.  Only the implicit-GEMM families take such launches (the recover decoder's up-conv algebra, plan_exec.hip:
+  // interior / last row / last column / corner of the output in one launch).  ncls, OHq, OWq, ooy, oox, taps[] are unused.
+  int nseg;
+  ConvSeg seg[UDET_MAX_SEGS];
+  int seg_tap[UDET_MAX_SEGS + 1];
+  const ConvTap* tap_tab;
+  int Mall;               // rows of the launch's flat row space: ncls * N * OHq * OWq, or the sum over the segments; filled by launch_conv
   FastDiv fd_ohw, fd_ow;  // filled by launch_conv
   int kfast;              // LDS-DMA kernels: stages never straddle taps (no up-sampled read; bit 0: Kc >= 32, 32-wide stages, bit 1: Kc >= 16,
                           // 16-wide stages): wave-uniform K cursor; filled by launch_conv

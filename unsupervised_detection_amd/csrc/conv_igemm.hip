@@ -99,6 +99,69 @@ __device__ __forceinline__ float* xpose_scratch(float* a, float* b, int wave) {
   else return nullptr;
 }
 
+// The class (or segment, ConvParams::nseg) an x-block belongs to and that block's place in it
+struct TileCls {
+  int cls, m0, Mtot, OHWq, OWq, ooy, oox, tap0, ntc, prow0;
+  FastDiv fd_ohw, fd_ow;
+};
+template <int BM>
+__device__ __forceinline__ TileCls tile_cls(const ConvParams& p, int bid) {
+  TileCls t;
+  if (p.nseg == 0) {
+    t.OHWq = p.OHq * p.OWq; t.OWq = p.OWq;
+    t.Mtot = p.N * t.OHWq;
+    const int mtiles = (t.Mtot + BM - 1) / BM;
+    t.cls = bid / mtiles;
+    t.m0 = (bid - t.cls * mtiles) * BM;
+    t.tap0 = p.cls_tap[t.cls];
+    t.ntc = p.cls_tap[t.cls + 1] - t.tap0;
+    t.ooy = p.ncls > 1 ? (t.cls >> 1) : p.ooy; t.oox = p.ncls > 1 ? (t.cls & 1) : p.oox;
+    t.prow0 = t.cls * t.Mtot;
+    t.fd_ohw = p.fd_ohw; t.fd_ow = p.fd_ow;
+    return t;
+  }
+  int s = 0, b = bid;
+  for (; s < p.nseg - 1; ++s) {
+    const int mt = (p.N * p.seg[s].h * p.seg[s].w + BM - 1) / BM;
+    if (b < mt) break;
+    b -= mt;
+  }
+  const ConvSeg& g = p.seg[s];
+  t.cls = s;
+  t.OHWq = g.h * g.w; t.OWq = g.w;
+  t.Mtot = p.N * t.OHWq;
+  t.m0 = b * BM;
+  t.tap0 = p.seg_tap[s];
+  t.ntc = p.seg_tap[s + 1] - t.tap0;
+  t.ooy = g.oy; t.oox = g.ox;
+  t.prow0 = g.prow0;
+  t.fd_ohw = g.fd_hw; t.fd_ow = g.fd_w;
+  return t;
+}
+__device__ __forceinline__ ConvTap conv_tap(const ConvParams& p, int i) { return p.nseg ? p.tap_tab[i] : p.taps[i]; }
+// output pixel offset of row `ma` of the launch's flat row space (split-K second pass)
+__device__ __forceinline__ int row_pixel_off(const ConvParams& p, int ma) {
+  int m, OHWq, OWq, ooy, oox;
+  FastDiv fa, fb;
+  if (p.nseg == 0) {
+    OHWq = p.OHq * p.OWq; OWq = p.OWq;
+    const int Mtot = p.N * OHWq, cls = ma / Mtot;
+    m = ma - cls * Mtot;
+    ooy = p.ncls > 1 ? (cls >> 1) : p.ooy; oox = p.ncls > 1 ? (cls & 1) : p.oox;
+    fa = p.fd_ohw; fb = p.fd_ow;
+  } else {
+    int s = 0;
+    while (s < p.nseg - 1 && ma >= p.seg[s + 1].prow0) ++s;
+    const ConvSeg& g = p.seg[s];
+    m = ma - g.prow0;
+    OHWq = g.h * g.w; OWq = g.w; ooy = g.oy; oox = g.ox;
+    fa = g.fd_hw; fb = g.fd_w;
+  }
+  const int nb = (int)fdiv(m, fa), rem = m - nb * OHWq;
+  const int qy = (int)fdiv(rem, fb), qx = rem - qy * OWq;
+  return (nb * p.OH + qy * p.osy + ooy) * p.OW + qx * p.osx + oox;
+}
+
 // Result of one workgroup: plain launches run the epilogue; split-K launches store the partial tile into slab blockIdx.z
 // (row index = parity class * Mtot + pixel).
 // The MFMA accumulator holds COLUMN n = lane of 8+8 rows, so a direct store is one dword per lane and (bias, activation, 64-bit
@@ -193,7 +256,7 @@ __device__ __forceinline__ void splitk_fold(const ConvParams& p, const int* rowo
   if (!*s_last) return;
   constexpr int C4 = BN / 4, ROWS = NT / C4;
   const int c4 = t % C4, n = n0 + c4 * 4;
-  const size_t slab = (size_t)p.ncls * Mtot * p.ldp;
+  const size_t slab = (size_t)p.Mall * p.ldp;
   if (n < p.ldp && t < ROWS * C4) {  // (BN = 96: 240 of the 256 threads tile the [ROWS][C4] grid exactly)
     for (int row = t / C4; row < BM; row += ROWS) {
       const int off = rowoff[row];
@@ -263,28 +326,23 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 2) void conv_igemm_kernel(
     const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int OHWq = p.OHq * p.OWq;
-  const int Mtot = p.N * OHWq;  // per class
-  const int mtiles = (Mtot + BM - 1) / BM;
-  const int cls = bid / mtiles;
-  const int m0 = (bid - cls * mtiles) * BM;
+  const TileCls tc = tile_cls<BM>(p, bid);
+  const int OHWq = tc.OHWq, Mtot = tc.Mtot /* of this class / segment */, m0 = tc.m0, tap0 = tc.tap0, ntc = tc.ntc, ooy = tc.ooy, oox = tc.oox;
   const int n0 = blockIdx.y * BN;
-  const int tap0 = p.cls_tap[cls];
-  const int ntc = p.cls_tap[cls + 1] - tap0;
-  const int ooy = p.ncls > 1 ? (cls >> 1) : p.ooy, oox = p.ncls > 1 ? (cls & 1) : p.oox;
   const int Hs = p.H >> p.up_shift, Ws = p.W >> p.up_shift;
 
   // ---- per-block tables -----------------------------------------------------
   for (int i = tid; i < ntc; i += NT) {
-    tap_yx[i] = make_int2(p.taps[tap0 + i].dy, p.taps[tap0 + i].dx);
-    tap_w[i] = p.taps[tap0 + i].widx;
+    const ConvTap tp = conv_tap(p, tap0 + i);
+    tap_yx[i] = make_int2(tp.dy, tp.dx);
+    tap_w[i] = tp.widx;
   }
   for (int r = tid; r < BM; r += NT) {
     const int m = m0 + r;
     int off = -1;
     if (m < Mtot) {
-      const int n = (int)fdiv(m, p.fd_ohw), rem = m - n * OHWq;
-      const int qy = (int)fdiv(rem, p.fd_ow), qx = rem - qy * p.OWq;
+      const int n = (int)fdiv(m, tc.fd_ohw), rem = m - n * OHWq;
+      const int qy = (int)fdiv(rem, tc.fd_ow), qx = rem - qy * tc.OWq;
       off = (n * p.OH + qy * p.osy + ooy) * p.OW + qx * p.osx + oox;
     }
     rowoff[r] = off;
@@ -296,8 +354,8 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 2) void conv_igemm_kernel(
     const int r = t / KQ + j * A_ROWS;
     const int m = m0 + r;
     if (m < Mtot) {
-      const int n = (int)fdiv(m, p.fd_ohw), rem = m - n * OHWq;
-      const int qy = (int)fdiv(rem, p.fd_ow), qx = rem - qy * p.OWq;
+      const int n = (int)fdiv(m, tc.fd_ohw), rem = m - n * OHWq;
+      const int qy = (int)fdiv(rem, tc.fd_ow), qx = rem - qy * tc.OWq;
       a_base[j] = n * Hs * Ws;
       a_iy0[j] = qy * p.isy;
       a_ix0[j] = qx * p.isx;
@@ -466,9 +524,9 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 2) void conv_igemm_kernel(
   }
 
   // ---- epilogue -------------------------------------------------------------
-  igemm_store<TM, TN, WTM, WTN>(p, acc, rowoff, wm, wn, li, lh, n0, cls * Mtot + m0, Mtot, p.ksplit > 1,
-                                (long)blockIdx.z * p.ncls * Mtot * p.ldp, xpose_scratch<sizeof(As), sizeof(Bs)>(&As[0][0][0], &Bs[0][0][0], wave));
-  if (p.ksplit > 1 && p.fold) splitk_fold<BM, BN, 256>(p, rowoff, &s_last, t, n0, cls * Mtot + m0, Mtot, blockIdx.y * gridDim.x + bid);
+  igemm_store<TM, TN, WTM, WTN>(p, acc, rowoff, wm, wn, li, lh, n0, tc.prow0 + m0, Mtot, p.ksplit > 1,
+                                (long)blockIdx.z * p.Mall * p.ldp, xpose_scratch<sizeof(As), sizeof(Bs)>(&As[0][0][0], &Bs[0][0][0], wave));
+  if (p.ksplit > 1 && p.fold) splitk_fold<BM, BN, 256>(p, rowoff, &s_last, t, n0, tc.prow0 + m0, Mtot, blockIdx.y * gridDim.x + bid);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -527,27 +585,22 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void conv_igemm_dma_kernel(co
       bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
   }
-  const int OHWq = p.OHq * p.OWq;
-  const int Mtot = p.N * OHWq;
-  const int mtiles = (Mtot + BM - 1) / BM;
-  const int cls = bid / mtiles;
-  const int m0 = (bid - cls * mtiles) * BM;
+  const TileCls tc = tile_cls<BM>(p, bid);
+  const int OHWq = tc.OHWq, Mtot = tc.Mtot /* of this class / segment */, m0 = tc.m0, tap0 = tc.tap0, ntc = tc.ntc, ooy = tc.ooy, oox = tc.oox;
   const int n0 = blockIdx.y * BN;
-  const int tap0 = p.cls_tap[cls];
-  const int ntc = p.cls_tap[cls + 1] - tap0;
-  const int ooy = p.ncls > 1 ? (cls >> 1) : p.ooy, oox = p.ncls > 1 ? (cls & 1) : p.oox;
   const int Hs = p.H >> p.up_shift, Ws = p.W >> p.up_shift;
 
   for (int i = tid; i < ntc; i += 512) {
-    tap_yx[i] = make_int2(p.taps[tap0 + i].dy, p.taps[tap0 + i].dx);
-    tap_w[i] = p.taps[tap0 + i].widx;
+    const ConvTap tp = conv_tap(p, tap0 + i);
+    tap_yx[i] = make_int2(tp.dy, tp.dx);
+    tap_w[i] = tp.widx;
   }
   for (int r = tid; r < BM; r += 512) {
     const int m = m0 + r;
     int off = -1;
     if (m < Mtot) {
-      const int n = (int)fdiv(m, p.fd_ohw), rem = m - n * OHWq;
-      const int qy = (int)fdiv(rem, p.fd_ow), qx = rem - qy * p.OWq;
+      const int n = (int)fdiv(m, tc.fd_ohw), rem = m - n * OHWq;
+      const int qy = (int)fdiv(rem, tc.fd_ow), qx = rem - qy * tc.OWq;
       off = (n * p.OH + qy * p.osy + ooy) * p.OW + qx * p.osx + oox;
     }
     rowoff[r] = off;
@@ -564,7 +617,7 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void conv_igemm_dma_kernel(co
     c_end = (int)((long)nchunks * (kz + 1) / knz);
   }
   // slab of this slice: regular split-K keeps whole-output slabs, the tail split only the rows from tail_prow0 on
-  const long slab_off = p.tail_ks > 1 ? ((long)kz * (p.ncls * Mtot - p.tail_prow0) - p.tail_prow0) * p.ldp : (long)kz * p.ncls * Mtot * p.ldp;
+  const long slab_off = p.tail_ks > 1 ? ((long)kz * (p.Mall - p.tail_prow0) - p.tail_prow0) * p.ldp : (long)kz * p.Mall * p.ldp;
   __syncthreads();
 
   if (role == 1) {
@@ -579,8 +632,8 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void conv_igemm_dma_kernel(co
     for (int j = 0; j < A_LD; ++j) {
       const int m = m0 + j * 32 + wave * 8 + (lane >> 3);
       if (m < Mtot) {
-        const int n = (int)fdiv(m, p.fd_ohw), rem = m - n * OHWq;
-        const int qy = (int)fdiv(rem, p.fd_ow), qx = rem - qy * p.OWq;
+        const int n = (int)fdiv(m, tc.fd_ohw), rem = m - n * OHWq;
+        const int qy = (int)fdiv(rem, tc.fd_ow), qx = rem - qy * tc.OWq;
         a_base[j] = n * Hs * Ws;
         a_iy0[j] = qy * p.isy;
         a_ix0[j] = qx * p.isx;
@@ -809,9 +862,9 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void conv_igemm_dma_kernel(co
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv;
   }
-  igemm_store<TM, TN, WTM, WTN>(p, acc, rowoff, wm, wn, li, lh, n0, cls * Mtot + m0, Mtot, knz > 1, slab_off,
+  igemm_store<TM, TN, WTM, WTN>(p, acc, rowoff, wm, wn, li, lh, n0, tc.prow0 + m0, Mtot, knz > 1, slab_off,
                                 xpose_scratch<sizeof(As), sizeof(Bs)>(&As[0][0][0], &Bs[0][0][0], wave));
-  if (p.ksplit > 1 && p.fold) splitk_fold<BM, BN, 256>(p, rowoff, &s_last, t, n0, cls * Mtot + m0, Mtot, blockIdx.y * gridDim.x + bid);
+  if (p.ksplit > 1 && p.fold) splitk_fold<BM, BN, 256>(p, rowoff, &s_last, t, n0, tc.prow0 + m0, Mtot, blockIdx.y * gridDim.x + bid);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -854,27 +907,22 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_dma4_kernel(const ConvParam
     const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int OHWq = p.OHq * p.OWq;
-  const int Mtot = p.N * OHWq;
-  const int mtiles = (Mtot + BM - 1) / BM;
-  const int cls = bid / mtiles;
-  const int m0 = (bid - cls * mtiles) * BM;
+  const TileCls tc = tile_cls<BM>(p, bid);
+  const int OHWq = tc.OHWq, Mtot = tc.Mtot /* of this class / segment */, m0 = tc.m0, tap0 = tc.tap0, ntc = tc.ntc, ooy = tc.ooy, oox = tc.oox;
   const int n0 = blockIdx.y * BN;
-  const int tap0 = p.cls_tap[cls];
-  const int ntc = p.cls_tap[cls + 1] - tap0;
-  const int ooy = p.ncls > 1 ? (cls >> 1) : p.ooy, oox = p.ncls > 1 ? (cls & 1) : p.oox;
   const int Hs = p.H >> p.up_shift, Ws = p.W >> p.up_shift;
 
   for (int i = t; i < ntc; i += 256) {
-    tap_yx[i] = make_int2(p.taps[tap0 + i].dy, p.taps[tap0 + i].dx);
-    tap_w[i] = p.taps[tap0 + i].widx;
+    const ConvTap tp = conv_tap(p, tap0 + i);
+    tap_yx[i] = make_int2(tp.dy, tp.dx);
+    tap_w[i] = tp.widx;
   }
   for (int r = t; r < BM; r += 256) {
     const int m = m0 + r;
     int off = -1;
     if (m < Mtot) {
-      const int n = (int)fdiv(m, p.fd_ohw), rem = m - n * OHWq;
-      const int qy = (int)fdiv(rem, p.fd_ow), qx = rem - qy * p.OWq;
+      const int n = (int)fdiv(m, tc.fd_ohw), rem = m - n * OHWq;
+      const int qy = (int)fdiv(rem, tc.fd_ow), qx = rem - qy * tc.OWq;
       off = (n * p.OH + qy * p.osy + ooy) * p.OW + qx * p.osx + oox;
     }
     rowoff[r] = off;
@@ -898,8 +946,8 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_dma4_kernel(const ConvParam
   for (int j = 0; j < A_LD; ++j) {
     const int m = m0 + j * 64 + wave * 16 + (lane >> 2);
     if (m < Mtot) {
-      const int n = (int)fdiv(m, p.fd_ohw), rem = m - n * OHWq;
-      const int qy = (int)fdiv(rem, p.fd_ow), qx = rem - qy * p.OWq;
+      const int n = (int)fdiv(m, tc.fd_ohw), rem = m - n * OHWq;
+      const int qy = (int)fdiv(rem, tc.fd_ow), qx = rem - qy * tc.OWq;
       a_base[j] = n * Hs * Ws;
       a_iy0[j] = qy * p.isy;
       a_ix0[j] = qx * p.isx;
@@ -1071,18 +1119,16 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_dma4_kernel(const ConvParam
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv;
   }
-  igemm_store<TM, TN, WTM, WTN>(p, acc, rowoff, wm, wn, li, lh, n0, cls * Mtot + m0, Mtot, p.ksplit > 1,
-                                (long)blockIdx.z * p.ncls * Mtot * p.ldp, xpose_scratch<sizeof(As), sizeof(Bs)>(&As[0][0][0], &Bs[0][0][0], wave));
-  if (p.ksplit > 1 && p.fold) splitk_fold<BM, BN, 256>(p, rowoff, &s_last, t, n0, cls * Mtot + m0, Mtot, blockIdx.y * gridDim.x + bid);
+  igemm_store<TM, TN, WTM, WTN>(p, acc, rowoff, wm, wn, li, lh, n0, tc.prow0 + m0, Mtot, p.ksplit > 1,
+                                (long)blockIdx.z * p.Mall * p.ldp, xpose_scratch<sizeof(As), sizeof(Bs)>(&As[0][0][0], &Bs[0][0][0], wave));
+  if (p.ksplit > 1 && p.fold) splitk_fold<BM, BN, 256>(p, rowoff, &s_last, t, n0, tc.prow0 + m0, Mtot, blockIdx.y * gridDim.x + bid);
 }
 
 // second pass of a split-K launch: sum the partial slabs and run the epilogue.  SL lanes share one output element
 // (each sums every SL-th slab, then a fixed-order shuffle tree): small outputs with many splits stay parallel.
 template <int SL>
 __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const ConvParams p) {
-  const int OHWq = p.OHq * p.OWq;
-  const int Mtot = p.N * OHWq;
-  const int Mall = p.ncls * Mtot;
+  const int Mall = p.Mall;
   const long total = (long)Mall * p.Cout;
   const int sl = threadIdx.x % SL;
   for (long e = ((long)blockIdx.x * 256 + threadIdx.x) / SL; e < total; e += (long)gridDim.x * (256 / SL)) {
@@ -1105,11 +1151,7 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const ConvPar
 #pragma unroll
     for (int d = SL / 2; d > 0; d >>= 1) v += __shfl_xor(v, d, SL);
     if (sl != 0) continue;
-    const int cls = ma / Mtot, m = ma - cls * Mtot;
-    const int ooy = p.ncls > 1 ? (cls >> 1) : p.ooy, oox = p.ncls > 1 ? (cls & 1) : p.oox;
-    const int nb = (int)fdiv(m, p.fd_ohw), rem = m - nb * OHWq;
-    const int qy = (int)fdiv(rem, p.fd_ow), qx = rem - qy * p.OWq;
-    const int off = (nb * p.OH + qy * p.osy + ooy) * p.OW + qx * p.osx + oox;
+    const int off = row_pixel_off(p, ma);
     conv_epilogue(p, off, n, v);
   }
 }
@@ -1117,9 +1159,7 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(const ConvPar
 // the one-lane-per-element form with four consecutive channels per thread: 16-byte slab loads (a quarter of the load instructions
 // and address arithmetic per byte), the same per-element summation order as conv_splitk_epilogue_kernel<1>
 __global__ __launch_bounds__(256) void conv_splitk_epilogue4_kernel(const ConvParams p) {
-  const int OHWq = p.OHq * p.OWq;
-  const int Mtot = p.N * OHWq;
-  const int Mall = p.ncls * Mtot;
+  const int Mall = p.Mall;
   const int nq = p.ldp >> 2;  // quads per partial row (ldp = Cout rounded up to 4)
   const int row0 = p.tail_ks > 1 ? p.tail_prow0 : 0, ksplit = p.tail_ks > 1 ? p.tail_ks : p.ksplit;  // tail split: rows >= tail_prow0 only
   const long total = (long)(Mall - row0) * nq;
@@ -1144,11 +1184,7 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue4_kernel(const ConvPa
       const float4 a0 = *reinterpret_cast<const float4*>(src + (size_t)s * slab);
       v.x += a0.x; v.y += a0.y; v.z += a0.z; v.w += a0.w;
     }
-    const int cls = ma / Mtot, m = ma - cls * Mtot;
-    const int ooy = p.ncls > 1 ? (cls >> 1) : p.ooy, oox = p.ncls > 1 ? (cls & 1) : p.oox;
-    const int nb = (int)fdiv(m, p.fd_ohw), rem = m - nb * OHWq;
-    const int qy = (int)fdiv(rem, p.fd_ow), qx = rem - qy * p.OWq;
-    const int off = (nb * p.OH + qy * p.osy + ooy) * p.OW + qx * p.osx + oox;
+    const int off = row_pixel_off(p, ma);
     if (vec) {  // (Cout a multiple of 4: whole quads)
       if (n < p.Cout) conv_epilogue4(p, off, n, v);
       continue;
@@ -1160,10 +1196,17 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue4_kernel(const ConvPa
   }
 }
 
+// x-blocks of a launch: M tiles of every class / segment
+static int conv_xblocks(const ConvParams& p, int bm) {
+  if (p.nseg == 0) return p.ncls * ((p.N * p.OHq * p.OWq + bm - 1) / bm);
+  int x = 0;
+  for (int s = 0; s < p.nseg; ++s) x += (p.N * p.seg[s].h * p.seg[s].w + bm - 1) / bm;
+  return x;
+}
+
 // second pass of a split-K launch (no tail split, not folded): sums the ksplit slabs of p.partial and runs the epilogue
 int launch_splitk_second_pass(const ConvParams& p, hipStream_t stream) {
-  const int Mtot = p.N * p.OHq * p.OWq;
-  const long total = (long)p.ncls * Mtot * p.Cout;
+  const long total = (long)p.Mall * p.Cout;
   // lanes per element: keep >= ~64k threads busy while the split count allows it
   const int sl = (p.ksplit >= 16 && total * 16 <= 262144) ? 16 : ((p.ksplit >= 4 && total * 4 <= 262144) ? 4 : 1);
   long nbl = (total * sl + 255) / 256;
@@ -1171,7 +1214,7 @@ int launch_splitk_second_pass(const ConvParams& p, hipStream_t stream) {
   if (sl == 16) UDET_LAUNCH(conv_splitk_epilogue_kernel<16>, dim3(nb), dim3(256), 0, stream, p);
   else if (sl == 4) UDET_LAUNCH(conv_splitk_epilogue_kernel<4>, dim3(nb), dim3(256), 0, stream, p);
   else if (p.ldp % 4 == 0 && !(reinterpret_cast<uintptr_t>(p.partial) & 15)) {
-    const long nb4l = ((long)p.ncls * Mtot * (p.ldp >> 2) + 255) / 256;
+    const long nb4l = ((long)p.Mall * (p.ldp >> 2) + 255) / 256;
     UDET_LAUNCH(conv_splitk_epilogue4_kernel, dim3((int)(nb4l > 4096 ? 4096 : nb4l)), dim3(256), 0, stream, p);
   } else UDET_LAUNCH(conv_splitk_epilogue_kernel<1>, dim3(nb), dim3(256), 0, stream, p);
   UDET_HIP(hipGetLastError());
@@ -1195,8 +1238,8 @@ void conv_force_config(int bm, int bn, int ks) {
 
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
 static int launch_cfg(ConvParams& p, int ws, hipStream_t stream) {
-  const int Mtot = p.N * p.OHq * p.OWq;
-  dim3 grid(p.ncls * ((Mtot + BM - 1) / BM), (p.Cout + BN - 1) / BN, p.ksplit > 1 ? p.ksplit : 1);
+  const int Mtot = p.N * p.OHq * p.OWq;  // (tail split: unsegmented launches only, run_cfg)
+  dim3 grid(conv_xblocks(p, BM), (p.Cout + BN - 1) / BN, p.ksplit > 1 ? p.ksplit : 1);
   if (p.tail_ks > 1) {  // tail split (run_cfg checked the kernel family, the slab capacity and the alignment)
     const int mtiles = (Mtot + BM - 1) / BM;
     p.tail_prow0 = (p.tail_full / mtiles) * Mtot + (p.tail_full % mtiles) * BM;
@@ -1227,7 +1270,7 @@ static int launch_cfg(ConvParams& p, int ws, hipStream_t stream) {
   else UDET_LAUNCH((conv_igemm_kernel<BM, BN, BK, WAVES_M, WAVES_N, false>), grid, dim3(256), 0, stream, p);
   UDET_HIP(hipGetLastError());
   if (p.tail_ks > 1) {
-    const long nb4l = ((long)(p.ncls * Mtot - p.tail_prow0) * (p.ldp >> 2) + 255) / 256;
+    const long nb4l = ((long)(p.Mall - p.tail_prow0) * (p.ldp >> 2) + 255) / 256;
     UDET_LAUNCH(conv_splitk_epilogue4_kernel, dim3((int)(nb4l > 4096 ? 4096 : nb4l)), dim3(256), 0, stream, p);
     UDET_HIP(hipGetLastError());
   } else if (p.ksplit > 1 && !p.fold) {
@@ -1240,11 +1283,12 @@ static int launch_cfg(ConvParams& p, int ws, hipStream_t stream) {
 struct ConvCfg { int bm, bn, ks, ws, fold, tail; };  // fold: split-K summed by the last-arriving workgroup (no second launch);
                                                     // tail > 0: x-blocks [0, tail) unsplit, the rest cut into ks slices (ConvParams::tail_full)
 static long cfg_tiles(const ConvParams& p, int bm, int bn) {
-  const int Mtot = p.N * p.OHq * p.OWq;
-  return (long)p.ncls * ((Mtot + bm - 1) / bm) * ((p.Cout + bn - 1) / bn);
+  return (long)conv_xblocks(p, bm) * ((p.Cout + bn - 1) / bn);
 }
 static int max_class_taps(const ConvParams& p) {
   int mx = 0;
+  for (int c = 0; c < p.nseg; ++c) mx = p.seg_tap[c + 1] - p.seg_tap[c] > mx ? p.seg_tap[c + 1] - p.seg_tap[c] : mx;
+  if (p.nseg) return mx;
   for (int c = 0; c < p.ncls; ++c) mx = p.cls_tap[c + 1] - p.cls_tap[c] > mx ? p.cls_tap[c + 1] - p.cls_tap[c] : mx;
   return mx;
 }
@@ -1252,7 +1296,7 @@ static int max_ksplit(const ConvParams& p) {  // capacity / minimum-work bound o
   if (!p.partial) return 1;
   const int nchunks = (max_class_taps(p) * p.Kc + 31) / 32;
   int ks = nchunks / 2 > 64 ? 64 : nchunks / 2;
-  const size_t per_split = (size_t)p.ncls * p.N * p.OHq * p.OWq * ((p.Cout + 3) & ~3);
+  const size_t per_split = (size_t)p.Mall * ((p.Cout + 3) & ~3);
   while (ks > 1 && per_split * ks > p.partial_cap) --ks;
   return ks < 1 ? 1 : ks;
 }
@@ -1260,6 +1304,7 @@ struct TileGeoms;
 size_t conv_tile_lds_bytes(const ConvParams& p, int th, int cbmax, TileGeoms* gout, bool* big);
 int launch_conv_tile(const ConvParams& p, int th, int cbmax, hipStream_t stream);
 static bool tile_ok(const ConvParams& p, int th, int cb = 32) {
+  if (p.nseg) return false;  // segmented launches: implicit-GEMM families only
   if (cb == 16 && p.Kc <= 16) return false;  // (the same launch as cb = 32)
   const size_t b = conv_tile_lds_bytes(p, th, cb, nullptr, nullptr);
   // (<= 256 columns: the kernel walks 32-column blocks as blockIdx.y and re-reads the halo per block -- thin inputs with wide outputs,
@@ -1273,6 +1318,7 @@ static bool dma_ok(const ConvParams& p) { return p.xa == nullptr && p.zero16 != 
 // tail split for workgroups filling r slots per CU: x-blocks of the whole rounds stay unsplit (*full_x of them), the rest is cut
 // into *ks slices so that it fills one more round.  false: the tile count is a whole number of rounds, or less than one.
 static bool tail_for_rounds(const ConvParams& p, int bm, int bn, int r, int kcap, int* full_x, int* ks) {
+  if (p.nseg) return false;
   const int Mtot = p.N * p.OHq * p.OWq, X = p.ncls * ((Mtot + bm - 1) / bm), Y = (p.Cout + bn - 1) / bn;
   const long S = 256L * r, T = (long)X * Y, fullT = T / S * S;
   if (fullT == 0 || fullT == T) return false;
@@ -1323,7 +1369,7 @@ static int run_cfg(ConvParams& p, const ConvCfg& c, hipStream_t stream) {
     p.ldp = (p.Cout + 3) & ~3;
     p.fold = c.fold && p.tickets && cfg_tiles(p, c.bm, c.bn) <= UDET_MAX_TICKETS;
     const int Mtot = p.N * p.OHq * p.OWq, mtiles = (Mtot + c.bm - 1) / c.bm, xb = p.ncls * mtiles;
-    if (c.tail > 0 && c.tail < xb && (c.ws == 2 || c.ws == 4 || c.ws == 5) && !(reinterpret_cast<uintptr_t>(p.partial) & 15)) {
+    if (c.tail > 0 && c.tail < xb && !p.nseg && (c.ws == 2 || c.ws == 4 || c.ws == 5) && !(reinterpret_cast<uintptr_t>(p.partial) & 15)) {
       const long prow0 = (long)(c.tail / mtiles) * Mtot + (long)(c.tail % mtiles) * c.bm;
       if ((size_t)((long)p.ncls * Mtot - prow0) * p.ldp * p.ksplit <= p.partial_cap) {
         p.tail_full = c.tail; p.tail_ks = p.ksplit; p.ksplit = 1; p.fold = 0;
@@ -1423,6 +1469,8 @@ static uint64_t conv_key(const ConvParams& p) {
                                                                                          // decides what the Winograd sub-lattices look like)
   uint64_t h = 1469598103934665603ull;
   for (int v : f) { h ^= (uint64_t)(uint32_t)v; h *= 1099511628211ull; }
+  for (int s = 0; s < p.nseg; ++s)  // segmented launches: the segment grids and their tap counts (ncls / OHq / OWq / taps[] are zero)
+    for (int v : {p.seg[s].oy, p.seg[s].ox, p.seg[s].h, p.seg[s].w, p.seg_tap[s + 1]}) { h ^= (uint64_t)(uint32_t)v; h *= 1099511628211ull; }
   return h;
 }
 static float time_cfg(ConvParams& p, const ConvCfg& c, int reps, hipStream_t stream) {
@@ -1435,6 +1483,8 @@ static float time_cfg(ConvParams& p, const ConvCfg& c, int reps, hipStream_t str
   if (hipEventSynchronize(e1) != hipSuccess) return 1e30f;
   float ms = 0.f;
   (void)hipEventElapsedTime(&ms, e0, e1);
+  static const float pen = getenv("UDET_TUNE_SPLIT_PENALTY") ? (float)atof(getenv("UDET_TUNE_SPLIT_PENALTY")) : 0.f;
+  if ((c.ks > 1 || c.tail > 0) && pen > 0.f) return ms / reps * (1.f + pen);
   return ms / reps;
 }
 static ConvCfg tune_cfg_impl(ConvParams& p, hipStream_t stream);
@@ -1631,10 +1681,33 @@ int launch_conv(ConvParams& p, hipStream_t stream) {
     set_error("conv: x / packed weights must be 16-byte aligned");
     return UDET_ERR_ALIGN;
   }
-  if (p.ncls != 4) {
-    p.ncls = 1;
-    p.cls_tap[0] = 0;
-    p.cls_tap[1] = p.ntaps;
+  if (p.nseg) {
+    if (p.nseg < 0 || p.nseg > UDET_MAX_SEGS || !p.tap_tab || p.up_shift || p.xa) {
+      set_error("conv: malformed segmented launch");
+      return UDET_ERR_ARG;
+    }
+    int prow = 0;
+    for (int s = 0; s < p.nseg; ++s) {
+      ConvSeg& g = p.seg[s];
+      if (g.h < 1 || g.w < 1 || p.seg_tap[s + 1] - p.seg_tap[s] > UDET_MAX_TAPS || p.seg_tap[s + 1] < p.seg_tap[s]) {
+        set_error("conv: segment %d is empty or has more than %d taps", s, UDET_MAX_TAPS);
+        return UDET_ERR_SHAPE;
+      }
+      g.prow0 = prow;
+      prow += p.N * g.h * g.w;
+      g.fd_hw = make_fastdiv((unsigned)(g.h * g.w));
+      g.fd_w = make_fastdiv((unsigned)g.w);
+    }
+    p.Mall = prow;
+    p.ncls = 1; p.ntaps = 0; p.cls_tap[0] = p.cls_tap[1] = 0;
+    p.OHq = p.seg[0].h; p.OWq = p.seg[0].w;  // (what the untuned heuristics and the log lines look at: the first, largest segment)
+  } else {
+    if (p.ncls != 4) {
+      p.ncls = 1;
+      p.cls_tap[0] = 0;
+      p.cls_tap[1] = p.ntaps;
+    }
+    p.Mall = p.ncls * p.N * p.OHq * p.OWq;
   }
   p.fd_ohw = make_fastdiv((unsigned)(p.OHq * p.OWq));
   p.fd_ow = make_fastdiv((unsigned)p.OWq);

@@ -135,6 +135,7 @@ static bool thin_n_pick(const ConvParams& p, int* th, ThinGeom* g) {
   return false;
 }
 bool conv_thin_n_ok(const ConvParams& p) {
+  if (p.nseg) return false;  // segmented launches: implicit-GEMM families only
   if (p.Cout > 2 || p.Cout < 1 || p.xa != nullptr || p.Kc % 4 || p.ldw < 2 || p.ntaps < 1 || p.isy != p.isx || p.isy < 1 || p.isy > 2) return false;
   ThinGeom g;
   int th;
@@ -217,6 +218,7 @@ __global__ __launch_bounds__(256) void conv_thin_k_kernel(const ConvParams p, co
 }
 
 bool conv_thin_k_ok(const ConvParams& p) {
+  if (p.nseg) return false;  // segmented launches: implicit-GEMM families only
   const int kr = p.kreal > 0 ? p.kreal : p.Kc;
   if (kr != 2 || p.Kc < 2 || p.ldx % 2 || p.x_coff % 2 || (reinterpret_cast<uintptr_t>(p.x) & 7)) return false;
   if (p.ncls == 4 || p.isy != 1 || p.isx != 1 || p.up_shift || p.xa != nullptr || p.ntaps < 1 || p.ntaps > 25 || p.Cout < 32) return false;

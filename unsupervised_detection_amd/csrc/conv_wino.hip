@@ -673,6 +673,7 @@ bool conv_wino_geometry(const ConvParams& p, int* dil, int widx_at[9]) {
   return true;
 }
 bool conv_wino_ok(const ConvParams& p) {
+  if (p.nseg) return false;  // segmented launches: implicit-GEMM families only
   int d, w[9];
   if (p.f16 || p.xa != nullptr || p.wino_u == nullptr || p.zero16 == nullptr) return false;
   if ((reinterpret_cast<uintptr_t>(p.zero16) | reinterpret_cast<uintptr_t>(p.wino_u) | reinterpret_cast<uintptr_t>(p.x)) & 15) return false;

@@ -7,7 +7,6 @@ int launch_resize_bilinear_bwd(const float* dy, int ldy, int y_coff, int N, int 
                                int H, int W, int C, int accumulate, hipStream_t s);
 int launch_upb_ring(const float* x, int ld, int N, int H, int W, float* xh, hipStream_t s);
 int launch_upb_ring_fold(const float* dxh, int ld, int N, int H, int W, float* dx, hipStream_t s);
-int launch_upb_extract(const float* du, int ldu, int N, int OH, int OW, int C, float* srow, float* scol, float* scor, hipStream_t s);
 int launch_share_samples(float* buf, long P, int ld, int coff, int C, int copies, hipStream_t s);
 int launch_fold_samples(float* buf, long P, int ld, int coff, int C, int copies, hipStream_t s);
 int launch_emit_du(const float* d, const float* a, float* u, long P, int ld, int coff, int C, int act, float alpha, hipStream_t s);

@@ -856,8 +856,7 @@ int launch_nonfinite_count(const float* g, long n, int* out, hipStream_t s) {
 //   x^[R][C] = sy(R) sx(C) x[clamp(R - 1)][clamp(C - 1)],  R in [0, H + 2), C in [0, W + 2),  s = -1 on ring row / column 0 (the zero
 //   padding of the up-sampled grid), +1 elsewhere (the clamp of the legacy resize at the bottom / right edge).
 // upb_ring: x -> x^.  upb_ring_fold: its adjoint, dx[j][i] = sum over the ring cells that read x[j][i] (written, not accumulated).
-// upb_extract: the last two rows / columns / the 2x2 corner of the full-resolution dU as small dense tensors (operands of the
-// backward-data correction launches).  float4 over channels.
+// float4 over channels.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void upb_ring_kernel(const float* __restrict__ x, int ldx, int N, int H, int W, float* __restrict__ xh, int C4) {
   const int PH = H + 2, PW = W + 2;
@@ -918,45 +917,6 @@ int launch_upb_ring_fold(const float* dxh, int ld, int N, int H, int W, float* d
   UDET_HIP(hipGetLastError());
   return UDET_OK;
 }
-// du [N][OH][OW] (channel stride ldu, channels [0, 4 C4)) -> srow [N][2][OW][4 C4], scol [N][OH][2][4 C4], scor [N][2][2][4 C4]
-__global__ __launch_bounds__(256) void upb_extract_kernel(const float* __restrict__ du, int ldu, int N, int OH, int OW, int C4,
-                                                          float* __restrict__ srow, float* __restrict__ scol, float* __restrict__ scor) {
-  const long nrow = (long)N * 2 * OW * C4, ncol = (long)N * OH * 2 * C4, ncor = (long)N * 4 * C4;
-  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < nrow + ncol + ncor; e += (long)gridDim.x * 256) {
-    long r = e;
-    float* dst;
-    int n, y, x, c4;
-    if (r < nrow) {
-      c4 = (int)(r % C4); r /= C4;
-      x = (int)(r % OW); r /= OW;
-      const int s = (int)(r % 2); n = (int)(r / 2);
-      y = OH - 2 + s;
-      dst = srow + (((long)n * 2 + s) * OW + x) * (C4 * 4) + c4 * 4;
-    } else if (r < nrow + ncol) {
-      r -= nrow;
-      c4 = (int)(r % C4); r /= C4;
-      const int s = (int)(r % 2); r /= 2;
-      y = (int)(r % OH); n = (int)(r / OH);
-      x = OW - 2 + s;
-      dst = scol + (((long)n * OH + y) * 2 + s) * (C4 * 4) + c4 * 4;
-    } else {
-      r -= nrow + ncol;
-      c4 = (int)(r % C4); r /= C4;
-      const int sx = (int)(r % 2); r /= 2;
-      const int sy = (int)(r % 2); n = (int)(r / 2);
-      y = OH - 2 + sy; x = OW - 2 + sx;
-      dst = scor + (((long)n * 2 + sy) * 2 + sx) * (C4 * 4) + c4 * 4;
-    }
-    *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(du + (((long)n * OH + y) * OW + x) * ldu + c4 * 4);
-  }
-}
-int launch_upb_extract(const float* du, int ldu, int N, int OH, int OW, int C, float* srow, float* scol, float* scor, hipStream_t s) {
-  const long total = (long)N * (2 * OW + 2 * OH + 4) * (C / 4);
-  hipLaunchKernelGGL(upb_extract_kernel, dim3(grid_for(total, 2048)), dim3(256), 0, s, du, ldu, N, OH, OW, C / 4, srow, scol, scor);
-  UDET_HIP(hipGetLastError());
-  return UDET_OK;
-}
-
 // y = a*x (+ y)   small helper for skip-gradients that need no conv
 __global__ __launch_bounds__(256) void axpy_kernel(const float* __restrict__ x, float* __restrict__ y, long n, float a,
                                                    int accumulate) {

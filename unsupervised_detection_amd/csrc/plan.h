@@ -56,11 +56,20 @@ struct Layer {
   size_t wino_off = 0, winoT_off = 0;
   int wino_np = 0, winoT_np = 0;
   // Recover decoder levels 1-3 ("up-conv algebra", plan_exec.hip): legacy bilinear x2 + 4x4 convolution as four 3x3 convolutions on the
-  // ringed low-resolution source `xhat`.  Forward weight sets per OUTPUT region {interior, last row, last column, corner}; backward-data
-  // sets {interior, (last - interior) rows, (last - interior) columns, both} (transposed)
+  // ringed low-resolution source `xhat`, ONE segmented launch per pass (ConvParams::nseg): weight sets {interior, last row, last column,
+  // corner} back to back (forward: wupb_off, backward-data: wupbT_off), segments and device tap tables built by plan_build
   bool upb = false;
+  bool upb_bwd = false;      // backward-data too (the deepest level has too few low-resolution pixels to fill the chip: forward only)
+  bool upb_split = false;    // forward: interior as an ordinary four-class launch + the border segments (see run_fwd_upb)
   int xhat = -1, src = -1;   // ringed source [N, h + 2, w + 2, ld] / the source it is built from
-  size_t wupb_off[4] = {0, 0, 0, 0}, wupbT_off[4] = {0, 0, 0, 0};
+  size_t wupb_off = 0, wupbT_off = 0;
+  struct SegLaunch {
+    int nseg = 0;
+    ConvSeg seg[UDET_MAX_SEGS];
+    int seg_tap[UDET_MAX_SEGS + 1];
+    std::vector<ConvTap> taps;
+    size_t tab_off = 0;  // device copy of `taps` (floats from the workspace base)
+  } upb_f, upb_b;
   // tensors
   int x = -1, x_coff = 0, y = -1, y_coff = 0;
   int res = -1, res_coff = 0, y2 = -1;
@@ -155,6 +164,7 @@ struct Plan {
 #define UDET_SMALL_OVF 300     // fp16_overflow: int[2 nets][2] = {non-finite values of the last apply, running total}
 #define UDET_SMALL_SUMS 1024   // loss_sums
 Plan* plan_build(const Config& cfg);
+void plan_debug_upb_min_pixels(long v);  // (libudet_debug)
 
 // execution (all asynchronous on `s`)
 int plan_init_workspace(Plan* P, float* ws, hipStream_t s);

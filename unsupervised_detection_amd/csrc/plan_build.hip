@@ -182,6 +182,73 @@ Plan::~Plan() {
   if (ovf_host) (void)hipHostFree(ovf_host);
 }
 
+// recover decoder's up-conv algebra: fewest low-resolution source pixels (batch included) of a level whose backward-data pass uses it
+// too (measured on the benchmark plan: 12 x 12 x 24 pixels lose to the up-sampled form -- too few tiles for the chip --, 12 x 24 x 48 win);
+// the tests set 0 so that small plans run the backward form on every level (udet_debug_upb_min_pixels)
+static long g_upb_bwd_min = 8192;
+void plan_debug_upb_min_pixels(long v) { g_upb_bwd_min = v < 0 ? 8192 : v; }
+
+// Segments and tap tables of the recover decoder's up-conv algebra for a low-resolution source of h x w (plan_exec.hip has the algebra).
+// Merge rows that are all zero in a variant (0 interior, 1 last row / column) carry no tap.
+static inline bool upb_used(int parity, int last, int a) { return !last || (parity == 0 ? a < 2 : a < 1); }
+static void build_upb_launches(Layer& L, int h, int w) {
+  // forward: 4 output regions {interior, last row, last column, corner} x 4 parity classes; class (py, px), merged tap (a, b) of the
+  // quotient pixel q reads x^[q + p + (a, b)] (ring coordinates) with weight set = region
+  Layer::SegLaunch& F = L.upb_f;
+  F.nseg = 0; F.taps.clear();
+  for (int r = 0; r < 4; ++r) {
+    const int rv = r & 1, cv = r >> 1;
+    const int r0 = rv ? h - 1 : 0, c0 = cv ? w - 1 : 0, nr = rv ? 1 : h - 1, nc = cv ? 1 : w - 1;
+    for (int c = 0; c < 4; ++c) {
+      const int py = c >> 1, px = c & 1;
+      ConvSeg& g = F.seg[F.nseg];
+      memset(&g, 0, sizeof(g));
+      g.oy = 2 * r0 + py; g.ox = 2 * c0 + px; g.h = nr; g.w = nc;
+      F.seg_tap[F.nseg++] = (int)F.taps.size();
+      for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) {
+          if (!upb_used(py, rv, a) || !upb_used(px, cv, b)) continue;
+          F.taps.push_back(ConvTap{r0 + a + py, c0 + b + px, r * 36 + 9 * c + 3 * a + b});
+        }
+    }
+  }
+  F.seg_tap[F.nseg] = (int)F.taps.size();
+  // backward-data: the ringed gradient x^[R] collects dU[2R - p - 2a] W~[class p][a]^T where the quotient pixel q = R - p - a exists;
+  // q == h - 1 takes the last-row set.  Rows split into {R < h - 1} (every q interior) and R = h - 1, h, h + 1 (a fixed mix per row);
+  // columns alike: 16 segments, each with its own (tap, weight set) list.
+  Layer::SegLaunch& B = L.upb_b;
+  B.nseg = 0; B.taps.clear();
+  struct Combo { int p, a, last; };
+  auto combos = [](int grp, std::vector<Combo>& out) {  // grp 0: R < n - 1; grp k: R = n - 2 + k
+    out.clear();
+    for (int p = 0; p < 2; ++p)
+      for (int a = 0; a < 3; ++a) {
+        int last = 0;
+        if (grp > 0) {
+          const int rp = grp - 1;  // q = n - 1 + rp - p - a
+          if (p + a < rp) continue;
+          last = (p + a == rp);
+        }
+        if (upb_used(p, last, a)) out.push_back(Combo{p, a, last});
+      }
+  };
+  std::vector<Combo> rc, cc;
+  for (int gr = 0; gr < 4; ++gr)
+    for (int gc = 0; gc < 4; ++gc) {
+      const int R0 = gr == 0 ? 0 : h - 2 + gr, C0 = gc == 0 ? 0 : w - 2 + gc;
+      ConvSeg& g = B.seg[B.nseg];
+      memset(&g, 0, sizeof(g));
+      g.oy = R0; g.ox = C0; g.h = gr == 0 ? h - 1 : 1; g.w = gc == 0 ? w - 1 : 1;
+      B.seg_tap[B.nseg++] = (int)B.taps.size();
+      combos(gr, rc);
+      combos(gc, cc);
+      for (const Combo& y : rc)
+        for (const Combo& x : cc)
+          B.taps.push_back(ConvTap{2 * R0 - y.p - 2 * y.a, 2 * C0 - x.p - 2 * x.a, (y.last + 2 * x.last) * 36 + 9 * (2 * y.p + x.p) + 3 * y.a + x.a});
+    }
+  B.seg_tap[B.nseg] = (int)B.taps.size();
+}
+
 Plan* plan_build(const Config& cfg) {
   if (cfg.batch > 16) {
     set_error("plan: batch %d > 16 per GPU is not laid out (reduction scratch); shard over more ranks", cfg.batch);
@@ -400,13 +467,12 @@ Plan* plan_build(const Config& cfg) {
         // 4x4 convolution over the up-sampled tensor (9 of 16 tap products; plan_exec.hip).  The filter gradient keeps the up-sampled form.
         if (k <= 3 && !cfg.conv_fp16 && hs[k] == 2 * hs[k + 1] && wsz[k] == 2 * wsz[k + 1] && hs[k + 1] >= 4 && wsz[k + 1] >= 4) {
           L.upb = true;
+          L.upb_bwd = (long)N * hs[k + 1] * wsz[k + 1] >= g_upb_bwd_min;
+          L.upb_split = d.cout <= 16;
           L.src = src;
           L.xhat = P->add_buf(S("rec.p%d", k + 1), N, hs[k + 1] + 2, wsz[k + 1] + 2, ldsrc);
           P->add_buf(S("rec.d.p%d", k + 1), N, hs[k + 1] + 2, wsz[k + 1] + 2, ldsrc);
-          const int kct = round_up(d.cout, 8);
-          P->add_buf(S("rec.d.sr%d", k), N, 2, wsz[k], kct);  // last two rows / columns / corner of dU (backward-data corrections)
-          P->add_buf(S("rec.d.sc%d", k), N, hs[k], 2, kct);
-          P->add_buf(S("rec.d.sx%d", k), N, 2, 2, kct);
+          build_upb_launches(L, hs[k + 1], wsz[k + 1]);
         }
         P->rec.push_back(L);
       }
@@ -482,11 +548,12 @@ Plan* plan_build(const Config& cfg) {
       L.wu_off = off; off = align64(off + (size_t)16 * L.Kc * L.ldw);
       L.wuT_off = off; off = align64(off + (size_t)16 * L.KcT * L.ldwT);
     }
-    if (L.upb)
-      for (int r = 0; r < 4; ++r) {
-        L.wupb_off[r] = off; off = align64(off + (size_t)36 * L.Kc * L.ldw);
-        L.wupbT_off[r] = off; off = align64(off + (size_t)36 * L.KcT * L.ldwT);
-      }
+    if (L.upb) {  // four weight sets back to back each way (a tap's widx = set * 36 + class * 9 + merged tap), the two tap tables
+      L.wupb_off = off; off = align64(off + (size_t)4 * 36 * L.Kc * L.ldw);
+      L.wupbT_off = off; off = align64(off + (size_t)4 * 36 * L.KcT * L.ldwT);
+      L.upb_f.tab_off = off; off = align64(off + L.upb_f.taps.size() * (sizeof(ConvTap) / sizeof(float)));
+      L.upb_b.tab_off = off; off = align64(off + L.upb_b.taps.size() * (sizeof(ConvTap) / sizeof(float)));
+    }
     // Winograd operands: 3x3 stride-1 layers whose K extent is whole 8-channel stages (the tuner decides per shape whether the family runs)
     if (L.kh == 3 && L.kw == 3 && L.stride == 1 && !L.up && !L.transposed && !L.col2im && L.cout >= 16 && L.H * L.W >= 512) {
       if (L.Kc % 8 == 0) {

@@ -202,48 +202,18 @@ static void setup_up_dgrad(ConvParams& p, int N, int H, int W) {
 // at a quarter of the size.  The borders are exact, not approximated: the source carries a one-pixel ring x^ (upb_ring_kernel) that is
 // the NEGATED edge at the top / left (the two halves of the merged even row 0 then cancel to the zero padding of the up-sampled grid)
 // and the CLAMPED edge at the bottom / right (the resize's clamp for row 2H-3); only the LAST low-resolution row / column merges
-// differently (rows 2H-2, 2H-1 see the clamp and the padding), so the output splits into four regions -- interior, last row, last
-// column, corner -- each a launch with its own weight set.  Class (py, px), tap (a, b) of output quotient q reads x^[q + p + (a, b)].
-// Backward-data: one launch with the interior weights over every output (a stride-2 walk over dU: x^[R] collects dU[2R - p - 2a]), three
-// thin launches that add (last - interior) weights on the last two rows / columns / the corner of dU (copied out as dense strips so
-// that the launch's height bound is also its batch stride), then the adjoint of the ring (upb_ring_fold) -- which replaces the resize
-// adjoint.  The filter gradient keeps the up-sampled operand.
+// differently (rows 2H-2, 2H-1 see the clamp and the padding).  Both passes are ONE segmented launch (ConvParams::nseg, 16 segments,
+// tables built by plan_build's build_upb_launches): forward = {interior, last row, last column, corner} x 4 parity classes, each
+// segment with the weight set of its region; backward-data = the ringed gradient x^[R] collects dU[2R - p - 2a] over the quotient
+// pixels q = R - p - a, with the last-row set where q is the last row -- a fixed mix per output row R >= H - 1, hence row groups
+// {R < H - 1}, H - 1, H, H + 1 times the same for columns -- followed by the adjoint of the ring (upb_ring_fold), which replaces the
+// resize adjoint.  The filter gradient keeps the up-sampled operand.
 // ------------------------------------------------------------------------------------------------------------------------------
-// merge rows that are all zero in a variant (0 interior, 1 last, 2 last - interior): their taps are not launched
-static inline bool upb_used(int parity, int var, int a) {
-  if (var == 1) return parity == 0 ? a < 2 : a < 1;
-  if (var == 2) return parity == 0 ? a > 0 : true;
-  return true;
-}
-static void setup_upb_fwd(ConvParams& p, int N, int h, int w, int r0, int c0, int nr, int nc, int rv, int cv) {
-  p.N = N; p.H = h + 2; p.W = w + 2;
-  p.OH = 2 * h; p.OW = 2 * w; p.OHq = nr; p.OWq = nc;
-  p.osy = p.osx = 2; p.ooy = p.oox = 0; p.isy = p.isx = 1;
-  p.ncls = 4; p.ntaps = 0;
-  for (int c = 0; c < 4; ++c) {
-    p.cls_tap[c] = p.ntaps;
-    for (int a = 0; a < 3; ++a)
-      for (int b = 0; b < 3; ++b) {
-        if (!upb_used(c >> 1, rv, a) || !upb_used(c & 1, cv, b)) continue;
-        ConvTap& tp = p.taps[p.ntaps++];
-        tp.dy = r0 + a + (c >> 1); tp.dx = c0 + b + (c & 1); tp.widx = 9 * c + 3 * a + b;
-      }
-  }
-  p.cls_tap[4] = p.ntaps;
-}
-// dU grid gh x gw (the full 2h x 2w tensor or a strip), output rows x cols of the ringed gradient
-static void setup_upb_dgrad(ConvParams& p, int N, int gh, int gw, int OH, int OW, int nr, int nc, int rv, int cv) {
-  p.N = N; p.H = gh; p.W = gw;
-  p.OH = OH; p.OW = OW; p.OHq = nr; p.OWq = nc;
-  p.osy = p.osx = 1; p.ooy = p.oox = 0; p.isy = p.isx = 2;
-  p.ncls = 1; p.ntaps = 0;
-  for (int c = 0; c < 4; ++c)
-    for (int a = 0; a < 3; ++a)
-      for (int b = 0; b < 3; ++b) {
-        if (!upb_used(c >> 1, rv, a) || !upb_used(c & 1, cv, b)) continue;
-        ConvTap& tp = p.taps[p.ntaps++];
-        tp.dy = -(c >> 1) - 2 * a; tp.dx = -(c & 1) - 2 * b; tp.widx = 9 * c + 3 * a + b;
-      }
+static void fill_segments(ConvParams& p, const Layer::SegLaunch& g, float* ws, int first = 0) {  // segments [first, nseg)
+  p.nseg = g.nseg - first;
+  memcpy(p.seg, g.seg + first, sizeof(ConvSeg) * p.nseg);
+  memcpy(p.seg_tap, g.seg_tap + first, sizeof(int) * (p.nseg + 1));  // (offsets into the whole table)
+  p.tap_tab = reinterpret_cast<const ConvTap*>(ws + g.tab_off);
 }
 
 // fp16 mode: gradient operands are multiplied by this power of two before the fp16 conversion (and the fp32 accumulators divided by it)
@@ -263,44 +233,55 @@ static int run_fwd_upb(Plan* P, const Layer& L, int N, float* ws, const Lane& ln
   const int h = bs.h, w = bs.w;
   prof_begin(P, PROF_CONV_FWD, layer_flops(L, N) * 9.0 / 16.0, 0, s, L.name.c_str());
   UDET_TRY(launch_upb_ring(ws + bs.off, bs.ld, N, h, w, ws + bp.off, s));
-  for (int r = 0; r < 4; ++r) {  // interior, last row, last column, corner
-    const int rv = r & 1, cv = r >> 1;
-    const int r0 = rv ? h - 1 : 0, c0 = cv ? w - 1 : 0, nr = rv ? 1 : h - 1, nc = cv ? 1 : w - 1;
-    ConvParams p;
-    memset(&p, 0, sizeof(p));
-    setup_upb_fwd(p, N, h, w, r0, c0, nr, nc, rv, cv);
-    p.x = ws + bp.off; p.ldx = bp.ld; p.x_coff = 0;
-    p.wp = ws + L.wupb_off[r]; p.Kc = L.Kc; p.ldw = L.ldw; p.bias = ws + L.bias_f_off;
-    p.y = ws + by.off + ((size_t)2 * r0 * p.OW + 2 * c0) * by.ld; p.ldy = by.ld; p.y_coff = L.y_coff; p.Cout = L.cout;
-    p.act = L.act; p.alpha = L.alpha;
-    fill_common(P, p, ws, ln.slot);
-    UDET_TRY(launch_conv(p, s));
+  ConvParams p;
+  memset(&p, 0, sizeof(p));
+  p.N = N; p.H = h + 2; p.W = w + 2;
+  p.OH = 2 * h; p.OW = 2 * w;
+  p.osy = p.osx = 2; p.isy = p.isx = 1;
+  p.x = ws + bp.off; p.ldx = bp.ld; p.x_coff = 0;
+  p.wp = ws + L.wupb_off; p.Kc = L.Kc; p.ldw = L.ldw; p.bias = ws + L.bias_f_off;
+  p.y = ws + by.off; p.ldy = by.ld; p.y_coff = L.y_coff; p.Cout = L.cout;
+  p.act = L.act; p.alpha = L.alpha;
+  fill_common(P, p, ws, ln.slot);
+  if (L.upb_split) {
+    // <= 16 output channels: the tile-resident kernel (conv_tile.hip) is the fast family and takes no segments -- the interior as an
+    // ordinary four-class launch (segments 0-3 of the table: weight set 0), the twelve border segments in a second, short launch
+    ConvParams q = p;
+    q.OHq = h - 1; q.OWq = w - 1;
+    q.ncls = 4;
+    for (int c = 0; c < 4; ++c) {
+      q.cls_tap[c] = q.ntaps;
+      for (int t = L.upb_f.seg_tap[c]; t < L.upb_f.seg_tap[c + 1]; ++t) q.taps[q.ntaps++] = L.upb_f.taps[t];
+    }
+    q.cls_tap[4] = q.ntaps;
+    UDET_TRY(launch_conv(q, s));
+    fill_segments(p, L.upb_f, ws, 4);
+  } else {
+    fill_segments(p, L.upb_f, ws);
   }
+  UDET_TRY(launch_conv(p, s));
   prof_end(P, s);
   return UDET_OK;
 }
 
 // gradient w.r.t. the low-resolution source of an upb level: dsrc (written) from dU (`du` buffer, channels [0, KcT))
-static int run_dgrad_upb(Plan* P, const Layer& L, int N, int du, int dxhat, int srow, int scol, int scor, int dsrc, float* ws, const Lane& ln) {
+static int run_dgrad_upb(Plan* P, const Layer& L, int N, int du, int dxhat, int dsrc, float* ws, const Lane& ln) {
   hipStream_t s = ln.s;
   const Buf &bu = P->buf(du), &bp = P->buf(dxhat), &bd = P->buf(dsrc);
-  const Buf &br = P->buf(srow), &bc = P->buf(scol), &bx = P->buf(scor);
-  const int h = bd.h, w = bd.w, PH = h + 2, PW = w + 2;
+  const int h = bd.h, w = bd.w;
   prof_begin(P, PROF_CONV_DGRAD, layer_flops(L, N) * 9.0 / 16.0, 0, s, L.name.c_str());
-  UDET_TRY(launch_upb_extract(ws + bu.off, bu.ld, N, 2 * h, 2 * w, L.KcT, ws + br.off, ws + bc.off, ws + bx.off, s));
-  for (int r = 0; r < 4; ++r) {  // everything with the interior weights, then the row / column / corner corrections
-    const int rv = (r & 1) ? 2 : 0, cv = (r >> 1) ? 2 : 0;
-    const Buf& in = r == 0 ? bu : (r == 1 ? br : (r == 2 ? bc : bx));
-    ConvParams p;
-    memset(&p, 0, sizeof(p));
-    setup_upb_dgrad(p, N, (r & 1) ? 2 : 2 * h, (r >> 1) ? 2 : 2 * w, PH, PW, (r & 1) ? 3 : PH, (r >> 1) ? 3 : PW, rv, cv);
-    p.x = ws + in.off; p.ldx = in.ld; p.x_coff = r == 0 ? L.y_coff : 0;
-    p.wp = ws + L.wupbT_off[r]; p.Kc = L.KcT; p.ldw = L.ldwT; p.kreal = L.cout;
-    p.y = ws + bp.off + ((size_t)((r & 1) ? h - 1 : 0) * PW + ((r >> 1) ? w - 1 : 0)) * bp.ld; p.ldy = bp.ld; p.y_coff = 0; p.Cout = L.cin;
-    p.accumulate = r > 0;
-    fill_common(P, p, ws, ln.slot);
-    UDET_TRY(launch_conv(p, s));
-  }
+  ConvParams p;
+  memset(&p, 0, sizeof(p));
+  p.N = N; p.H = 2 * h; p.W = 2 * w;
+  p.OH = h + 2; p.OW = w + 2;
+  p.osy = p.osx = 1; p.isy = p.isx = 2;
+  fill_segments(p, L.upb_b, ws);
+  p.x = ws + bu.off; p.ldx = bu.ld; p.x_coff = L.y_coff;
+  p.wp = ws + L.wupbT_off; p.Kc = L.KcT; p.ldw = L.ldwT; p.kreal = L.cout;
+  p.y = ws + bp.off; p.ldy = bp.ld; p.y_coff = 0; p.Cout = L.cin;
+  fill_common(P, p, ws, ln.slot);
+  p.f16_xscale = UDET_F16_GRAD_SCALE;
+  UDET_TRY(launch_conv(p, s));
   UDET_TRY(launch_upb_ring_fold(ws + bp.off, bp.ld, N, h, w, ws + bd.off, s));
   prof_end(P, s);
   return UDET_OK;
@@ -539,16 +520,15 @@ int plan_init_workspace(Plan* P, float* ws, hipStream_t s) {
         jobs.push_back(j);
         j.T = T;
       }
-      if (L.upb)  // up-conv algebra of the recover decoder: four forward and four backward-data weight sets (pack modes 9 / 10)
-        for (int r = 0; r < 4; ++r) {
+      if (L.upb)  // up-conv algebra of the recover decoder: four forward and four backward-data weight sets (pack modes 9 / 10), set
+        for (int r = 0; r < 4; ++r) {  // r = (last row) + 2 (last column) -> job variant (row, column) in {interior, last}
+          // (a level that keeps the up-sampled form for backward-data packs its four transposed sets all the same: cheap, never read)
           j.T = 36; j.gamma_off = -1;
-          // forward sets by OUTPUT region: 0 interior, 1 last row, 2 last column, 3 corner -> (row variant, column variant) in {0, 1}
-          j.dst_off = (long)L.wupb_off[r]; j.R = L.cin; j.C = L.cout; j.Kc = L.Kc; j.ldw = L.ldw; j.k_split = L.k_split; j.k_gap = L.k_gap;
+          j.dst_off = (long)(L.wupb_off + (size_t)r * 36 * L.Kc * L.ldw); j.R = L.cin; j.C = L.cout; j.Kc = L.Kc; j.ldw = L.ldw; j.k_split = L.k_split; j.k_gap = L.k_gap;
           j.mode = 9; j.beta_off = (long)((r & 1) * 3 + (r >> 1)); j.total = (long)L.Kc * L.ldw;  // (one work item per (k, n))
           jobs.push_back(j);
-          // backward-data sets: 0 interior, 1 (last - interior) rows, 2 (last - interior) columns, 3 both
-          j.dst_off = (long)L.wupbT_off[r]; j.Kc = L.KcT; j.ldw = L.ldwT; j.k_split = L.KcT; j.k_gap = 0;
-          j.mode = 10; j.beta_off = (long)((r & 1) * 2 * 3 + (r >> 1) * 2); j.total = (long)L.KcT * L.ldwT;
+          j.dst_off = (long)(L.wupbT_off + (size_t)r * 36 * L.KcT * L.ldwT); j.Kc = L.KcT; j.ldw = L.ldwT; j.k_split = L.KcT; j.k_gap = 0;
+          j.mode = 10; j.total = (long)L.KcT * L.ldwT;
           jobs.push_back(j);
           j.T = T; j.beta_off = beoff;
         }
@@ -570,6 +550,11 @@ int plan_init_workspace(Plan* P, float* ws, hipStream_t s) {
     UDET_HIP(hipMemcpyAsync(ws + P->jobs_off[net], jobs.data(), jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice, s));
     UDET_HIP(hipStreamSynchronize(s));  // `jobs` is a host temporary
   }
+  for (const auto& L : P->rec)  // tap tables of the segmented launches (recover decoder's up-conv algebra)
+    if (L.upb)
+      for (const Layer::SegLaunch* g : {&L.upb_f, &L.upb_b})
+        UDET_HIP(hipMemcpyAsync(ws + g->tab_off, g->taps.data(), g->taps.size() * sizeof(ConvTap), hipMemcpyHostToDevice, s));
+  UDET_HIP(hipStreamSynchronize(s));
   P->pwc_packed = false;
   return UDET_OK;
 }
@@ -882,9 +867,8 @@ static int rec_backward(Plan* P, int N, const char* dp, bool with_wgrad, bool ne
       UDET_TRY(launch_resize_bilinear_bwd(ws + drf.off, drf.ld, 0, N, drf.h, drf.w, ws + dfn.off, dfn.ld, 0, dfn.h, dfn.w, drf.ld, 0, s));
     }
     if (with_wgrad) UDET_TRY(wgrad(*dc, uconcat, true));
-    if (dc->upb) {
-      UDET_TRY(run_dgrad_upb(P, *dc, N, uconcat, D_(S("p%d", k + 1)), D_(S("sr%d", k)), D_(S("sc%d", k)), D_(S("sx%d", k)),
-                             D_(S("concat%d", k + 1)), ws, LD));
+    if (dc->upb_bwd) {
+      UDET_TRY(run_dgrad_upb(P, *dc, N, uconcat, D_(S("p%d", k + 1)), D_(S("concat%d", k + 1)), ws, LD));
       continue;
     }
     const int dr = D_(S("r%d", k + 1));
