@@ -432,7 +432,8 @@ def main():
                     "frac_step": round(exe_flops / (ms * 1e-3) / 1e12 / peak_tf, 4),
                     "frac_step_algorithmic": round(alg_flops / (ms * 1e-3) / 1e12 / peak_tf, 4),
                     "numerator": "executed GFLOP of the launches (recover encoder A once instead of three times; the generator's NN x2 + 3x3 "
-                                 "layers as four 2x2 convolutions: 16 of 36 tap products) -- `achieved_algorithmic` / `frac_algorithmic` divide "
+                                 "layers as four 2x2 convolutions: 16 of 36 tap products; the recover decoder's bilinear x2 + 4x4 layers of levels 1-3 as four "
+                                 "3x3 convolutions on the low-resolution source: 9 of 16) -- `achieved_algorithmic` / `frac_algorithmic` divide "
                                  "the reference graph's 871.78 GFLOP by the same time",
                     "executed_gflop_per_step": round(exe_flops / 1e9, 2), "alg_gflop_per_step": round(alg_flops / 1e9, 2),
                     # Winograd F(2x2,3x3) launches (conv_wino_kernel) are credited with the multiply-adds of the DIRECT convolution they

@@ -270,7 +270,8 @@ def test_conv_winograd_family(ops, force_conv, variant, ks, case):
     assert (dx - gx.float()).abs().max() < 2e-4 * max(1.0, float(gx.abs().max()))
 
 
-@pytest.mark.parametrize("case", [(2, 13, 37, 98, 3), (1, 31, 45, 50, 5), (1, 9, 70, 386, 3), (3, 8, 8, 196, 3), (1, 40, 72, 64, 5)])
+@pytest.mark.parametrize("case", [(2, 13, 37, 98, 3), (1, 31, 45, 50, 5), (1, 9, 70, 386, 3), (3, 8, 8, 196, 3), (1, 40, 72, 64, 5),
+                                  (2, 21, 100, 56, 5), (1, 16, 64, 36, 3)])
 def test_two_channel_heads_run_the_direct_kernels(ops, force_conv, case):
     """The flow / up_feat heads (2 output channels over a deep input) and their backward-data pass (2 input channels, wide output):
     the direct kernels of conv_thin.hip are what an untuned launch runs (families 8 / 7), they agree with the oracle, and they
@@ -297,11 +298,13 @@ def test_two_channel_heads_run_the_direct_kernels(ops, force_conv, case):
     assert (dx - ref_dx).abs().max() < 2e-5 * max(1.0, float(ref_dx.abs().max()))
 
 
-def test_transposed_two_channel_head_runs_the_direct_kernel(ops, force_conv):
+@pytest.mark.parametrize("grid", [(2, 12, 20, 529), (1, 10, 50, 36)])
+def test_transposed_two_channel_head_runs_the_direct_kernel(ops, force_conv, grid):
     """up_feat_l (models/PWCNet/model_pwcnet.py:283-286): conv2d_transpose 4x4 s2 with two output channels -- the four output
     parity classes share the staged input tile of the direct kernel."""
-    x = rnd(2, 12, 20, 529, seed=55)
-    wt = rnd(4, 4, 2, 529, seed=56, scale=(1.0 / (16 * 529)) ** 0.5)
+    n, h, w, c = grid
+    x = rnd(n, h, w, c, seed=55)
+    wt = rnd(4, 4, 2, c, seed=56, scale=(1.0 / (16 * c)) ** 0.5)
     b = rnd(2, seed=57, scale=0.1)
     y = ops.conv2d_transpose4x4s2(x.cuda(), wt.cuda(), b.cuda()).cpu()
     assert (force_conv.udet_debug_last_conv() & 0xff) == 8

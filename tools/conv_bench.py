@@ -29,6 +29,9 @@ SHAPES = [
     ("pwc.conv2aa", 8, 96, 160, 32, 32, 3, 1, 1, False),
     ("gen.conv1", 4, 192, 384, 5, 32, 5, 1, 1, False),
     ("gen.conv17", 4, 192, 384, 16, 2, 3, 1, 1, False),
+    ("rec.flow1", 12, 96, 192, 56, 2, 5, 1, 1, False),
+    ("rec.flow2", 12, 48, 96, 104, 2, 3, 1, 1, False),
+    ("pwc.flow2", 4, 96, 160, 568, 2, 3, 1, 1, False),
     ("rec.aconv1", 12, 192, 384, 3, 16, 7, 2, 1, False),
     ("rec.aconv2", 12, 96, 192, 16, 32, 5, 2, 1, False),
     ("gen.conv5", 4, 48, 96, 128, 128, 3, 1, 1, False),

@@ -1483,8 +1483,6 @@ static float time_cfg(ConvParams& p, const ConvCfg& c, int reps, hipStream_t str
   if (hipEventSynchronize(e1) != hipSuccess) return 1e30f;
   float ms = 0.f;
   (void)hipEventElapsedTime(&ms, e0, e1);
-  static const float pen = getenv("UDET_TUNE_SPLIT_PENALTY") ? (float)atof(getenv("UDET_TUNE_SPLIT_PENALTY")) : 0.f;
-  if ((c.ks > 1 || c.tail > 0) && pen > 0.f) return ms / reps * (1.f + pen);
   return ms / reps;
 }
 static ConvCfg tune_cfg_impl(ConvParams& p, hipStream_t stream);
