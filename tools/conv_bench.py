@@ -31,6 +31,8 @@ SHAPES = [
     ("gen.conv17", 4, 192, 384, 16, 2, 3, 1, 1, False),
     ("rec.flow1", 12, 96, 192, 56, 2, 5, 1, 1, False),
     ("rec.flow2", 12, 48, 96, 104, 2, 3, 1, 1, False),
+    ("rec.flow1_dgrad", 12, 96, 192, 2, 50, 5, 1, 1, False),     # two input channels, wide output: conv_thin_k
+    ("rec.flow2_dgrad", 12, 48, 96, 2, 98, 3, 1, 1, False),
     ("pwc.flow2", 4, 96, 160, 568, 2, 3, 1, 1, False),
     ("rec.aconv1", 12, 192, 384, 3, 16, 7, 2, 1, False),
     ("rec.aconv2", 12, 96, 192, 16, 32, 5, 2, 1, False),

@@ -1589,6 +1589,8 @@ static ConvCfg tune_cfg_impl(ConvParams& p, hipStream_t stream) {
     if (!(ws == 7 ? conv_thin_k_ok(p) : conv_thin_n_ok(p)) || p.f16) continue;  // (fp16 mode: every configuration must multiply alike)
     const ConvCfg d = {0, 0, 1, ws, 0, 0};
     const float ms = time_cfg(p, d, 5, stream);
+    if (getenv("UDET_TUNE_LOG") && atoi(getenv("UDET_TUNE_LOG")) > 1)
+      fprintf(stderr, "[udet tune]   direct family %d: %.1f us against %.1f (N=%d %dx%d Kc=%d taps=%d Cout=%d)\n", ws, ms * 1e3f, (a < b ? a : b) * 1e3f, p.N, p.OHq, p.OWq, p.Kc, p.ntaps, p.Cout);
     if (ms < (a < b ? a : b) * 0.97f) { a = b = ms; best = d; }
   }
   if (conv_wino_ok(p)) {  // Winograd F(2x2,3x3): 2.25x fewer multiplications; K slices where the tiles do not fill the chip

@@ -31,6 +31,36 @@ __device__ __forceinline__ void thin_epilogue(const ConvParams& p, int off, int 
     p.uo[(size_t)off * p.ldu + p.u_coff + n] = v * act_dfo(p.ua[(size_t)off * p.ldua + p.ua_coff + n], p.uact, p.ualpha);
 }
 
+// The same epilogue for a row of W pixels of one output channel (pixel u at off0 + u * osx, the first `nvalid` exist), in two phases:
+// every load of the row (accumulate / residual / saved activation) is issued before the first store.  Pixel by pixel, each load waits
+// for the previous pixel's store -- the compiler must assume they alias -- and a launch whose arithmetic takes 20 us spends 75 in
+// its epilogue (the 5x5 flow head's backward-data pass).
+template <int W>
+__device__ __forceinline__ void thin_epilogue_row(const ConvParams& p, int off0, int nvalid, int n, const float (&val)[W]) {
+  const bool emit = p.uo && n >= p.u_c0 && n < p.u_c1;
+  const float bias = p.bias ? p.bias[n] : 0.f;
+  float accv[W], resv[W], uav[W];
+#pragma unroll
+  for (int u = 0; u < W; ++u) {
+    const size_t off = (size_t)(off0 + u * p.osx);
+    const bool on = u < nvalid;
+    accv[u] = (p.accumulate && on) ? p.y[off * p.ldy + p.y_coff + n] : 0.f;
+    resv[u] = (p.res && on) ? p.res[off * p.ldres + p.res_coff + n] : 0.f;
+    uav[u] = (emit && on) ? p.ua[off * p.ldua + p.ua_coff + n] : 0.f;
+  }
+#pragma unroll
+  for (int u = 0; u < W; ++u) {
+    if (u >= nvalid) break;
+    const size_t off = (size_t)(off0 + u * p.osx);
+    float v = act_fwd(val[u] + bias, p.act, p.alpha);
+    if (p.y2) p.y2[off * p.ldy2 + p.y2_coff + n] = v;
+    if (p.res) v += resv[u];
+    if (p.accumulate) v += accv[u];
+    p.y[off * p.ldy + p.y_coff + n] = v;
+    if (emit) p.uo[off * p.ldu + p.u_coff + n] = v * act_dfo(uav[u], p.uact, p.ualpha);
+  }
+}
+
 struct ThinGeom {
   int min_dy, min_dx, PH, PW;  // halo tile of one workgroup on the (logical) input grid
 };
@@ -195,26 +225,108 @@ __global__ __launch_bounds__(256) void conv_thin_k_kernel(const ConvParams p, co
     const int ty = wave * 2 + r, oy = oy0 + ty;
     if (oy >= p.OHq) break;
     // four neighbouring pixels at a time: eight independent accumulation chains hide the multiply-add and LDS latencies
+    float out[TW];
+#pragma unroll
     for (int tx = 0; tx < TW; tx += 4) {
-      if (ox0 + tx >= p.OWq) break;
       const float2* xr = xs + ty * g.PW + tx;
       float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+      if (ox0 + tx < p.OWq) {
 #pragma unroll
-      for (int i = 0; i < T; ++i) {
-        const float2* q = xr + toff[i];  // same address in every lane: broadcast reads
+        for (int i = 0; i < T; ++i) {
+          const float2* q = xr + toff[i];  // same address in every lane: broadcast reads
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const float2 v = q[u];
-          a0[u] = fmaf(v.x, w[i][0], a0[u]);
-          a1[u] = fmaf(v.y, w[i][1], a1[u]);
+          for (int u = 0; u < 4; ++u) {
+            const float2 v = q[u];
+            a0[u] = fmaf(v.x, w[i][0], a0[u]);
+            a1[u] = fmaf(v.y, w[i][1], a1[u]);
+          }
         }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
-        if (ox0 + tx + u < p.OWq)
-          thin_epilogue(p, (n * p.OH + oy * p.osy + p.ooy) * p.OW + (ox0 + tx + u) * p.osx + p.oox, co, a0[u] + a1[u]);
+      for (int u = 0; u < 4; ++u) out[tx + u] = a0[u] + a1[u];
     }
+    thin_epilogue_row<TW>(p, (n * p.OH + oy * p.osy + p.ooy) * p.OW + ox0 * p.osx + p.oox, p.OWq - ox0, co, out);
   }
+}
+
+// The same for a DENSE KH x KW tap window at unit spacing (every stride-1, undilated head): the 2-channel input window of four
+// neighbouring pixels -- KH x (KW + 3) float2 -- is read into registers in one burst and the multiply-adds index it statically.  The
+// generic kernel above waits for the LDS after every tap (168 s_waitcnt for 200 reads in the 25-tap instantiation: 75 us for a launch
+// whose multiply-adds take 18).
+struct ThinWin { int widx_at[25]; };  // window position r * KW + c -> weight matrix of the tap there (resolved on the host: a
+                                       // kernarg table indexed through another one is 25 dependent scalar loads per workgroup)
+template <int KH, int KW>
+__global__ __launch_bounds__(256) void conv_thin_kw_kernel(const ConvParams p, const ThinGeom g, const ThinWin win) {
+  constexpr int TH = 8, TW = 16, T = KH * KW;
+  extern __shared__ __attribute__((aligned(16))) float xs_[];  // [PIX] float2
+  float2* xs = reinterpret_cast<float2*>(xs_);
+  const int PIX = g.PH * g.PW;
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int tiles_x = (p.OWq + TW - 1) / TW, tiles_y = (p.OHq + TH - 1) / TH;
+  const int bid = blockIdx.x;
+  const int bx = bid % tiles_x, by = (bid / tiles_x) % tiles_y, n = bid / (tiles_x * tiles_y);
+  const int oy0 = by * TH, ox0 = bx * TW;
+  const int iy0 = oy0 + g.min_dy, ix0 = ox0 + g.min_dx;
+  const float* xb = p.x + (size_t)n * p.H * p.W * p.ldx + p.x_coff;
+  const int co = blockIdx.y * 64 + lane;
+  float w[T][2];  // this lane's weights by window position
+#pragma unroll
+  for (int i = 0; i < T; ++i) {
+    const float* src = p.wp + ((size_t)win.widx_at[i] * p.Kc) * p.ldw + (co < p.ldw ? co : 0);
+    w[i][0] = co < p.ldw ? src[0] : 0.f;
+    w[i][1] = co < p.ldw ? src[p.ldw] : 0.f;
+  }
+  for (int pix = t; pix < PIX; pix += 256) {
+    const int py = pix / g.PW, px = pix - py * g.PW;
+    const int iy = iy0 + py, ix = ix0 + px;
+    float2 v = make_float2(0.f, 0.f);
+    if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) v = *reinterpret_cast<const float2*>(xb + (size_t)(iy * p.W + ix) * p.ldx);
+    xs[pix] = v;
+  }
+  __syncthreads();
+  if (co >= p.Cout) return;
+  for (int r = 0; r < 2; ++r) {
+    const int ty = wave * 2 + r, oy = oy0 + ty;
+    if (oy >= p.OHq) break;
+    float out[TW];
+#pragma unroll
+    for (int tx = 0; tx < TW; tx += 4) {
+      float a0[4] = {0.f, 0.f, 0.f, 0.f}, a1[4] = {0.f, 0.f, 0.f, 0.f};
+      if (ox0 + tx < p.OWq) {
+        const float2* xr = xs + ty * g.PW + tx;  // same address in every lane: broadcast reads
+        float2 v[KH][KW + 3];
+#pragma unroll
+        for (int wr = 0; wr < KH; ++wr)
+#pragma unroll
+          for (int wc = 0; wc < KW + 3; ++wc) v[wr][wc] = xr[wr * g.PW + wc];
+#pragma unroll
+        for (int wr = 0; wr < KH; ++wr)
+#pragma unroll
+          for (int wc = 0; wc < KW; ++wc)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              a0[u] = fmaf(v[wr][wc + u].x, w[wr * KW + wc][0], a0[u]);
+              a1[u] = fmaf(v[wr][wc + u].y, w[wr * KW + wc][1], a1[u]);
+            }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) out[tx + u] = a0[u] + a1[u];
+    }
+    thin_epilogue_row<TW>(p, (n * p.OH + oy * p.osy + p.ooy) * p.OW + ox0 * p.osx + p.oox, p.OWq - ox0, co, out);
+  }
+}
+// dense window?  fills the position -> tap table
+static bool thin_window(const ConvParams& p, const ThinGeom& g, int* kh, int* kw, ThinWin* win) {
+  const int KH = g.PH - 7, KW = g.PW - 15;  // (thin_geom of an 8 x 16 tile at unit stride)
+  if (!((KH == 3 && KW == 3) || (KH == 5 && KW == 5)) || p.ntaps != KH * KW) return false;
+  for (int i = 0; i < 25; ++i) win->widx_at[i] = -1;
+  for (int t = 0; t < p.ntaps; ++t) {
+    const int pos = (p.taps[t].dy - g.min_dy) * KW + (p.taps[t].dx - g.min_dx);
+    if (win->widx_at[pos] >= 0 || p.taps[t].widx < 0) return false;
+    win->widx_at[pos] = p.taps[t].widx;
+  }
+  *kh = KH; *kw = KW;
+  return true;
 }
 
 bool conv_thin_k_ok(const ConvParams& p) {
@@ -232,6 +344,14 @@ int launch_conv_thin_k(const ConvParams& p, hipStream_t stream) {
   thin_geom(p, 8, 16, &g);
   const size_t lds = (size_t)g.PH * g.PW * sizeof(float2);
   const dim3 grid(p.N * ((p.OHq + 7) / 8) * ((p.OWq + 15) / 16), (p.Cout + 63) / 64);
+  int kh = 0, kw = 0;
+  ThinWin win;
+  if (thin_window(p, g, &kh, &kw, &win)) {
+    if (kh == 3) UDET_LAUNCH((conv_thin_kw_kernel<3, 3>), grid, dim3(256), lds, stream, p, g, win);
+    else UDET_LAUNCH((conv_thin_kw_kernel<5, 5>), grid, dim3(256), lds, stream, p, g, win);
+    UDET_HIP(hipGetLastError());
+    return UDET_OK;
+  }
   if (p.ntaps <= 9) UDET_LAUNCH(conv_thin_k_kernel<9>, grid, dim3(256), lds, stream, p, g);
   else UDET_LAUNCH(conv_thin_k_kernel<25>, grid, dim3(256), lds, stream, p, g);
   UDET_HIP(hipGetLastError());
