@@ -522,14 +522,15 @@ int plan_init_workspace(Plan* P, float* ws, hipStream_t s) {
       }
       if (L.upb)  // up-conv algebra of the recover decoder: four forward and four backward-data weight sets (pack modes 9 / 10), set
         for (int r = 0; r < 4; ++r) {  // r = (last row) + 2 (last column) -> job variant (row, column) in {interior, last}
-          // (a level that keeps the up-sampled form for backward-data packs its four transposed sets all the same: cheap, never read)
           j.T = 36; j.gamma_off = -1;
           j.dst_off = (long)(L.wupb_off + (size_t)r * 36 * L.Kc * L.ldw); j.R = L.cin; j.C = L.cout; j.Kc = L.Kc; j.ldw = L.ldw; j.k_split = L.k_split; j.k_gap = L.k_gap;
           j.mode = 9; j.beta_off = (long)((r & 1) * 3 + (r >> 1)); j.total = (long)L.Kc * L.ldw;  // (one work item per (k, n))
           jobs.push_back(j);
-          j.dst_off = (long)(L.wupbT_off + (size_t)r * 36 * L.KcT * L.ldwT); j.Kc = L.KcT; j.ldw = L.ldwT; j.k_split = L.KcT; j.k_gap = 0;
-          j.mode = 10; j.total = (long)L.KcT * L.ldwT;
-          jobs.push_back(j);
+          if (L.upb_bwd) {  // (a level that keeps the up-sampled form for backward-data never reads these)
+            j.dst_off = (long)(L.wupbT_off + (size_t)r * 36 * L.KcT * L.ldwT); j.Kc = L.KcT; j.ldw = L.ldwT; j.k_split = L.KcT; j.k_gap = 0;
+            j.mode = 10; j.total = (long)L.KcT * L.ldwT;
+            jobs.push_back(j);
+          }
           j.T = T; j.beta_off = beoff;
         }
       if (L.wino_off) {  // Winograd operand of the forward pass: K = input channels with the slab's gap map, N = output channels
