@@ -8,6 +8,7 @@ from unsupervised_detection_amd._ffi import lib
 from unsupervised_detection_amd.engine import BOTH, Engine, EngineConfig
 from unsupervised_detection_amd.trainer import TrainState, train_step
 eng = Engine(EngineConfig(batch_size=4))
+prio = [int(v) for v in sys.argv[1].split(",")] if len(sys.argv) > 1 else None  # priorities of the three side streams (lanes 1 | 3 | 4, 5)
 lib.udet_tune_load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'profiles', 'r04_tune.txt').encode())
 st = TrainState(eng, seed=8964, autotune=False)
 batches = []
@@ -16,6 +17,11 @@ for i in range(4):
     batches.append((data.preprocess_image(torch.from_numpy(f1).cuda()), data.preprocess_image(torch.from_numpy(f2).cuda())))
 torch.cuda.synchronize()
 torch.cuda.set_stream(torch.cuda.Stream())
+if prio:
+    print("stream priority range", torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else "?")
+    side = [torch.cuda.Stream(priority=q) for q in prio]
+    eng.pin_lanes(side)
+    print("lanes", eng.lane_queues())
 def step(i):
     a, b = batches[i % 4]; nx = batches[(i + 1) % 4]
     train_step(st, a, b, BOTH, next_pair=nx)
