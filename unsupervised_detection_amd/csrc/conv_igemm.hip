@@ -1599,6 +1599,7 @@ static ConvCfg tune_cfg_impl(ConvParams& p, hipStream_t stream) {
       const long wgs = conv_wino_workgroups(p, v);
       const int cap = conv_wino_max_ksplit(p, v);
       std::vector<int> kss = {1};
+      if (wgs < 256 && cap >= 2) kss.push_back(2);  // (under one round of workgroups: two K slices even where no whole round results)
       if (wgs < 384)
         for (int r = 1; r <= 3; ++r) {
           const int ks = (int)(256L * r / (wgs > 0 ? wgs : 1));
@@ -1607,6 +1608,9 @@ static ConvCfg tune_cfg_impl(ConvParams& p, hipStream_t stream) {
       for (int ks : kss) {
         const ConvCfg d = {v, 0, ks, 9, 0, 0};
         const float ms = time_cfg(p, d, 3, stream);
+        if (getenv("UDET_TUNE_LOG") && atoi(getenv("UDET_TUNE_LOG")) > 1)
+          fprintf(stderr, "[udet tune]   winograd variant %d ks=%d (%ld workgroups): %.1f us against %.1f (N=%d %dx%d Kc=%d Cout=%d)\n", v, ks, wgs, ms * 1e3f,
+                  (a < b ? a : b) * 1e3f, p.N, p.OHq, p.OWq, p.Kc, p.Cout);
         if (ms < (a < b ? a : b) * 0.97f) {
           const float ms5 = time_cfg(p, d, 5, stream);
           if (ms5 < (a < b ? a : b) * 0.97f) { a = b = ms5; best = d; }
