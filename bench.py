@@ -187,9 +187,21 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
-    if world > 1:
+    # UDET_DP_WORLD1=1 (one-GPU box): a process group of ONE rank on the RCCL backend, and the gradient exchange issued although there is
+    # nobody to exchange with (trainer._dp_active) -- the N > 1 code path of this script, call for call: init_process_group("nccl",
+    # device_id), both all-reduces on their streams, the event hand-over, allreduce_ms, destroy.  It says nothing about scaling.
+    dp = world > 1 or os.environ.get("UDET_DP_WORLD1") == "1"
+    if dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if world == 1 and "MASTER_PORT" not in os.environ:
+            import socket
+            with socket.socket() as so:
+                so.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(so.getsockname()[1])
+        if world == 1:
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if one_gpu:
             dist.init_process_group("gloo")
         else:
@@ -233,7 +245,7 @@ def main():
     torch.cuda.set_stream(work_stream)
 
     def barrier():
-        if world > 1:
+        if dp:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -283,7 +295,7 @@ def main():
     step_ms = sorted(marks[k].elapsed_time(marks[k + 1]) for k in range(args.steps))
     pct = lambda q: step_ms[min(len(step_ms) - 1, int(round(q * (len(step_ms) - 1))))] if step_ms else None
     tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
-    if world > 1:
+    if dp:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     ms = dt / args.steps * 1e3
@@ -294,7 +306,7 @@ def main():
     # the gradient exchange alone, timed after the headline region: the SAME two collectives a BOTH step issues (recover gradients on
     # the communication stream, generator gradients on the compute stream, the compute stream then waits) with nothing to hide behind
     allreduce_ms = None
-    if world > 1:
+    if dp:
         barrier()
         t0 = time.perf_counter()
         for _ in range(10):
@@ -306,7 +318,7 @@ def main():
     # how much of that the step hides: the same K steps WITHOUT the exchange (group=False; the replicas drift apart from here on,
     # nothing below depends on them agreeing).  exposed = what the exchange adds to a step; hidden = the rest of its stand-alone time
     exchange = None
-    if world > 1:
+    if dp:
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -337,7 +349,7 @@ def main():
                 run_step(w)
         barrier()
         dc = torch.tensor([time.perf_counter() - t0], device="cuda", dtype=torch.float64)
-        if world > 1:
+        if dp:
             dist.all_reduce(dc, op=dist.ReduceOp.MAX)
         dc = float(dc.item())
         ref_cycle = {"schedule": "1 recover step + 3 generator steps (iter_rec=1, iter_gen=3)", "cycles": args.cycles,
@@ -353,7 +365,7 @@ def main():
             print(json.dumps({"metric": "frame-pairs/sec per adversarial step, DAVIS 480p batch4, 1/2/4/8 GPU", "value": round(pairs_per_s, 3),
                               "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
                               "ms_per_step_median": round(pct(0.5), 3), "trace_only": True, "tuned_configurations_loaded": loaded}), flush=True)
-        if world > 1:
+        if dp:
             dist.barrier()
             dist.destroy_process_group()
         return 0
@@ -412,12 +424,26 @@ def main():
                 traffic = int(sum(k["hbm_MB_per_step"] for k in fam) * 1e6)
             traffic_source = "%s (offline rocprofv3 --pmc passes over serial steps, not re-collected by this run; unit: bytes per step = " \
                              "per pass of all convolution launches, like `achieved`)" % os.path.relpath(args.pmc_json, os.path.dirname(os.path.abspath(__file__)))
+        peak_tf = 2500.0 if args.fp16_convs else PEAK_FP32_MFMA_TFLOPS  # dense MFMA peak of the multiplication dtype (MI355X_MICROARCH.md)
+        # EFFECTIVE peak of a launch family = matrix peak x (multiply-adds of the direct form / multiply-adds the family issues): 157.3 for
+        # the direct families, 157.3 x 36/16 = 353.9 for fused Winograd F(2x2,3x3) (forward, backward-data and, round 5, the filter
+        # gradient).  A launch credited with its direct-equivalent work is priced against THAT, so no fraction of the line exceeds 1.
+        def eff_peak(l):
+            return peak_tf * (l[3] / l[5] if l[5] > 0 else 1.0)
         top_launch = None
         if top is not None:
             top_tf = top[3] / top[2] if top[2] > 0 else 0.0  # GFLOP / ms = TFLOP/s
             top_launch = {"layer": top[1], "alg_gflop": round(top[3], 3), "ms": round(top[2], 4), "achieved": round(top_tf, 2),
-                          "frac": round(top_tf / (2500.0 if args.fp16_convs else PEAK_FP32_MFMA_TFLOPS), 4)}
-        peak_tf = 2500.0 if args.fp16_convs else PEAK_FP32_MFMA_TFLOPS  # dense MFMA peak of the multiplication dtype (MI355X_MICROARCH.md)
+                          "achieved_note": "direct-equivalent TFLOP/s (the reference algorithm's multiply-adds over the launch's duration)",
+                          "effective_peak": round(eff_peak(top), 1), "frac": round(top_tf / eff_peak(top), 4),
+                          "frac_note": "of effective_peak = matrix peak x 36/16 for a Winograd launch (it issues 16 of the direct form's 36 "
+                                       "multiplications); equals the launch's matrix-pipe occupancy"}
+        direct = [l for l in layers if l[0] < 3 and not l[5] < l[3] * 0.99]
+        def fam_row(ls, scale):
+            t, g, m = sum(l[2] for l in ls), sum(l[3] for l in ls), sum(l[5] for l in ls)
+            return {"launch_groups_per_step": len(ls), "ms_per_step_serial": round(t, 3), "executed_gflop": round(g, 2),
+                    "achieved": round(g / max(t, 1e-9), 2), "effective_peak": round(peak_tf * scale, 1),
+                    "frac_of_effective_peak": round(m / max(t, 1e-9) / peak_tf, 4)}
         roofline = {"bound": "mfma",
                     "kernel": "conv_igemm_dma_kernel / conv_igemm_kernel / conv_wino_kernel (fused Winograd F(2x2,3x3), 3x3 stride-1 layers) / "
                               "conv_tile_kernel / conv_wgrad_kernel (v_mfma_f32_32x32x2_f32, "
@@ -444,6 +470,11 @@ def main():
                                  "achieved_direct_equivalent": round(sum(l[3] for l in wino) / max(sum(l[2] for l in wino), 1e-9), 2)},
                     "mfma_issued_gflop_per_step": round(mfma_flops / 1e9, 2),
                     "frac_mfma_issued": round(mfma_flops / (conv_ms * 1e-3) / 1e12 / peak_tf, 4),
+                    # one statement per family and for the whole step: work credited / (time x effective peak).  For the whole step the
+                    # effective peak is the time-weighted mix of the two, so frac_of_effective_peak == frac_mfma_issued by construction.
+                    "families": {"direct": fam_row(direct, 1.0), "winograd_f2x2_3x3": fam_row(wino, 36.0 / 16.0)},
+                    "effective_peak": round(peak_tf * exe_flops / max(mfma_flops, 1.0), 1),
+                    "frac_of_effective_peak": round(mfma_flops / (conv_ms * 1e-3) / 1e12 / peak_tf, 4),
                     "achieved_algorithmic": round(alg_flops / (conv_ms * 1e-3) / 1e12, 2),
                     "frac_algorithmic": round(alg_flops / (conv_ms * 1e-3) / 1e12 / peak_tf, 4),
                     # HBM bytes from PMC counters are collected offline (tools/pmc_step.py, separate rocprofv3 --pmc passes, summaries
@@ -507,6 +538,8 @@ def main():
                           "note": "step = forward(prefetched PWC flow) + PWC flow of the next pair beside both backward passes "
                                   "+ 2 applies; every timed step contains all of that work exactly once"},
             "allreduce_ms": allreduce_ms, "gradient_exchange": exchange,
+            "process_group": ({"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                               "forced_at_world_size_one": world == 1} if dp else None),
             "reference_schedule": ref_cycle,
             "ensemble": ensemble,
             "losses": {k: round(v, 5) for k, v in losses.items()},
@@ -521,7 +554,7 @@ def main():
         print(json.dumps(out), flush=True)
         if rc:
             print("bench.py: PARITY CHECK FAILED: %s" % json.dumps(out["parity_check"]), file=sys.stderr, flush=True)
-    if world > 1:
+    if dp:
         dist.barrier()
         dist.destroy_process_group()
     return rc

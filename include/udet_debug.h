@@ -24,6 +24,9 @@ void udet_debug_force_wgrad(int nsplit, int dma);
  * level whose source has at least `v` pixels (batch included); v < 0 restores the default of 8192.  Tests use 0 on small plans. */
 void udet_debug_upb_min_pixels(long v);
 void udet_debug_set_tuning(int on);
+/* experiment knobs read by the plan executor at enqueue time (0 = shipped behaviour).  id 0: lane (1..5) that runs the recover net's
+ * encoder-A backward chain of a which = 3 backward instead of the recover-loss pass's own stream. */
+void udet_debug_knob(int id, long v);
 /* what the most recent convolution launch actually ran: family (0 plain, 1 wave-specialised, 2 LDS-DMA, 3 tile-resident,
  * 6 self-staging LDS-DMA, 7 / 8 direct kernel for two input / two output channels) | tile rows << 8 | split count << 20 | folded split-K << 28 */
 int udet_debug_last_conv(void);

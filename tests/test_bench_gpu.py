@@ -51,3 +51,29 @@ def test_gpus_flag_without_a_launcher_starts_the_ranks_itself():
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 8 and out["allreduce_ms"] > 0
+
+
+def test_rccl_branch_at_world_size_one():
+    """The RCCL branch of bench.py / trainer._exchange_gradients executed on the ONE GPU of the box (UDET_DP_WORLD1=1):
+    init_process_group("nccl", device_id=...), the recover gradients' all-reduce on the communication stream behind
+    udet_stream_wait_grads, the generator gradients' on the compute stream, the event hand-over, the stand-alone exchange
+    (allreduce_ms), barrier + destroy.  A group of one rank proves nothing about scaling; it proves that the calls, the stream
+    semantics and the environment (HSA_ENABLE_IPC_MODE_LEGACY=0) are valid on this ROCm / RCCL stack before an 8-GPU node runs them
+    (models/adversarial_learner.py:167-172 is the algebra the exchange implements: the mean over ranks, here over one)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "UDET_BENCH_ONE_GPU")}
+    env.update(UDET_DP_WORLD1="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--cycles", "1", "--no-cpu-baseline",
+           "--ensemble-frames", "0"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["process_group"] == {"backend": "nccl", "world_size": 1, "forced_at_world_size_one": True}
+    assert out["n_gpus"] == 1 and out["allreduce_ms"] is not None and out["allreduce_ms"] > 0
+    ex = out["gradient_exchange"]
+    assert ex is not None and ex["ms_per_step_without_exchange"] > 0
+    # a one-rank mean changes nothing: the losses of the run are finite and the step time is that of the plain N = 1 run (loosely)
+    assert all(v == v for v in out["losses"].values()) and out["ms_per_step"] < 40

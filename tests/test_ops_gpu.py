@@ -270,6 +270,35 @@ def test_conv_winograd_family(ops, force_conv, variant, ks, case):
     assert (dx - gx.float()).abs().max() < 2e-4 * max(1.0, float(gx.abs().max()))
 
 
+@pytest.mark.parametrize("variant,ks", [(2, 1), (0, 1), (3, 2)])
+def test_conv_winograd_family_at_the_largest_launch(ops, force_conv, variant, ks):
+    """The Winograd family forced on the step's largest launch, pwcnet/ctxt/dc_conv21's own problem (4 x 96 x 160, 565 -> 128 channels:
+    model_pwcnet.py:562): the large-grid paths -- conv_wino_ok's 32-bit byte-offset guard (a 568-channel operand of 4 x 96 x 160 pixels is
+    139.6 MB), 960 tile blocks in the XCD-aware order, K slices through the split-K slabs at that size -- directly, not only through the
+    whole-step tests.  Reference: the fp32 PyTorch-CPU convolution of the oracle (80 GFLOP: float64 would take minutes); the implicit-GEMM
+    family on the same data must agree with both."""
+    n, h, w, cin, cout = 4, 96, 160, 565, 128
+    x = rnd(n, h, w, cin, seed=71)
+    wt = rnd(3, 3, cin, cout, seed=72, scale=(2.0 / (9 * cin)) ** 0.5)
+    b = rnd(cout, seed=73, scale=0.1)
+    y = _oracle_conv(x, wt, b, 1, 1, "leaky", 0.1, False)
+    dy = rnd(n, h, w, cout, seed=74)
+    gx = torch.nn.grad.conv2d_input((n, cin, h, w), wt.permute(3, 2, 0, 1).contiguous(), dy.permute(0, 3, 1, 2).contiguous(),
+                                    padding=1).permute(0, 2, 3, 1)  # SAME 3x3 stride 1: symmetric padding 1
+    xg, wg, bg, dyg = x.cuda(), wt.cuda(), b.cuda(), dy.cuda()
+    force_conv.udet_debug_force_conv((1 << 25) + variant, 0, ks)
+    got = ops.conv2d(xg, wg, bg, 1, 1, "leaky", 0.1, False).cpu()
+    assert (force_conv.udet_debug_last_conv() & 0xff) == 9
+    assert (got - y).abs().max() < 1e-4 * max(1.0, float(y.abs().max()))
+    dx = ops.conv2d_backward_data(dyg, None, wg, (h, w), 1, 1, "none", 0.0).cpu()
+    assert (force_conv.udet_debug_last_conv() & 0xff) == 9
+    assert (dx - gx).abs().max() < 2e-4 * max(1.0, float(gx.abs().max()))
+    force_conv.udet_debug_force_conv(*FAMILIES["lds_dma"])
+    ref = ops.conv2d(xg, wg, bg, 1, 1, "leaky", 0.1, False).cpu()
+    assert (force_conv.udet_debug_last_conv() & 0xff) == 2
+    assert (got - ref).abs().max() < 5e-5 * max(1.0, float(ref.abs().max()))
+
+
 @pytest.mark.parametrize("case", [(2, 13, 37, 98, 3), (1, 31, 45, 50, 5), (1, 9, 70, 386, 3), (3, 8, 8, 196, 3), (1, 40, 72, 64, 5),
                                   (2, 21, 100, 56, 5), (1, 16, 64, 36, 3)])
 def test_two_channel_heads_run_the_direct_kernels(ops, force_conv, case):

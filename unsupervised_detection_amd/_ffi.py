@@ -71,11 +71,17 @@ class UdetError(RuntimeError):
     pass
 
 
+class UdetOverflow(OverflowError):
+    """UDET_ERR_OVERFLOW (-6): an fp16-mode optimizer update was dropped on the device (include/udet.h, udet_config.conv_fp16).
+    Its own type, so that callers which retry on it (trainer.train_step) do not swallow Python's / ctypes' own OverflowError
+    (argument marshalling of a too-large integer, for example)."""
+
+
 def check(status: int):
     if status != 0:
         msg = lib.udet_last_error().decode("utf-8", "replace")
         if status in (-1, -2, -5):
             raise ValueError(f"libudet error {status}: {msg}")
         if status == -6:
-            raise OverflowError(f"libudet error {status}: {msg}")
+            raise UdetOverflow(f"libudet error {status}: {msg}")
         raise UdetError(f"libudet error {status}: {msg}")

@@ -725,7 +725,8 @@ int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream) {
   if (p.ntaps < T) UDET_HIP(hipMemsetAsync(p.dw, 0, wsz * sizeof(float), stream));  // culled taps have zero gradient
   const long total = (long)(Mreal + 1) * g.Cout;
   const bool dma_ok = p.ya == nullptr && p.zero16 != nullptr && !(reinterpret_cast<uintptr_t>(p.zero16) & 15);
-  // BN-folded layers (generator) finish inside the reduction launch when the caller provides a ticket (plans do)
+  // BN-folded layers (generator): the slab reduction also scales and forms dgamma's dot partials, a one-block launch finishes (two launches
+  // behind the GEMM; wgrad_reduce_bn_kernel above)
   const bool fused_bn = p.gamma && !g.swapped && !p.ycls && p.ntaps == T && p.Cout <= 128 && p.db && p.dgamma && p.dbeta && p.w && p.b;
   auto run = [&](int cfg) {
     const int ns = cfg & 0xfffff;
@@ -736,7 +737,7 @@ int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream) {
     if (bn == 128) wgrad_launch<128, 128, 2, 2>(q, m_tiles, co_tiles, ns, dma, stream);
     else if (bn == 64) wgrad_launch<128, 64, 2, 2>(q, m_tiles, co_tiles, ns, dma, stream);
     else wgrad_launch<128, 32, 4, 1>(q, m_tiles, co_tiles, ns, dma, stream);
-    if (fused_bn) {  // reduction + BN finalisation in one launch
+    if (fused_bn) {  // reduction + scaling + dot partials, then the one-block finish
       const int cw = g.Cout > 64 ? 128 : (g.Cout > 32 ? 64 : (g.Cout > 16 ? 32 : 16));
       int rb = 256 / cw;  // rows per block: ONE element per thread (the reduction is latency-bound: 28 slabs 590 KB apart per element --
                           // it needs every CU; eight rows per thread on 72 blocks took 30 us instead of 5)

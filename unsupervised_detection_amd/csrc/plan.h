@@ -159,12 +159,18 @@ struct Plan {
   int bid(const std::string& name) const;
 };
 
+// capacity (entries) of a network's device PackJob table; plan_init_workspace refuses to copy more
+#define UDET_PACKJOB_CAP(layers) (8 * (layers) + 32)
 // offsets (floats) inside the plan's small region; registered as named views by plan_build
 #define UDET_SMALL_NOISE 256   // noise_flag
 #define UDET_SMALL_OVF 300     // fp16_overflow: int[2 nets][2] = {non-finite values of the last apply, running total}
 #define UDET_SMALL_SUMS 1024   // loss_sums
 Plan* plan_build(const Config& cfg);
 void plan_debug_upb_min_pixels(long v);  // (libudet_debug)
+// experiment knobs (libudet_debug: udet_debug_knob; tools/ only -- every knob's 0 is the shipped behaviour)
+enum { UDET_KNOB_ENC_A_LANE = 0, UDET_KNOB_COUNT = 8 };
+void plan_debug_knob(int id, long v);
+long plan_knob(int id);
 
 // execution (all asynchronous on `s`)
 int plan_init_workspace(Plan* P, float* ws, hipStream_t s);

@@ -187,6 +187,9 @@ Plan::~Plan() {
 // the tests set 0 so that small plans run the backward form on every level (udet_debug_upb_min_pixels)
 static long g_upb_bwd_min = 8192;
 void plan_debug_upb_min_pixels(long v) { g_upb_bwd_min = v < 0 ? 8192 : v; }
+static long g_knob[UDET_KNOB_COUNT] = {};
+void plan_debug_knob(int id, long v) { if (id >= 0 && id < UDET_KNOB_COUNT) g_knob[id] = v; }
+long plan_knob(int id) { return id >= 0 && id < UDET_KNOB_COUNT ? g_knob[id] : 0; }
 
 // Segments and tap tables of the recover decoder's up-conv algebra for a low-resolution source of h x w (plan_exec.hip has the algebra).
 // Merge rows that are all zero in a variant (0 interior, 1 last row / column) carry no tap.
@@ -471,7 +474,8 @@ Plan* plan_build(const Config& cfg) {
           L.upb_split = d.cout <= 16;
           L.src = src;
           L.xhat = P->add_buf(S("rec.p%d", k + 1), N, hs[k + 1] + 2, wsz[k + 1] + 2, ldsrc);
-          P->add_buf(S("rec.d.p%d", k + 1), N, hs[k + 1] + 2, wsz[k + 1] + 2, ldsrc);
+          // (the ringed gradient grid exists only where the level's backward-data pass takes the low-resolution form)
+          if (L.upb_bwd) P->add_buf(S("rec.d.p%d", k + 1), N, hs[k + 1] + 2, wsz[k + 1] + 2, ldsrc);
           build_upb_launches(L, hs[k + 1], wsz[k + 1]);
         }
         P->rec.push_back(L);
@@ -550,12 +554,15 @@ Plan* plan_build(const Config& cfg) {
     }
     if (L.upb) {  // four weight sets back to back each way (a tap's widx = set * 36 + class * 9 + merged tap), the two tap tables
       L.wupb_off = off; off = align64(off + (size_t)4 * 36 * L.Kc * L.ldw);
-      L.wupbT_off = off; off = align64(off + (size_t)4 * 36 * L.KcT * L.ldwT);
       L.upb_f.tab_off = off; off = align64(off + L.upb_f.taps.size() * (sizeof(ConvTap) / sizeof(float)));
-      L.upb_b.tab_off = off; off = align64(off + L.upb_b.taps.size() * (sizeof(ConvTap) / sizeof(float)));
+      if (L.upb_bwd) {  // (a forward-only level reads neither the transposed sets nor the backward table)
+        L.wupbT_off = off; off = align64(off + (size_t)4 * 36 * L.KcT * L.ldwT);
+        L.upb_b.tab_off = off; off = align64(off + L.upb_b.taps.size() * (sizeof(ConvTap) / sizeof(float)));
+      }
     }
-    // Winograd operands: 3x3 stride-1 layers whose K extent is whole 8-channel stages (the tuner decides per shape whether the family runs)
-    if (L.kh == 3 && L.kw == 3 && L.stride == 1 && !L.up && !L.transposed && !L.col2im && L.cout >= 16 && L.H * L.W >= 512) {
+    // Winograd operands: 3x3 stride-1 layers whose K extent is whole 8-channel stages (the tuner decides per shape whether the family runs).
+    // Not in fp16 plans: conv_wino_ok rejects p.f16, the operands would be re-packed every step for nothing.
+    if (!cfg.conv_fp16 && L.kh == 3 && L.kw == 3 && L.stride == 1 && !L.up && !L.transposed && !L.col2im && L.cout >= 16 && L.H * L.W >= 512) {
       if (L.Kc % 8 == 0) {
         L.wino_np = conv_wino_np(L.cout);
         L.wino_off = off; off = align64(off + conv_wino_floats(L.Kc, L.cout));
@@ -589,10 +596,12 @@ Plan* plan_build(const Config& cfg) {
     P->seg_off[net] = off;
     off = align64(off + 4 * net_params(net).p.size() + 64);  // two long tables (offset, len) = 4 floats per entry
   }
-  for (int net = 1; net <= 2; ++net) {  // PackJob tables: <= 8 jobs per layer (+ 8 for each of the three up-conv decoder levels: inside the slack)
+  for (int net = 1; net <= 2; ++net) {  // PackJob tables: UDET_PACKJOB_CAP(layers) entries -- an ordinary layer has at most 6 jobs (forward, transposed,
+                                        // taps-into-N | the two NN x2 sets, the two Winograd operands, bias), each of the up to four up-conv decoder
+                                        // levels 8 more (four forward + four backward-data weight sets); plan_init_workspace checks the count
     const size_t nl = net == NET_GEN ? P->gen.size() : P->rec.size();
     P->jobs_off[net] = off;
-    off = align64(off + (8 * nl + 32) * (sizeof(PackJob) / sizeof(float)) + 64);
+    off = align64(off + UDET_PACKJOB_CAP(nl) * (sizeof(PackJob) / sizeof(float)) + 64);
   }
   P->arena_floats = off;
   // UDET_SERIAL=1 (read once, here; documented in include/udet.h next to udet_plan_set_concurrent): every lane collapses onto

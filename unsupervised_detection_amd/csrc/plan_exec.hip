@@ -193,7 +193,7 @@ static void setup_up_dgrad(ConvParams& p, int N, int H, int W) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// Recover decoder, levels 1-3 (Layer::upb): legacy bilinear x2 (out[2j] = x[j], out[2j+1] = (x[j] + x[j+1]) / 2, clamped at the end;
+// Recover decoder, levels 1-4 (Layer::upb; backward-data form on the levels with enough source pixels, Layer::upb_bwd): legacy bilinear x2 (out[2j] = x[j], out[2j+1] = (x[j] + x[j+1]) / 2, clamped at the end;
 // nets.py:91-110 through tf.image.resize_bilinear) followed by the 4x4 SAME convolution (padding 1 before, 2 after) is, per output
 // parity class, a 3x3 convolution over the LOW-resolution source:
 //   even rows 2j   read u[2j-1 .. 2j+2] = (x[j-1]+x[j])/2, x[j], (x[j]+x[j+1])/2, x[j+1]      -> x[j-1], x[j], x[j+1] through E
@@ -547,6 +547,11 @@ int plan_init_workspace(Plan* P, float* ws, hipStream_t s) {
       j.src_off = (long)np.p[L.b_idx].offset; j.dst_off = (long)L.bias_f_off; j.mode = 2; j.total = L.cout;
       jobs.push_back(j);
     }
+    if (jobs.size() > UDET_PACKJOB_CAP(layers.size())) {  // (the arena reserves exactly that many entries: plan_build)
+      set_error("plan_init: %zu weight re-layout jobs for %zu layers exceed the table's %zu entries", jobs.size(), layers.size(),
+                (size_t)UDET_PACKJOB_CAP(layers.size()));
+      return UDET_ERR_ARG;
+    }
     P->njobs[net] = (int)jobs.size();
     UDET_HIP(hipMemcpyAsync(ws + P->jobs_off[net], jobs.data(), jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice, s));
     UDET_HIP(hipStreamSynchronize(s));  // `jobs` is a host temporary
@@ -554,7 +559,8 @@ int plan_init_workspace(Plan* P, float* ws, hipStream_t s) {
   for (const auto& L : P->rec)  // tap tables of the segmented launches (recover decoder's up-conv algebra)
     if (L.upb)
       for (const Layer::SegLaunch* g : {&L.upb_f, &L.upb_b})
-        UDET_HIP(hipMemcpyAsync(ws + g->tab_off, g->taps.data(), g->taps.size() * sizeof(ConvTap), hipMemcpyHostToDevice, s));
+        if (g == &L.upb_f || L.upb_bwd)
+          UDET_HIP(hipMemcpyAsync(ws + g->tab_off, g->taps.data(), g->taps.size() * sizeof(ConvTap), hipMemcpyHostToDevice, s));
   UDET_HIP(hipStreamSynchronize(s));
   P->pwc_packed = false;
   return UDET_OK;
@@ -747,8 +753,12 @@ int plan_recover_forward(Plan* P, int ncalls, float* ws, hipStream_t s, bool inp
   }
   for (int i = 0; i < 9; ++i) UDET_TRY(run_fwd(P, *find_layer(P->rec, std::string("b") + ENC_NAMES[i]), N, ws, L0));
   for (int k = 5; k >= 1; --k) {
-    UDET_TRY(rec_resize(P, k == 5 ? "rec.conv6" : S("rec.concat%d", k + 1).c_str(), S("rec.r%d", k + 1).c_str(), N, ws, s));
-    UDET_TRY(run_fwd(P, *find_layer(P->rec, S("deconv%d", k)), N, ws, L0));
+    // the up-sampled tensor rec.r{k+1}: the forward of an up-conv level (Layer::upb) reads the ringed low-resolution source instead, and
+    // nothing else in the forward or in either backward-data pass reads it -- only the level's filter gradient does, which builds it
+    // itself (rec_backward).  Inference, the generator-only schedule steps and the generator-loss pass never pay for it.
+    const Layer& dcl = *find_layer(P->rec, S("deconv%d", k));
+    if (!dcl.upb) UDET_TRY(rec_resize(P, k == 5 ? "rec.conv6" : S("rec.concat%d", k + 1).c_str(), S("rec.r%d", k + 1).c_str(), N, ws, s));
+    UDET_TRY(run_fwd(P, dcl, N, ws, L0));
     if (k < 5) {
       UDET_TRY(rec_resize(P, S("rec.flow%d", k + 1).c_str(), S("rec.rf%d", k + 1).c_str(), N, ws, s));
       UDET_TRY(run_fwd(P, *find_layer(P->rec, S("upflow%d", k)), N, ws, L0));
@@ -825,7 +835,7 @@ int plan_forward(Plan* P, const float* img1, const float* img2, int ncalls, floa
 // with_wgrad: parameter gradients into g_rec, each on lane LW right where its output gradient is final.
 // need_dfin: propagate to the b-encoder input.
 static int rec_backward(Plan* P, int N, const char* dp, bool with_wgrad, bool need_dfin, const float* w_rec, float* g_rec, float* ws,
-                        const Lane& LD, const Lane& LW) {
+                        const Lane& LD, const Lane& LW, const Lane* LAp = nullptr) {
   const Config& c = P->cfg;
   hipStream_t s = LD.s;
   const std::string pre = std::string("rec.") + dp + ".", upre = std::string("rec.u") + dp + ".";
@@ -837,6 +847,11 @@ static int rec_backward(Plan* P, int N, const char* dp, bool with_wgrad, bool ne
     order_after(P, LD, LW);
     return run_wgrad(P, L, n < 0 ? N : n, dy, is_du, w_rec, g_rec, ws, LW);
   };
+  // Encoder A's backward (shared image encoder: B samples, 8 backward-data + 9 filter-gradient launches of 12-25 us each) depends on the
+  // decoder's gradients only and touches channel segments no launch of encoder B's chain touches, so it may run as its own chain on
+  // another lane (LAp) beside encoder B's instead of inside the recover-loss pass's serial chain; joined to LD at the end.
+  const Lane LA = LAp ? *LAp : LD;
+  const bool a_own_lane = LA.s != LD.s;
   // shared encoder A (plan_rec_image_branch): its activations exist for the B images only and are identical for every
   // call, so the calls' output gradients are summed (fold) where they enter the encoder and its backward runs on B samples
   const int ncopies = N / c.batch;
@@ -867,7 +882,13 @@ static int rec_backward(Plan* P, int N, const char* dp, bool with_wgrad, bool ne
       const Buf &drf = P->buf(D_(S("rf%d", k + 1))), &dfn = P->buf(D_(S("flow%d", k + 1)));
       UDET_TRY(launch_resize_bilinear_bwd(ws + drf.off, drf.ld, 0, N, drf.h, drf.w, ws + dfn.off, dfn.ld, 0, dfn.h, dfn.w, drf.ld, 0, s));
     }
-    if (with_wgrad) UDET_TRY(wgrad(*dc, uconcat, true));
+    if (with_wgrad) {
+      if (dc->upb) {  // the filter gradient's X operand (plan_recover_forward skipped it): built on the filter-gradient lane, right here
+        order_after(P, LD, LW);
+        UDET_TRY(rec_resize(P, k == 5 ? "rec.conv6" : S("rec.concat%d", k + 1).c_str(), S("rec.r%d", k + 1).c_str(), N, ws, LW.s));
+      }
+      UDET_TRY(wgrad(*dc, uconcat, true));
+    }
     if (dc->upb_bwd) {
       UDET_TRY(run_dgrad_upb(P, *dc, N, uconcat, D_(S("p%d", k + 1)), D_(S("concat%d", k + 1)), ws, LD));
       continue;
@@ -885,6 +906,7 @@ static int rec_backward(Plan* P, int N, const char* dp, bool with_wgrad, bool ne
     UDET_TRY(launch_emit_du(ws + d6.off, ws + a6.off, ws + u6.off, (long)N * d6.h * d6.w, d6.ld, 0, d6.ld, ACT_LEAKY, LEAK, s));
   }
   // encoders, deepest first.  gradient buffers mirror the forward buffers of each conv's output / input.
+  if (a_own_lane) order_after(P, LD, LA);  // (everything the decoder wrote)
   for (int i = 8; i >= 0; --i)
     for (const char* e : {"a", "b"}) {
       // encoder A sees only the image: without parameter gradients (generator-loss pass) nothing upstream needs it
@@ -893,11 +915,17 @@ static int rec_backward(Plan* P, int N, const char* dp, bool with_wgrad, bool ne
       const int du = U_(P->buf(L->y).name.substr(4));  // dU of this layer's output (emitted by its consumer's dgrad)
       const bool shared = e[0] == 'a' && a_shared;
       const int Ne = shared ? c.batch : N;
+      const bool own = e[0] == 'a' && a_own_lane;
+      const Lane& LE = own ? LA : LD;  // this encoder's backward-data chain
+      hipStream_t se = LE.s;
       if (shared && i == 8) {  // aconv6 half of conv6: dU was emitted per call above
         const Buf& u = P->buf(du);
-        UDET_TRY(launch_fold_samples(ws + u.off, (long)c.batch * u.h * u.w, u.ld, L->y_coff, L->cout, ncopies, s));
+        UDET_TRY(launch_fold_samples(ws + u.off, (long)c.batch * u.h * u.w, u.ld, L->y_coff, L->cout, ncopies, se));
       }
-      if (with_wgrad) UDET_TRY(wgrad(*L, du, true, Ne));
+      if (with_wgrad) {
+        if (own) UDET_TRY(run_wgrad(P, *L, Ne, du, true, w_rec, g_rec, ws, LA));  // (same lane: in chain order, no event)
+        else UDET_TRY(wgrad(*L, du, true, Ne));
+      }
       if (i == 0) {
         if (e[0] == 'b' && need_dfin) UDET_TRY(run_dgrad(P, *L, N, du, true, D_("fin"), 0, 0, -1, none, ws, LD));
         continue;
@@ -910,20 +938,21 @@ static int rec_backward(Plan* P, int N, const char* dp, bool with_wgrad, bool ne
       em.ubuf = U_(xname.substr(4)); em.abuf = L->x; em.c0 = 0; em.c1 = L->cin; em.act = ACT_LEAKY; em.alpha = LEAK;
       if (shared && slab_in) {  // the decoder's gradient of this skip segment, summed over the calls
         const Buf& d = P->buf(dx);
-        UDET_TRY(launch_fold_samples(ws + d.off, (long)c.batch * d.h * d.w, d.ld, L->x_coff, L->cin, ncopies, s));
+        UDET_TRY(launch_fold_samples(ws + d.off, (long)c.batch * d.h * d.w, d.ld, L->x_coff, L->cin, ncopies, se));
       }
-      UDET_TRY(run_dgrad(P, *L, Ne, du, true, dx, L->x_coff, slab_in ? 1 : 0, -1, em, ws, LD));
+      UDET_TRY(run_dgrad(P, *L, Ne, du, true, dx, L->x_coff, slab_in ? 1 : 0, -1, em, ws, LE));
     }
+  if (a_own_lane) order_after(P, LA, LD);
   return UDET_OK;
 }
 
 // d recover_loss / d FlownetS  (loss_utils.py:18; adversarial_learner.py:230-234)
-static int backward_recover(Plan* P, const float* w_rec, float* g_rec, float* ws, const Lane& LD, const Lane& LW) {
+static int backward_recover(Plan* P, const float* w_rec, float* g_rec, float* ws, const Lane& LD, const Lane& LW, const Lane* LA = nullptr) {
   const Config& c = P->cfg;
   const long BHW = (long)c.batch * c.img_h * c.img_w;
   UDET_TRY(launch_rec_loss_bwd(ws + P->buf(P->bid("flow")).off, ws + P->buf(P->bid("mask")).off, ws + P->buf(P->bid("pred")).off,
                                ws + P->buf(P->bid("d.pred")).off, BHW, c.cbn, 1.0f / (float)(c.img_w * c.img_h * c.batch), LD.s));
-  return rec_backward(P, 3 * c.batch, "d", true, false, w_rec, g_rec, ws, LD, LW);
+  return rec_backward(P, 3 * c.batch, "d", true, false, w_rec, g_rec, ws, LD, LW, LA);
 }
 
 // d generator_loss / d MaskNet  (adversarial_learner.py:224-228): through recover calls 1 and 2 (data gradient only,
@@ -982,7 +1011,9 @@ int plan_backward(Plan* P, int which, const float* w_gen, const float* w_rec, fl
   };
   if (which == 3) {
     order_after(P, L0, L1);
-    UDET_TRY(backward_recover(P, w_rec, g_rec, ws, L0, L2));
+    const int la = (int)plan_knob(UDET_KNOB_ENC_A_LANE);
+    const Lane LA = lane_of(P, s, la > 0 && la < Plan::NLANE ? la : 0);
+    UDET_TRY(backward_recover(P, w_rec, g_rec, ws, L0, L2, la > 0 ? &LA : nullptr));
     UDET_TRY(backward_generator(P, w_gen, g_gen, ws, L1, L3));
     order_after(P, L2, L0);
     mark(NET_REC);
@@ -1017,8 +1048,13 @@ int plan_apply(Plan* P, int net, float* w, float* g, float* m, float* v, float* 
     UDET_TRY(launch_grad_absmean(g, tab, tab + np.p.size(), (int)np.p.size(), sm + 2048, 1e-5f, sm + UDET_SMALL_NOISE, s));
     flag = sm + UDET_SMALL_NOISE;
   }
-  const long t = ++P->adam_t;  // ONE optimizer object: beta powers advance on every apply (:216) -- also for an update the fp16 overflow guard
-                               // drops on the device (the host cannot know at enqueue time; one missed bias-correction step)
+  // fp16 mode: the report of this network's PREVIOUS apply is consumed first (normally long over: that apply is a whole step old).  A
+  // dropped update gives its step count back there (overflow_consume), so the count -- the shared beta powers, udet_get_adam_step,
+  // checkpoints -- equals the number of updates that really happened from the next apply on, instead of running one ahead per dropped
+  // update for good.  The host cannot know at enqueue time, so the applies enqueued between a drop and its report (at most the other
+  // network's, and this network's next) still use the advanced count: a transient of one step, not a persistent offset.
+  if (c.conv_fp16) UDET_TRY(overflow_consume(P, net, true));
+  const long t = ++P->adam_t;  // ONE optimizer object: beta powers advance on every apply (:216)
   const double lr_t = (double)c.lr * sqrt(1.0 - pow((double)c.beta2, (double)t)) / (1.0 - pow((double)c.beta1, (double)t));
   const int* skip = nullptr;
   if (c.conv_fp16) {  // overflow guard of the static fp16 gradient scale (see Plan::ovf_host)
@@ -1031,10 +1067,7 @@ int plan_apply(Plan* P, int net, float* w, float* g, float* m, float* v, float* 
   if (c.conv_fp16) {
     if (!P->ovf_host) UDET_HIP(hipHostMalloc(reinterpret_cast<void**>(&P->ovf_host), 4 * sizeof(int), hipHostMallocDefault));
     if (!P->ovf_ev[net]) UDET_HIP(hipEventCreateWithFlags(&P->ovf_ev[net], hipEventDisableTiming));
-    // the pinned slot and the event are about to be re-used: a report of this network's PREVIOUS apply that no call has looked at yet
-    // (a host that never synchronises enqueues step k + 1's apply before step k's has run) is consumed first -- that apply is at
-    // least one whole step old, the wait is normally over already
-    UDET_TRY(overflow_consume(P, net, true));
+    // (the pinned slot and the event are re-used: the previous report was consumed above)
     UDET_HIP(hipMemcpyAsync(P->ovf_host + 2 * (net - 1), skip, 2 * sizeof(int), hipMemcpyDeviceToHost, s));
     UDET_HIP(hipEventRecord(P->ovf_ev[net], s));
     P->ovf_pending[net] = true;
@@ -1049,7 +1082,10 @@ static int overflow_consume(Plan* P, int net, bool wait) {
   else if (hipEventQuery(P->ovf_ev[net]) != hipSuccess) return UDET_OK;  // still in flight: looked at by a later call
   P->ovf_pending[net] = false;
   const int n = P->ovf_host[2 * (net - 1)];
-  if (n > 0) { P->ovf_report_values += n; P->ovf_report_nets |= net; ++P->ovf_skipped; }
+  if (n > 0) {
+    P->ovf_report_values += n; P->ovf_report_nets |= net; ++P->ovf_skipped;
+    if (P->adam_t > 0) --P->adam_t;  // the dropped update did not happen: it does not count (see plan_apply)
+  }
   return UDET_OK;
 }
 

@@ -82,10 +82,23 @@ def flush_weights(st: TrainState):
     st._dirty = 0
 
 
+def _dp_active(group) -> bool:
+    """Is there a gradient exchange to do?  No process group, group=False (a process that trains alone although a group exists) or a
+    group of ONE rank: no.  UDET_DP_WORLD1=1 lifts the last shortcut: a one-rank group then issues its (trivial) collectives through
+    exactly the calls, streams and events an N-rank job uses -- how a one-GPU box executes the RCCL branch (`backend="nccl"`,
+    tests/test_bench_gpu.py::test_rccl_branch_at_world_size_one) before an 8-GPU node ever does."""
+    import os
+
+    import torch.distributed as dist
+    if group is False or not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or os.environ.get("UDET_DP_WORLD1") == "1"
+
+
 def allreduce_mean_(t: torch.Tensor, group=None, async_op=False):
     """In-place mean over the data-parallel group (no-op without an initialised process group)."""
     import torch.distributed as dist
-    if group is False or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not _dp_active(group):
         return None  # group=False: this process trains alone even though a process group exists (reference runs of the tests)
     # SUM + one in-place division on every backend (gloo has no AVG; on RCCL the extra elementwise pass over the 19 MB payload costs
     # ~10 us and keeps ONE code path that the one-GPU gloo tests execute end to end).  Every rank divides the same sum by the same
@@ -106,8 +119,7 @@ def _exchange_gradients(st: TrainState, which: int, group):
         reduced on the compute stream once the whole backward is done;  the compute stream then waits for the communication
         stream.  Both collectives are issued in the same order on every rank.
       which = REC / GEN: one collective on the compute stream over what the step computed."""
-    import torch.distributed as dist
-    if group is False or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not _dp_active(group):
         return
     e = st.engine
     if which != BOTH:
@@ -130,8 +142,7 @@ def exchange_alone(st: TrainState, group=None):
     """The collectives of a which=BOTH step with nothing to overlap with (bench.py: `allreduce_ms`): g_rec on the communication
     stream, g_gen on the compute stream, the compute stream then waits -- the streams and the order of _exchange_gradients; the
     communication stream starts behind the compute stream instead of behind the recover-gradient event."""
-    import torch.distributed as dist
-    if group is False or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not _dp_active(group):
         return
     e = st.engine
     comm = getattr(st, "_comm_stream", None)
@@ -163,10 +174,13 @@ def train_step(st: TrainState, img1, img2, which: int = BOTH, group=None, next_p
         # conv_fp16 plans: a forward / backward call that finds an overflow report of an EARLIER optimizer update (dropped on the device,
         # weights untouched) raises before it enqueues anything (include/udet.h, udet_config.conv_fp16).  Like a skipped step of dynamic
         # loss scaling: count it, say so, and issue the call again -- training continues on the unchanged weights.
+        if not getattr(e.cfg, "conv_fp16", False):  # (fp32 plans cannot raise it: no retry wrapper at all)
+            return fn(*a)
+        from ._ffi import UdetOverflow
         for _ in range(4):
             try:
                 return fn(*a)
-            except OverflowError as ex:
+            except UdetOverflow as ex:
                 st.overflow_skipped = getattr(st, "overflow_skipped", 0) + 1
                 import sys
                 print("[udet] fp16 overflow: an optimizer update was dropped (%d so far): %s" % (st.overflow_skipped, ex), file=sys.stderr)
