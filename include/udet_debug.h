@@ -25,7 +25,8 @@ void udet_debug_force_wgrad(int nsplit, int dma);
 void udet_debug_upb_min_pixels(long v);
 void udet_debug_set_tuning(int on);
 /* experiment knobs read by the plan executor at enqueue time (0 = shipped behaviour).  id 0: lane (1..5) that runs the recover net's
- * encoder-A backward chain of a which = 3 backward instead of the recover-loss pass's own stream. */
+ * encoder-A backward chain of a which = 3 backward instead of the recover-loss pass's own stream; id 1: lane that runs the filter
+ * gradients of the recover DECODER layers (default: lane 2, with the encoders'). */
 void udet_debug_knob(int id, long v);
 /* what the most recent convolution launch actually ran: family (0 plain, 1 wave-specialised, 2 LDS-DMA, 3 tile-resident,
  * 6 self-staging LDS-DMA, 7 / 8 direct kernel for two input / two output channels) | tile rows << 8 | split count << 20 | folded split-K << 28 */

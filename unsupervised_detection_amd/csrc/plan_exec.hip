@@ -835,7 +835,7 @@ int plan_forward(Plan* P, const float* img1, const float* img2, int ncalls, floa
 // with_wgrad: parameter gradients into g_rec, each on lane LW right where its output gradient is final.
 // need_dfin: propagate to the b-encoder input.
 static int rec_backward(Plan* P, int N, const char* dp, bool with_wgrad, bool need_dfin, const float* w_rec, float* g_rec, float* ws,
-                        const Lane& LD, const Lane& LW, const Lane* LAp = nullptr) {
+                        const Lane& LD, const Lane& LW, const Lane* LAp = nullptr, const Lane* LWdecp = nullptr) {
   const Config& c = P->cfg;
   hipStream_t s = LD.s;
   const std::string pre = std::string("rec.") + dp + ".", upre = std::string("rec.u") + dp + ".";
@@ -843,10 +843,15 @@ static int rec_backward(Plan* P, int N, const char* dp, bool with_wgrad, bool ne
   auto D_ = [&](const std::string& n) { return P->bid(pre + n); };
   auto U_ = [&](const std::string& n) { return P->bid(upre + n); };
   auto Lr = [&](const std::string& n) { return find_layer(P->rec, n); };
-  auto wgrad = [&](const Layer& L, int dy, bool is_du, int n = -1) -> int {
-    order_after(P, LD, LW);
-    return run_wgrad(P, L, n < 0 ? N : n, dy, is_du, w_rec, g_rec, ws, LW);
+  // (LWdec: the filter-gradient lane of the DECODER layers -- the experiment knob UDET_KNOB_REC_DEC_WGRAD_LANE may send them to another
+  // lane than the encoders'; every lane that ran one is joined to LD at the end)
+  const Lane LWdec = LWdecp ? *LWdecp : LW;
+  auto wgrad_on = [&](const Lane& lw, const Layer& L, int dy, bool is_du, int n) -> int {
+    order_after(P, LD, lw);
+    return run_wgrad(P, L, n < 0 ? N : n, dy, is_du, w_rec, g_rec, ws, lw);
   };
+  auto wgrad = [&](const Layer& L, int dy, bool is_du, int n = -1) -> int { return wgrad_on(LW, L, dy, is_du, n); };
+  auto wgrad_dec = [&](const Layer& L, int dy, bool is_du) -> int { return wgrad_on(LWdec, L, dy, is_du, -1); };
   // Encoder A's backward (shared image encoder: B samples, 8 backward-data + 9 filter-gradient launches of 12-25 us each) depends on the
   // decoder's gradients only and touches channel segments no launch of encoder B's chain touches, so it may run as its own chain on
   // another lane (LAp) beside encoder B's instead of inside the recover-loss pass's serial chain; joined to LD at the end.
@@ -874,20 +879,20 @@ static int rec_backward(Plan* P, int N, const char* dp, bool with_wgrad, bool ne
     Emit em;
     em.ubuf = uconcat; em.abuf = fl->x; em.c0 = 0; em.c1 = dc->cout; em.act = ACT_LEAKY; em.alpha = LEAK;
     UDET_TRY(run_dgrad(P, *fl, N, D_(S("flow%d", k)), false, dconcat, 0, k == 1 ? 0 : 1, -1, em, ws, LD));
-    if (with_wgrad) UDET_TRY(wgrad(*fl, D_(S("flow%d", k)), false));
+    if (with_wgrad) UDET_TRY(wgrad_dec(*fl, D_(S("flow%d", k)), false));
     if (k < 5) {
       const Layer* uf = Lr(S("upflow%d", k));
-      if (with_wgrad) UDET_TRY(wgrad(*uf, dconcat, false));  // linear layer: raw gradient
+      if (with_wgrad) UDET_TRY(wgrad_dec(*uf, dconcat, false));  // linear layer: raw gradient
       UDET_TRY(run_dgrad(P, *uf, N, dconcat, false, D_(S("rf%d", k + 1)), 0, 0, -1, none, ws, LD));
       const Buf &drf = P->buf(D_(S("rf%d", k + 1))), &dfn = P->buf(D_(S("flow%d", k + 1)));
       UDET_TRY(launch_resize_bilinear_bwd(ws + drf.off, drf.ld, 0, N, drf.h, drf.w, ws + dfn.off, dfn.ld, 0, dfn.h, dfn.w, drf.ld, 0, s));
     }
     if (with_wgrad) {
       if (dc->upb) {  // the filter gradient's X operand (plan_recover_forward skipped it): built on the filter-gradient lane, right here
-        order_after(P, LD, LW);
-        UDET_TRY(rec_resize(P, k == 5 ? "rec.conv6" : S("rec.concat%d", k + 1).c_str(), S("rec.r%d", k + 1).c_str(), N, ws, LW.s));
+        order_after(P, LD, LWdec);
+        UDET_TRY(rec_resize(P, k == 5 ? "rec.conv6" : S("rec.concat%d", k + 1).c_str(), S("rec.r%d", k + 1).c_str(), N, ws, LWdec.s));
       }
-      UDET_TRY(wgrad(*dc, uconcat, true));
+      UDET_TRY(wgrad_dec(*dc, uconcat, true));
     }
     if (dc->upb_bwd) {
       UDET_TRY(run_dgrad_upb(P, *dc, N, uconcat, D_(S("p%d", k + 1)), D_(S("concat%d", k + 1)), ws, LD));
@@ -943,21 +948,24 @@ static int rec_backward(Plan* P, int N, const char* dp, bool with_wgrad, bool ne
       UDET_TRY(run_dgrad(P, *L, Ne, du, true, dx, L->x_coff, slab_in ? 1 : 0, -1, em, ws, LE));
     }
   if (a_own_lane) order_after(P, LA, LD);
+  if (with_wgrad && LWdec.s != LW.s) order_after(P, LWdec, LD);
   return UDET_OK;
 }
 
 // d recover_loss / d FlownetS  (loss_utils.py:18; adversarial_learner.py:230-234)
-static int backward_recover(Plan* P, const float* w_rec, float* g_rec, float* ws, const Lane& LD, const Lane& LW, const Lane* LA = nullptr) {
+static int backward_recover(Plan* P, const float* w_rec, float* g_rec, float* ws, const Lane& LD, const Lane& LW, const Lane* LA = nullptr,
+                            const Lane* LWdec = nullptr) {
   const Config& c = P->cfg;
   const long BHW = (long)c.batch * c.img_h * c.img_w;
   UDET_TRY(launch_rec_loss_bwd(ws + P->buf(P->bid("flow")).off, ws + P->buf(P->bid("mask")).off, ws + P->buf(P->bid("pred")).off,
                                ws + P->buf(P->bid("d.pred")).off, BHW, c.cbn, 1.0f / (float)(c.img_w * c.img_h * c.batch), LD.s));
-  return rec_backward(P, 3 * c.batch, "d", true, false, w_rec, g_rec, ws, LD, LW, LA);
+  return rec_backward(P, 3 * c.batch, "d", true, false, w_rec, g_rec, ws, LD, LW, LA, LWdec);
 }
 
 // d generator_loss / d MaskNet  (adversarial_learner.py:224-228): through recover calls 1 and 2 (data gradient only,
 // "e" buffers), the mask, then the generator.
-static int backward_generator(Plan* P, const float* w_gen, float* g_gen, float* ws, const Lane& LD, const Lane& LW) {
+static int backward_generator(Plan* P, const float* w_gen, float* g_gen, float* ws, const Lane& LD, const Lane& LW, const Lane* LWlate = nullptr,
+                              int nlate = 0) {
   const Config& c = P->cfg;
   const int B = c.batch;
   const long HW = (long)c.img_h * c.img_w;
@@ -975,8 +983,9 @@ static int backward_generator(Plan* P, const float* w_gen, float* g_gen, float* 
     const Layer& L = P->gen[i];
     const bool has_act = L.act != ACT_NONE;
     const int dy = has_act ? B_(S("gen.u%d", i + 1)) : B_(S("gen.d%d", i + 1));
-    order_after(P, LD, LW);
-    UDET_TRY(run_wgrad(P, L, B, dy, has_act, w_gen, g_gen, ws, LW));
+    const Lane& LWi = (LWlate && i < nlate) ? *LWlate : LW;  // (experiment knob: the last `nlate` layers' filter gradients on another lane)
+    order_after(P, LD, LWi);
+    UDET_TRY(run_wgrad(P, L, B, dy, has_act, w_gen, g_gen, ws, LWi));
     if (i == 0) break;
     // skip gradients: x2 = a6 (+ d11), x1 = a3 (+ d14), x0 = a1 (+ d15)   (nets.py:29,32,33)
     int res = -1;
@@ -1013,15 +1022,26 @@ int plan_backward(Plan* P, int which, const float* w_gen, const float* w_rec, fl
     order_after(P, L0, L1);
     const int la = (int)plan_knob(UDET_KNOB_ENC_A_LANE);
     const Lane LA = lane_of(P, s, la > 0 && la < Plan::NLANE ? la : 0);
-    UDET_TRY(backward_recover(P, w_rec, g_rec, ws, L0, L2, la > 0 ? &LA : nullptr));
-    UDET_TRY(backward_generator(P, w_gen, g_gen, ws, L1, L3));
+    // The recover DECODER's filter gradients (deconv / flow / upflow of the five levels, 0.65 ms of large launches, ready from the first
+    // 0.1 ms of the pass on) run on lane 3 -- the generator's filter-gradient queue, which has nothing to do until the generator-loss pass
+    // has walked the recover net (~0.8 ms) -- instead of lane 2, which shares its hardware queue with the recover-loss pass's own
+    // backward-data chain: on one queue they executed strictly behind each other, on two the large filter-gradient launches fill the CUs the
+    // chain's many small launches leave idle.  8.89 -> 8.70 ms per step (two boxes, alternating runs); the ENCODERS' filter gradients
+    // there as well: 8.96 (they then sit in front of the generator's, which are on the step's critical tail).  profiles/NOTES.md, round 5.
+    const int lw = (int)plan_knob(UDET_KNOB_REC_DEC_WGRAD_LANE), le = (int)plan_knob(UDET_KNOB_REC_ENC_WGRAD_LANE);
+    const Lane LWD = lane_of(P, s, lw > 0 && lw < Plan::NLANE ? lw : 3);
+    const Lane LWE = lane_of(P, s, le > 0 && le < Plan::NLANE ? le : 2);
+    UDET_TRY(backward_recover(P, w_rec, g_rec, ws, L0, LWE, la > 0 ? &LA : nullptr, &LWD));
+    if (LWE.s != L2.s) order_after(P, LWE, L0);
+    const int nlate = (int)plan_knob(UDET_KNOB_GEN_WGRAD_LATE);
+    UDET_TRY(backward_generator(P, w_gen, g_gen, ws, L1, L3, nlate > 0 ? &L2 : nullptr, nlate));
     order_after(P, L2, L0);
     mark(NET_REC);
     order_after(P, L1, L0);
     order_after(P, L3, L0);
     mark(NET_GEN);
   } else if (which == 2) {
-    UDET_TRY(backward_recover(P, w_rec, g_rec, ws, L0, L2));
+    UDET_TRY(backward_recover(P, w_rec, g_rec, ws, L0, L2, nullptr, &L3));  // (decoder filter gradients on lane 3's queue, as above)
     order_after(P, L2, L0);
     mark(NET_REC);
   } else {
