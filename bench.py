@@ -154,7 +154,7 @@ def main():
                     "after the headline region; 0 skips that extra measurement")
     ap.add_argument("--ensemble-frames", type=int, default=12, help="frames of the configs[3] ensemble workload timed after the headline "
                     "region (extra field `ensemble`); 0 skips it")
-    ap.add_argument("--pmc-json", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_pmc_step.json"),
+    ap.add_argument("--pmc-json", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r05_pmc_step.json"),
                     help="PMC counters of whole steps collected offline with tools/pmc_step.py (separate rocprofv3 --pmc passes); fills "
                          "roofline.traffic with the convolution kernels' HBM bytes per step")
     args = ap.parse_args()
@@ -191,7 +191,14 @@ def main():
     # nobody to exchange with (trainer._dp_active) -- the N > 1 code path of this script, call for call: init_process_group("nccl",
     # device_id), both all-reduces on their streams, the event hand-over, allreduce_ms, destroy.  It says nothing about scaling.
     dp = world > 1 or os.environ.get("UDET_DP_WORLD1") == "1"
+    json_out = sys.stdout
     if dp:
+        # RCCL (ROCm 7) prints a version banner with printf on fd 1 when the first communicator comes up; it is flushed at process exit, i.e.
+        # BEHIND the JSON line.  The contract is ONE JSON line on stdout: keep a private handle on the real stdout for that line and point
+        # fd 1 at stderr for everything else (native libraries included).
+        sys.stdout.flush()
+        json_out = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if world == 1 and "MASTER_PORT" not in os.environ:
@@ -364,7 +371,7 @@ def main():
         if rank == 0:
             print(json.dumps({"metric": "frame-pairs/sec per adversarial step, DAVIS 480p batch4, 1/2/4/8 GPU", "value": round(pairs_per_s, 3),
                               "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-                              "ms_per_step_median": round(pct(0.5), 3), "trace_only": True, "tuned_configurations_loaded": loaded}), flush=True)
+                              "ms_per_step_median": round(pct(0.5), 3), "trace_only": True, "tuned_configurations_loaded": loaded}), file=json_out, flush=True)
         if dp:
             dist.barrier()
             dist.destroy_process_group()
@@ -551,7 +558,7 @@ def main():
                 rc = 1
         else:
             out["cpu_baseline"], out["parity_check"] = None, None
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=json_out, flush=True)
         if rc:
             print("bench.py: PARITY CHECK FAILED: %s" % json.dumps(out["parity_check"]), file=sys.stderr, flush=True)
     if dp:

@@ -5,6 +5,7 @@
 # 2. rocprofv3 kernel traces of TIMED STEPS ONLY (serial and pipelined), reduced by tools/trace_report.py
 # 3. PMC counters of whole steps in separate passes (tools/pmc_step.py; never combined with the system trace domains)
 # 4. the HBM-bound warp / cost-volume kernels and the MFMA ceiling probe
+# 5. the fp16 mode, fp32 at batch 2, the one-rank RCCL run
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/prof
@@ -26,5 +27,9 @@ cd /tmp
 python "$R/tools/pmc_step.py" --tune-cache "$O/tune.txt" --out "$O/pmc_step.json" > /dev/null 2> "$O/pmc_step.err"
 cd "$R"
 python tools/cv_bench.py > "$O/cv_bench.txt" 2>&1
+# 5. BASELINE configs[4] (fp16 convolution GEMMs, batch 2) beside fp32 at that batch; the RCCL branch at world size 1 (allreduce_ms of a one-rank group)
+python bench.py --fp16-convs --cycles 0 --ensemble-frames 0 > "$O/bench_fp16_convs.json" 2> "$O/bench_fp16.err"
+python bench.py --batch 2 --cycles 0 --ensemble-frames 0 --no-cpu-baseline > "$O/bench_fp32_batch2.json" 2> /dev/null
+UDET_DP_WORLD1=1 python bench.py --tune-cache "$O/tune.txt" --cycles 0 --ensemble-frames 0 --no-cpu-baseline > "$O/bench_rccl_world1.json" 2> "$O/bench_rccl_world1.err"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-value -o /tmp/mfma_peak tools/mfma_peak.hip 2> /dev/null && /tmp/mfma_peak > "$O/mfma_peak.txt" 2>&1
 ls -la "$O"
