@@ -348,311 +348,6 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams p, cons
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------------
-// The four output-parity classes of a stride-2 backward-data pass / transposed convolution in ONE workgroup (launch family 10).  As
-// blockIdx.z (above) every class loads its own copy of almost the same dY halo and runs a K loop of 1, 2, 2 or 4 taps -- four short
-// workgroups, each a global -> LDS round trip per channel pass for a handful of MFMAs (conv2_downsample's backward-data: 83 us for 2.7 GFLOP).
-// Here the halo tile (union of the classes' tap offsets) is staged ONCE per channel pass, the weights of all taps sit class-major in LDS,
-// and the wave walks the four classes' quads one after the other into four accumulator sets; outputs of class (py, px) land on the
-// sub-lattice (2 q + p).  Same ConvParams contract (ncls == 4, unit input stride).
-// ---------------------------------------------------------------------------------------------------------------------------------
-template <int TH, int NW>
-__global__ __launch_bounds__(256) void conv_tile4_kernel(const ConvParams p, const TileGeom g, const int cbmax) {
-  constexpr int TW = 32;
-  constexpr int TM = TH / 4;     // tile rows per wave
-  constexpr int NG = 64 / NW;    // lane groups sharing one MFMA K step
-  constexpr int NQ4 = NW / 4;    // float4s per weight row
-  constexpr int MT = TILE_MT_BIG, MW = TILE_MW_BIG;
-  extern __shared__ __attribute__((aligned(16))) float4 smem4[];
-  const int nt = p.ntaps;
-  const int PIX = g.PH * g.PW, PIXP = PIX | 1;
-  const int CB = p.Kc < cbmax ? p.Kc : cbmax, CQB = CB >> 2;
-  float4* T4 = smem4;                                   // [CQB][PIXP]
-  float4* W4 = smem4 + (size_t)CQB * PIXP;              // class-major: [cls_tap[c] * cq + c * NG + quad][NW], NG zero rows behind each class
-  int* tapoff = reinterpret_cast<int*>(W4 + ((size_t)nt * CQB + 4 * NG) * NW);  // [nt]
-  int* pixoff = tapoff + nt;                            // [PIX]
-  int* qoff = pixoff + PIX;                             // [cls_tap[c] * cq + c * 3 * NG + quad] -> float4 offset of the quad's tile row (padding: 0)
-
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int col = lane & (NW - 1), grp = lane / NW;
-  const int tiles_x = (p.OWq + TW - 1) / TW, tiles_y = (p.OHq + TH - 1) / TH;
-  const int bid = blockIdx.x;
-  const int tx = bid % tiles_x, ty = (bid / tiles_x) % tiles_y, n = bid / (tiles_x * tiles_y);
-  const int oy0 = ty * TH, ox0 = tx * TW;
-  const int n0 = blockIdx.y * NW;
-  const int iy0 = oy0 + g.min_dy, ix0 = ox0 + g.min_dx;
-  const float* xb = p.x + (size_t)n * p.H * p.W * p.ldx + p.x_coff;
-
-  for (int i = t; i < nt; i += 256) tapoff[i] = (p.taps[i].dy - g.min_dy) * g.PW + (p.taps[i].dx - g.min_dx);
-  for (int pix = t; pix < PIX; pix += 256) {
-    const int py = pix / g.PW, px = pix - py * g.PW;
-    const int iy = iy0 + py, ix = ix0 + px;
-    pixoff[pix] = ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) ? (iy * p.W + ix) * p.ldx : -1;
-  }
-
-  TileAcc<NW> acc[4][TM];
-#pragma unroll
-  for (int c = 0; c < 4; ++c)
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      if constexpr (NW == 32) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[c][i].v[r] = 0.f;
-      } else {
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[c][i].v[h][r] = 0.f;
-      }
-    }
-  int abase[TM];
-#pragma unroll
-  for (int i = 0; i < TM; ++i) abase[i] = (wave * TM + i) * g.PW + col;
-  constexpr int ahalf = 16;
-
-  float4 tv[MT];
-  float4 wv[MW][4];
-  auto cls_of = [&](int tap) { return (tap >= p.cls_tap[1]) + (tap >= p.cls_tap[2]) + (tap >= p.cls_tap[3]); };
-  auto fetch = [&](int c0, int cw) {
-    const int cq = cw >> 2, NQ = nt * cq;
-#pragma unroll
-    for (int u = 0; u < MT; ++u) {
-      const int e = t + u * 256;
-      tv[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (e < PIX * cq) {
-        const int pix = e / cq, c4 = e - pix * cq;
-        const int o = pixoff[pix];
-        if (o >= 0) tv[u] = *reinterpret_cast<const float4*>(xb + (size_t)o + c0 + c4 * 4);
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < MW; ++u) {
-      const int e = t + u * 256;
-      wv[u][0] = wv[u][1] = wv[u][2] = wv[u][3] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (e < NQ * NQ4) {
-        const int n4 = e % NQ4, q = e / NQ4;
-        const int tap = q / cq, c4 = q - tap * cq;
-        const int nn = n0 + n4 * 4;
-        if (nn < p.ldw) {
-          const float* src = p.wp + ((size_t)p.taps[tap].widx * p.Kc + c0 + c4 * 4) * p.ldw + nn;
-          wv[u][0] = *reinterpret_cast<const float4*>(src);
-          wv[u][1] = *reinterpret_cast<const float4*>(src + p.ldw);
-          wv[u][2] = *reinterpret_cast<const float4*>(src + 2 * (size_t)p.ldw);
-          wv[u][3] = *reinterpret_cast<const float4*>(src + 3 * (size_t)p.ldw);
-        }
-      }
-    }
-  };
-  auto commit = [&](int cw) {
-    const int cq = cw >> 2, NQ = nt * cq;
-#pragma unroll
-    for (int u = 0; u < MT; ++u) {
-      const int e = t + u * 256;
-      if (e < PIX * cq) {
-        const int pix = e / cq, c4 = e - pix * cq;
-        T4[(size_t)c4 * PIXP + pix] = tv[u];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < MW; ++u) {
-      const int e = t + u * 256;
-      if (e < NQ * NQ4) {
-        const int n4 = e % NQ4, q = e / NQ4;
-        const int tap = q / cq;
-        float4* d = W4 + (size_t)(q + cls_of(tap) * NG) * NW + n4 * 4;
-        d[0] = make_float4(wv[u][0].x, wv[u][1].x, wv[u][2].x, wv[u][3].x);
-        d[1] = make_float4(wv[u][0].y, wv[u][1].y, wv[u][2].y, wv[u][3].y);
-        d[2] = make_float4(wv[u][0].z, wv[u][1].z, wv[u][2].z, wv[u][3].z);
-        d[3] = make_float4(wv[u][0].w, wv[u][1].w, wv[u][2].w, wv[u][3].w);
-      }
-    }
-    for (int e = t; e < 4 * NG * NW; e += 256) {  // the NG zero rows behind each class
-      const int c = e / (NG * NW), r = e - c * (NG * NW);
-      W4[(size_t)(p.cls_tap[c + 1] * cq + c * NG) * NW + r] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    for (int e = t; e < NQ + 12 * NG; e += 256) {  // class c: entries [cls_tap[c] * cq + 3 c NG, cls_tap[c + 1] * cq + 3 (c + 1) NG)
-      int c = 0;
-#pragma unroll
-      for (int k = 1; k < 4; ++k) c += e >= p.cls_tap[k] * cq + 3 * k * NG;
-      const int q = e - 3 * c * NG;  // global quad index (may run into the padding: >= the class's end)
-      int o = 0;
-      if (q < p.cls_tap[c + 1] * cq) {
-        const int tap = q / cq, c4 = q - tap * cq;
-        o = c4 * PIXP + tapoff[tap];
-      }
-      qoff[e] = o;
-    }
-  };
-
-  for (int c0 = -CB; c0 < p.Kc; c0 += CB) {
-    const int cw = c0 < 0 ? CB : (p.Kc - c0 < CB ? p.Kc - c0 : CB);
-    const int cq = cw >> 2;
-    __syncthreads();
-    if (c0 >= 0) {
-      commit(cw);
-      __syncthreads();
-    }
-    if (c0 + CB < p.Kc) fetch(c0 + CB, p.Kc - (c0 + CB) < CB ? p.Kc - (c0 + CB) : CB);
-    if (c0 < 0) continue;
-    constexpr int NA = NW == 32 ? TM : 2 * TM;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int NQ = (p.cls_tap[c + 1] - p.cls_tap[c]) * cq;
-      if (NQ == 0) continue;
-      const int steps = (NQ + NG - 1) / NG;
-      const float4* Wc = W4 + (size_t)(p.cls_tap[c] * cq + c * NG) * NW;
-      const int* qc = qoff + p.cls_tap[c] * cq + 3 * c * NG;
-      int q = grp;
-      int off1 = qc[q + NG];
-      float4 b = Wc[(size_t)q * NW + col];
-      float4 a[NA];
-      {
-        const float4* ta = T4 + qc[q];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          if constexpr (NW == 32) {
-            a[i] = ta[abase[i]];
-          } else {
-            a[2 * i] = ta[abase[i]];
-            a[2 * i + 1] = ta[abase[i] + ahalf];
-          }
-        }
-      }
-      for (int j = 0; j < steps; ++j) {
-        float4 bn = b, an[NA];
-#pragma unroll
-        for (int i = 0; i < NA; ++i) an[i] = a[i];
-        int off2 = 0;
-        if (j + 1 < steps) {  // uniform
-          q += NG;
-          off2 = qc[q + NG];
-          bn = Wc[(size_t)q * NW + col];
-          const float4* ta = T4 + off1;
-#pragma unroll
-          for (int i = 0; i < TM; ++i) {
-            if constexpr (NW == 32) {
-              an[i] = ta[abase[i]];
-            } else {
-              an[2 * i] = ta[abase[i]];
-              an[2 * i + 1] = ta[abase[i] + ahalf];
-            }
-          }
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          if constexpr (NW == 32) {
-            acc[c][i].v = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b.x, acc[c][i].v, 0, 0, 0);
-            acc[c][i].v = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b.y, acc[c][i].v, 0, 0, 0);
-            acc[c][i].v = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b.z, acc[c][i].v, 0, 0, 0);
-            acc[c][i].v = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b.w, acc[c][i].v, 0, 0, 0);
-          } else {
-            acc[c][i].v[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2 * i].x, b.x, acc[c][i].v[0], 0, 0, 0);
-            acc[c][i].v[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2 * i + 1].x, b.x, acc[c][i].v[1], 0, 0, 0);
-            acc[c][i].v[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2 * i].y, b.y, acc[c][i].v[0], 0, 0, 0);
-            acc[c][i].v[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2 * i + 1].y, b.y, acc[c][i].v[1], 0, 0, 0);
-            acc[c][i].v[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2 * i].z, b.z, acc[c][i].v[0], 0, 0, 0);
-            acc[c][i].v[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2 * i + 1].z, b.z, acc[c][i].v[1], 0, 0, 0);
-            acc[c][i].v[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2 * i].w, b.w, acc[c][i].v[0], 0, 0, 0);
-            acc[c][i].v[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2 * i + 1].w, b.w, acc[c][i].v[1], 0, 0, 0);
-          }
-        }
-        __builtin_amdgcn_sched_group_barrier(0x100, NA + 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NA, 0);
-        b = bn;
-#pragma unroll
-        for (int i = 0; i < NA; ++i) a[i] = an[i];
-        off1 = off2;
-      }
-    }
-  }
-
-  const int nn = n0 + col;
-  if (nn >= p.Cout) return;
-  const bool plain = !p.y2 && !p.res && !p.accumulate && !p.uo;
-  const float bias = p.bias ? p.bias[nn] : 0.f;
-#pragma unroll
-  for (int c = 0; c < 4; ++c) {
-    const int ooy = c >> 1, oox = c & 1;
-    auto rows = [&](auto&& emit) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const int oy = oy0 + wave * TM + i;
-        if (oy >= p.OHq) continue;
-        const int row = (n * p.OH + oy * p.osy + ooy) * p.OW + oox;  // output pixel index of ox = 0
-        if constexpr (NW == 32) {
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int ox = ox0 + (r & 3) + 8 * (r >> 2) + 4 * grp;
-            if (ox < p.OWq) emit(row, ox, acc[c][i].v[r]);
-          }
-        } else {
-#pragma unroll
-          for (int h = 0; h < 2; ++h)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const int ox = ox0 + h * 16 + grp * 4 + r;
-              if (ox < p.OWq) emit(row, ox, acc[c][i].v[h][r]);
-            }
-        }
-      }
-    };
-    if (plain) {
-      float* ycol = p.y + p.y_coff + nn;
-      const int xstep = p.osx * p.ldy;
-      rows([&](int row, int ox, float v) { ycol[(size_t)row * p.ldy + (size_t)ox * xstep] = act_fwd(v + bias, p.act, p.alpha); });
-    } else {
-      rows([&](int row, int ox, float v) { tile_epilogue(p, row + ox * p.osx, nn, v); });
-    }
-  }
-}
-
-// eligibility + LDS bytes of the merged-class kernel (0: not eligible); fills the union halo geometry
-size_t conv_tile4_lds_bytes(const ConvParams& p, int th, int cbmax, TileGeom* gout) {
-  if (p.ncls != 4 || p.nseg || p.f16 || p.ntaps < 1 || p.xa != nullptr || p.Kc % 4 != 0 || p.isy != 1 || p.isx != 1 || p.up_shift != 0) return 0;
-  if (p.osy != 2 || p.osx != 2 || (cbmax != 32 && cbmax != 16) || (th != 8 && th != 4)) return 0;
-  int mn_y = 0, mx_y = 0, mn_x = 0, mx_x = 0;
-  for (int t = 0; t < p.ntaps; ++t) {
-    if (t == 0 || p.taps[t].dy < mn_y) mn_y = p.taps[t].dy;
-    if (t == 0 || p.taps[t].dy > mx_y) mx_y = p.taps[t].dy;
-    if (t == 0 || p.taps[t].dx < mn_x) mn_x = p.taps[t].dx;
-    if (t == 0 || p.taps[t].dx > mx_x) mx_x = p.taps[t].dx;
-  }
-  TileGeom g;
-  g.min_dy = mn_y; g.min_dx = mn_x;
-  g.PH = (th - 1) + (mx_y - mn_y) + 1;
-  g.PW = 31 + (mx_x - mn_x) + 1;
-  if (gout) *gout = g;
-  const size_t cb = p.Kc < cbmax ? p.Kc : cbmax, cqb = cb / 4, pix = (size_t)g.PH * g.PW, nt = (size_t)p.ntaps, nw = p.Cout <= 16 ? 16 : 32, ng = 64 / nw;
-  if (pix * cqb > 256 * TILE_MT_BIG || nt * cqb * (nw / 4) > 256 * TILE_MW_BIG) return 0;  // per-thread register staging capacity
-  return (cqb * (pix | 1) + (nt * cqb + 4 * ng) * nw) * 16 + (nt + pix + nt * cqb + 12 * ng + 8) * sizeof(float);
-}
-bool conv_tile4_ok(const ConvParams& p, int th, int cbmax) {
-  const size_t b = conv_tile4_lds_bytes(p, th, cbmax, nullptr);
-  return b > 0 && b <= 96 * 1024;
-}
-int launch_conv_tile4(const ConvParams& p, int th, int cbmax, hipStream_t stream) {
-  TileGeom g;
-  const size_t lds = conv_tile4_lds_bytes(p, th, cbmax, &g);
-  if (lds == 0 || lds > 96 * 1024) {
-    set_error("conv_tile4: launch not eligible");
-    return UDET_ERR_UNSUPPORTED;
-  }
-  typedef void (*Kern)(const ConvParams, const TileGeom, const int);
-  static const Kern K[2][2] = {{conv_tile4_kernel<8, 32>, conv_tile4_kernel<8, 16>}, {conv_tile4_kernel<4, 32>, conv_tile4_kernel<4, 16>}};
-  static bool attr_set = false;
-  if (!attr_set) {
-    for (int a = 0; a < 2; ++a)
-      for (int b = 0; b < 2; ++b) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(K[a][b]), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-    attr_set = true;
-  }
-  const int tiles = ((p.OWq + 31) / 32) * ((p.OHq + th - 1) / th) * p.N;
-  const bool n16 = p.Cout <= 16;
-  dim3 grid(tiles, n16 ? 1 : (p.Cout + 31) / 32, 1);
-  UDET_LAUNCH(K[th == 4][n16], grid, dim3(256), lds, stream, p, g, cbmax);
-  UDET_HIP(hipGetLastError());
-  return UDET_OK;
-}
-
 // LDS bytes of the tile kernel for this launch at tile height th (0: not eligible); the maximum over the parity classes
 size_t conv_tile_lds_bytes(const ConvParams& p, int th, int cbmax, TileGeoms* gout, bool* big) {
   if (big) *big = false;
