@@ -475,37 +475,55 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const WgradParams p, 
 // device-scope stores / loads of the partial dots cost more than the launch they save.)
 #define BND_SPLIT 16
 #define BNR_MAXBLK 1024
-template <int CW>
+// SL lanes share one element (round 5): the split loop of an element is `nsplit` dependent-latency loads deep -- 256 slabs for the
+// generator's first layer, whose 6400 elements are 25 blocks: 12.6 us for 8 MB.  Lane sl sums every SL-th split (eight loads in flight),
+// the SL partials meet in LDS and are added in lane order: still one fixed summation order per split count.
+template <int CW, int SL>
 __global__ __launch_bounds__(256) void wgrad_reduce_bn_kernel(const WgradParams p, int ldn, int nsplit, int RB, float* __restrict__ pd) {
-  constexpr int RG = 256 / CW;
+  constexpr int RG = 256 / CW;   // thread rows of a block
+  constexpr int RR = RG / SL;    // element rows served at a time
+  static_assert(RR >= 1 && RR * SL == RG, "split lanes");
   __shared__ float red[256];
-  const int t = threadIdx.x, co = t % CW, rg = t / CW;
+  __shared__ float part[256];
+  const int t = threadIdx.x, co = t % CW, rg = t / CW, rr = rg / SL, sl = rg % SL;
   const int Mreal = p.ntaps * p.Cin4;
   const size_t slab = (size_t)p.Mpad * ldn;
   const int r0 = blockIdx.x * RB;
   float dot = 0.f;
-  if (co < p.Cout) {
-    const float gs = p.gamma[co] * p.bn_c;
-    for (int m = r0 + rg; m < r0 + RB && m < Mreal; m += RG) {
-      const int tap = m / p.Cin4, ci = m - tap * p.Cin4;
-      if (ci >= p.Cin) continue;
+  const float gs = co < p.Cout ? p.gamma[co] * p.bn_c : 0.f;
+  for (int mb = r0; mb < r0 + RB && mb < Mreal; mb += RR) {  // (uniform trip count: the barriers below are reached by every thread)
+    const int m = mb + rr;
+    const int tap = m / p.Cin4, ci = m - tap * p.Cin4;
+    const bool on = co < p.Cout && m < r0 + RB && m < Mreal && ci < p.Cin;
+    float s = 0.f;
+    if (on) {
       const float* src = p.partial + (size_t)m * ldn + co;
-      float s = 0.f;
-      int k = 0;
-      for (; k + 7 < nsplit; k += 8) {
+      int k = sl;
+      for (; k + 7 * SL < nsplit; k += 8 * SL) {
         float a[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) a[u] = src[(size_t)(k + u) * slab];
+        for (int u = 0; u < 8; ++u) a[u] = src[(size_t)(k + u * SL) * slab];
 #pragma unroll
         for (int u = 0; u < 8; ++u) s += a[u];
       }
-      for (; k < nsplit; ++k) s += src[(size_t)k * slab];
+      for (; k < nsplit; k += SL) s += src[(size_t)k * slab];
+    }
+    if (SL > 1) {
+      part[t] = s;
+      __syncthreads();
+      if (sl == 0) {
+#pragma unroll
+        for (int u = 1; u < SL; ++u) s += part[t + u * CW];
+      }
+      __syncthreads();
+    }
+    if (on && sl == 0) {
       const size_t e = ((size_t)p.taps[tap].widx * p.Cin + ci) * p.Cout + co;
       dot = fmaf(p.w[e], s, dot);
       p.dw[e] = s * gs;
     }
   }
-  red[t] = dot;
+  red[t] = dot;  // (zero in the lanes with sl != 0)
   __syncthreads();
   if (rg == 0 && co < p.Cout) {
     float d = red[co];
@@ -514,12 +532,15 @@ __global__ __launch_bounds__(256) void wgrad_reduce_bn_kernel(const WgradParams 
     pd[(size_t)blockIdx.x * p.Cout + co] = d;
   }
 }
-// second (last) launch of the BN-folded layers: per channel, the blocks' dots in block order and the bias partials in split order
+// second (last) launch of the BN-folded layers: per channel, the blocks' dots in block order and the bias partials in split order -- both
+// spread over the eight thread groups of a block (a group sums a contiguous run, the runs are added in group order)
 __global__ __launch_bounds__(256) void wgrad_bn_finish2_kernel(const WgradParams p, int ldn, int nsplit, int nb, const float* __restrict__ pd) {
   __shared__ float red[256];
+  __shared__ float redS[256];
   const int t = threadIdx.x, cl = t & 31, rg = t >> 5, co = blockIdx.x * 32 + cl;  // 8 thread groups x 32 channels per block
   const int per = (nb + 7) / 8, b0 = rg * per, b1 = b0 + per < nb ? b0 + per : nb;
-  float d = 0.f;
+  const int pers = (nsplit + 7) / 8, k0 = rg * pers, k1 = k0 + pers < nsplit ? k0 + pers : nsplit;
+  float d = 0.f, S = 0.f;
   if (co < p.Cout) {
     int b = b0;
     for (; b + 11 < b1; b += 12) {
@@ -530,26 +551,26 @@ __global__ __launch_bounds__(256) void wgrad_bn_finish2_kernel(const WgradParams
       for (int u = 0; u < 12; ++u) d += a[u];
     }
     for (; b < b1; ++b) d += pd[(size_t)b * p.Cout + co];
-  }
-  red[t] = d;
-  __syncthreads();
-  if (rg == 0 && co < p.Cout) {
-    float dsum = red[cl];
-#pragma unroll
-    for (int g = 1; g < 8; ++g) dsum += red[g * 32 + cl];
-    float S = 0.f;
-    int k = 0;
-    for (; k + 7 < nsplit; k += 8) {
+    int k = k0;
+    for (; k + 7 < k1; k += 8) {
       float a[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) a[u] = p.pbias[(size_t)(k + u) * ldn + co];
 #pragma unroll
       for (int u = 0; u < 8; ++u) S += a[u];
     }
-    for (; k < nsplit; ++k) S += p.pbias[(size_t)k * ldn + co];
-    p.dgamma[co] = p.bn_c * (dsum + p.b[co] * S);
-    p.dbeta[co] = S;
-    p.db[co] = p.gamma[co] * p.bn_c * S;
+    for (; k < k1; ++k) S += p.pbias[(size_t)k * ldn + co];
+  }
+  red[t] = d;
+  redS[t] = S;
+  __syncthreads();
+  if (rg == 0 && co < p.Cout) {
+    float dsum = red[cl], Ssum = redS[cl];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) { dsum += red[g * 32 + cl]; Ssum += redS[g * 32 + cl]; }
+    p.dgamma[co] = p.bn_c * (dsum + p.b[co] * Ssum);
+    p.dbeta[co] = Ssum;
+    p.db[co] = p.gamma[co] * p.bn_c * Ssum;
   }
 }
 // the separate form (single-operator launches with the class-structured / operand-swapped views): dgamma's dot sum W*G per output channel
@@ -739,14 +760,22 @@ int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream) {
     else wgrad_launch<128, 32, 4, 1>(q, m_tiles, co_tiles, ns, dma, stream);
     if (fused_bn) {  // reduction + scaling + dot partials, then the one-block finish
       const int cw = g.Cout > 64 ? 128 : (g.Cout > 32 ? 64 : (g.Cout > 16 ? 32 : 16));
-      int rb = 256 / cw;  // rows per block: ONE element per thread (the reduction is latency-bound: 28 slabs 590 KB apart per element --
-                          // it needs every CU; eight rows per thread on 72 blocks took 30 us instead of 5)
+      const int rg = 256 / cw;
+      // lanes per element: the split loop is latency-bound, but only filters small enough to leave CUs idle gain from more, smaller
+      // blocks (measured: the first layer's 25 blocks 12.6 -> 5.6 us with 8 lanes; the 128-channel layers' 576 blocks 6.4 -> 10.3 us with 2)
+      int sl = ns >= 64 ? 8 : (ns >= 32 ? 4 : (ns >= 12 ? 2 : 1));
+      if (sl > rg) sl = rg;
+      while (sl > 1 && (long)((Mreal + rg - 1) / rg) * sl > 512) sl >>= 1;
+      int rb = rg / sl;  // rows per block: ONE element per SL threads (the reduction needs every CU: eight rows per thread on 72 blocks
+                         // took 30 us instead of 5)
       while ((Mreal + rb - 1) / rb > BNR_MAXBLK) rb *= 2;
       const int nb = (Mreal + rb - 1) / rb;
-      if (cw == 128) UDET_LAUNCH(wgrad_reduce_bn_kernel<128>, dim3(nb), dim3(256), 0, stream, q, ldn, ns, rb, pd);
-      else if (cw == 64) UDET_LAUNCH(wgrad_reduce_bn_kernel<64>, dim3(nb), dim3(256), 0, stream, q, ldn, ns, rb, pd);
-      else if (cw == 32) UDET_LAUNCH(wgrad_reduce_bn_kernel<32>, dim3(nb), dim3(256), 0, stream, q, ldn, ns, rb, pd);
-      else UDET_LAUNCH(wgrad_reduce_bn_kernel<16>, dim3(nb), dim3(256), 0, stream, q, ldn, ns, rb, pd);
+#define UDET_RBN(CW_, SL_) UDET_LAUNCH((wgrad_reduce_bn_kernel<CW_, SL_>), dim3(nb), dim3(256), 0, stream, q, ldn, ns, rb, pd)
+      if (cw == 128) { if (sl == 2) UDET_RBN(128, 2); else UDET_RBN(128, 1); }
+      else if (cw == 64) { if (sl == 4) UDET_RBN(64, 4); else if (sl == 2) UDET_RBN(64, 2); else UDET_RBN(64, 1); }
+      else if (cw == 32) { if (sl == 8) UDET_RBN(32, 8); else if (sl == 4) UDET_RBN(32, 4); else if (sl == 2) UDET_RBN(32, 2); else UDET_RBN(32, 1); }
+      else { if (sl == 8) UDET_RBN(16, 8); else if (sl == 4) UDET_RBN(16, 4); else if (sl == 2) UDET_RBN(16, 2); else UDET_RBN(16, 1); }
+#undef UDET_RBN
       UDET_LAUNCH(wgrad_bn_finish2_kernel, dim3((g.Cout + 31) / 32), dim3(256), 0, stream, q, ldn, ns, nb, pd);
       return;
     }
