@@ -18,8 +18,11 @@ void udet_debug_conv_fp16(int on);
 /* while on, the first single-op launch of every distinct problem shape times its candidate configurations and caches the winner
  * (what udet_autotune does for a plan); tools/conv_bench.py / wgrad_bench.py use it to measure the tuned kernels stand-alone */
 /* filter gradient: nsplit > 0 pins the number of pixel slices (clamped to the workspace capacity), dma = 0 / 1 / 2 the staging variant
- * (register-staged / LDS-DMA with a 2- / 3-stage ring; -1: as tuned); nsplit = 0 restores the tuned / heuristic choice */
+ * (register-staged / LDS-DMA with a 2- / 3-stage ring / 3: the Winograd-domain family; -1: as tuned); nsplit = 0 restores the tuned / heuristic choice */
 void udet_debug_force_wgrad(int nsplit, int dma);
+/* what the most recent filter-gradient launch ran: K slices | variant << 20 (0 register-staged, 1 / 2 LDS-DMA, 3 the Winograd-domain family of
+ * conv_wgrad_wino.hip; dma = 3 above forces it where a launch is eligible: 3x3 stride-1, whole 64-channel blocks) */
+int udet_debug_last_wgrad(void);
 /* plans created after this call: the recover decoder's backward-data pass takes the low-resolution ("up-conv algebra") form on every
  * level whose source has at least `v` pixels (batch included); v < 0 restores the default of 8192.  Tests use 0 on small plans. */
 void udet_debug_upb_min_pixels(long v);

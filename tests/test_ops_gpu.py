@@ -146,6 +146,66 @@ def test_conv2d_backward(ops, case):
         assert (dx.cpu() - gx.float()).abs().max() < tol(gx)
 
 
+# Winograd-domain filter gradient (conv_wgrad_wino.hip; udet_debug_force_wgrad(slices, 3)): n, h, w, cin, cout, dilation, K slices
+WGRAD_WINO_CASES = [
+    (2, 24, 48, 64, 64, 1, 16),       # whole strips (W / 2 = 24 tiles = three strips of eight)
+    (1, 32, 64, 128, 128, 2, 9),      # dilation 2: four sub-lattices of 16 x 32, four channel-block pairs
+    (2, 13, 21, 64, 128, 1, 5),       # odd grid: half tiles on both axes, a partly filled strip
+    (1, 41, 50, 64, 64, 3, 1000),     # dilation 3: nine sub-lattices of unequal size; more slices asked for than strips exist
+    (1, 9, 7, 64, 64, 1, 1),          # smaller than one strip, one slice
+    (3, 12, 24, 128, 64, 4, 7),       # dilation 4 on a small grid: 3 x 6 sub-lattices, mostly padding tiles
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_WINO_CASES)
+def test_filter_gradient_winograd_family(ops, case):
+    """dW and db of a 3x3 stride-1 convolution through the Winograd-domain family against float64 autograd, and against the direct
+    family on the same data; the family under test really ran."""
+    from unsupervised_detection_amd._devel import dbg
+    n, h, w, cin, cout, d, ns = case
+    x = rnd(n, h, w, cin, seed=91).double()
+    wt = rnd(3, 3, cin, cout, seed=92, scale=(2.0 / (9 * cin)) ** 0.5).double().requires_grad_(True)
+    b = rnd(cout, seed=93, scale=0.1).double().requires_grad_(True)
+    y = O.conv2d_same(x, wt, b, 1, d)
+    dy = rnd(*y.shape, seed=94).double()
+    gw, gb = torch.autograd.grad((y * dy).sum(), [wt, b])
+    xg, dyg = x.float().cuda(), dy.float().cuda()
+    try:
+        dbg.udet_debug_force_wgrad(ns, 3)
+        dw, db = ops.conv2d_backward_filter(xg, dyg, None, (3, 3), 1, d, "none", 0.0, False)
+        last = dbg.udet_debug_last_wgrad()
+        dbg.udet_debug_force_wgrad(max(1, min(ns, 8)), 1)
+        dw1, db1 = ops.conv2d_backward_filter(xg, dyg, None, (3, 3), 1, d, "none", 0.0, False)
+        last1 = dbg.udet_debug_last_wgrad()
+    finally:
+        dbg.udet_debug_force_wgrad(0, -1)
+    eligible = not (d == 4 and h == 12)  # (padding tiles beyond three times the pixels: the family declines, the direct form runs)
+    assert ((last >> 20) == 3) == eligible and (last1 >> 20) != 3
+    tol = lambda ref: 2e-4 * max(1.0, float(ref.abs().max()))
+    assert (dw.cpu() - gw.float()).abs().max() < tol(gw)
+    assert (db.cpu() - gb.float()).abs().max() < tol(gb)
+    assert (dw.cpu() - dw1.cpu()).abs().max() < 1e-4 * max(1.0, float(gw.abs().max()))
+
+
+def test_filter_gradient_winograd_family_at_the_generator_shape(ops):
+    """The family on the generator's 128 -> 128 layers' own problem (4 x 48 x 96: models/nets.py:23-31), 64 K slices x 4 channel-block pairs =
+    one workgroup per CU; reference: the float32 PyTorch-CPU weight gradient (5.4 GFLOP; float64 would take minutes)."""
+    from unsupervised_detection_amd._devel import dbg
+    n, h, w, c = 4, 48, 96, 128
+    x = rnd(n, h, w, c, seed=95)
+    dy = rnd(n, h, w, c, seed=96)
+    gw = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2).contiguous(), (c, c, 3, 3), dy.permute(0, 3, 1, 2).contiguous(), padding=1).permute(2, 3, 1, 0)
+    gb = dy.sum((0, 1, 2))
+    try:
+        dbg.udet_debug_force_wgrad(64, 3)
+        dw, db = ops.conv2d_backward_filter(x.cuda(), dy.cuda(), None, (3, 3), 1, 1, "none", 0.0, False)
+        assert (dbg.udet_debug_last_wgrad() >> 20) == 3 and (dbg.udet_debug_last_wgrad() & 0xfffff) == 64
+    finally:
+        dbg.udet_debug_force_wgrad(0, -1)
+    assert (dw.cpu() - gw).abs().max() < 2e-4 * max(1.0, float(gw.abs().max()))
+    assert (db.cpu() - gb).abs().max() < 2e-4 * max(1.0, float(gb.abs().max()))
+
+
 @pytest.mark.parametrize("n,h,w,cin,cout", [(2, 6, 10, 529, 2), (1, 12, 20, 2, 2), (1, 24, 40, 64, 32)])
 def test_conv2d_transpose(ops, n, h, w, cin, cout):
     x = rnd(n, h, w, cin, seed=13)

@@ -14,6 +14,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <type_traits>
 #include <vector>
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -233,6 +234,169 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   }
 }
 
+// VER 3: EIGHT waves, two per SIMD (conv_wino8_kernel's idea): waves 0-3 ("role 0") own position rows {1, 2} of their 32 x 32 block, waves
+// 4-7 ("role 1") rows {0, 3} -- 8 accumulators = 128 registers per wave, so that one wave multiplies while the other reads and transforms.
+// Row p of B^T d needs patch rows {0,2} {1,2} {2,1} {1,3}: role 0 reads rows 1, 2 only; row p of A dY: e0, e0 + e1, e0 - e1, -e1.
+// The output transform's row sums meet through LDS once, in the epilogue: h0 = M0 + (M1 + M2) / 2, h1 = (M1 - M2) / 2, h2 = (M1 + M2) / 2 + M3.
+template <int ABL>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void wwg8_kernel(const Prob p) {
+  extern __shared__ __attribute__((aligned(16))) float smem8[];  // 96 KB: the two staging buffers, then (aliased) the roles' exchange
+  float (*xs)[XS] = reinterpret_cast<float (*)[XS]>(smem8);
+  float (*us)[US] = reinterpret_cast<float (*)[US]>(smem8 + 2 * XS);
+  float (*xch)[6][16][64] = reinterpret_cast<float (*)[6][16][64]>(smem8);  // role 1 -> role 0: [wave tile][value][accumulator register][lane]
+  const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int role = wave >> 2, sub = wave & 3;
+  const int li = lane & 31, lh = lane >> 5;
+  const int cib = sub & 1, cob = sub >> 1;
+  const int nci = p.Cin / 64, nco = p.Cout / 64;
+  const int blk = blockIdx.x % (nci * nco), slice = blockIdx.x / (nci * nco);
+  const int ci0 = (blk % nci) * 64, co0 = (blk / nci) * 64;
+  const int s_begin = (int)((long)p.strips * slice / p.slices), s_end = (int)((long)p.strips * (slice + 1) / p.slices);
+
+  floatx16 acc[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+  constexpr int NXV = (XS / 4 + 511) / 512, NUV = US / 4 / 512;
+  float4 rx[NXV], ru[NUV];
+  auto fetch = [&](int s) {
+    int n, ty, tx0;
+    strip_pos(p, s, &n, &ty, &tx0);
+#pragma unroll
+    for (int j = 0; j < NXV; ++j) {
+      const int e = t + j * 512;
+      const int c4 = e & 15, px = (e >> 4) % XP, r = (e >> 4) / XP;
+      const int y = 2 * ty - 1 + r, x = 2 * tx0 - 1 + px;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (e < XS / 4 && y >= 0 && y < p.H && x >= 0 && x < p.W)
+        v = *reinterpret_cast<const float4*>(p.x + ((size_t)(n * p.H + y) * p.W + x) * p.Cin + ci0 + c4 * 4);
+      rx[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < NUV; ++j) {
+      const int e = t + j * 512;
+      const int c4 = e & 15, px = (e >> 4) & 15, r = e >> 8;
+      ru[j] = *reinterpret_cast<const float4*>(p.du + ((size_t)(n * p.H + 2 * ty + r) * p.W + 2 * tx0 + px) * p.Cout + co0 + c4 * 4);
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < NXV; ++j) {
+      const int e = t + j * 512;
+      if (e < XS / 4) *reinterpret_cast<float4*>(&xs[buf][e * 4]) = rx[j];
+    }
+#pragma unroll
+    for (int j = 0; j < NUV; ++j) *reinterpret_cast<float4*>(&us[buf][(t + j * 512) * 4]) = ru[j];
+  };
+
+  auto body = [&](auto ROLE) {
+    constexpr int R = decltype(ROLE)::value;
+    if (s_begin < s_end) {
+      fetch(s_begin);
+      stash(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int s = s_begin; s < s_end; ++s) {
+      const bool more = s + 1 < s_end;
+      if (more && !(ABL & 2)) fetch(s + 1);
+      const float* xb = &xs[buf][cib * 32 + li];
+      const float* ub = &us[buf][cob * 32 + li];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int j = 2 * k + lh;
+        float e[2][2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+          for (int c = 0; c < 2; ++c) e[r][c] = ub[(r * 16 + 2 * j + c) * 64];
+        float ta[4], tb[4];  // the two rows of B^T d this role owns
+        if (R == 0) {
+          float d1[4], d2[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) { d1[c] = xb[(1 * XP + 2 * j + c) * 64]; d2[c] = xb[(2 * XP + 2 * j + c) * 64]; }
+#pragma unroll
+          for (int c = 0; c < 4; ++c) { ta[c] = d1[c] + d2[c]; tb[c] = d2[c] - d1[c]; }  // rows 1, 2
+        } else {
+          float d0[4], d1[4], d2[4], d3[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            d0[c] = xb[(0 * XP + 2 * j + c) * 64]; d1[c] = xb[(1 * XP + 2 * j + c) * 64];
+            d2[c] = xb[(2 * XP + 2 * j + c) * 64]; d3[c] = xb[(3 * XP + 2 * j + c) * 64];
+          }
+#pragma unroll
+          for (int c = 0; c < 4; ++c) { ta[c] = d0[c] - d2[c]; tb[c] = d1[c] - d3[c]; }  // rows 0, 3
+        }
+        float Va[4] = {ta[0] - ta[2], ta[1] + ta[2], ta[2] - ta[1], ta[1] - ta[3]};
+        float Vb[4] = {tb[0] - tb[2], tb[1] + tb[2], tb[2] - tb[1], tb[1] - tb[3]};
+        float fa[2], fb[2];  // the two rows of A e
+        if (R == 0) { fa[0] = e[0][0] + e[1][0]; fa[1] = e[0][1] + e[1][1]; fb[0] = e[0][0] - e[1][0]; fb[1] = e[0][1] - e[1][1]; }
+        else { fa[0] = e[0][0]; fa[1] = e[0][1]; fb[0] = -e[1][0]; fb[1] = -e[1][1]; }
+        float Ea[4] = {fa[0], fa[0] + fa[1], fa[0] - fa[1], -fa[1]};
+        float Eb[4] = {fb[0], fb[0] + fb[1], fb[0] - fb[1], -fb[1]};
+        if (!(ABL & 4)) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(Va[c], Ea[c], acc[c], 0, 0, 0);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[4 + c] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vb[c], Eb[c], acc[4 + c], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) { acc[c][0] += Va[c] * Ea[c]; acc[4 + c][0] += Vb[c] * Eb[c]; }
+        }
+      }
+      if (more) stash(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+    }
+  };
+  if (role == 0) body(std::integral_constant<int, 0>());
+  else body(std::integral_constant<int, 1>());
+
+  // column (q) transform of the own two rows: z[b] = sum_q G[q][b] M[q]
+  float za[3][16], zb[3][16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    za[0][r] = acc[0][r] + 0.5f * (acc[1][r] + acc[2][r]);
+    za[1][r] = 0.5f * (acc[1][r] - acc[2][r]);
+    za[2][r] = 0.5f * (acc[1][r] + acc[2][r]) + acc[3][r];
+    zb[0][r] = acc[4][r] + 0.5f * (acc[5][r] + acc[6][r]);
+    zb[1][r] = 0.5f * (acc[5][r] - acc[6][r]);
+    zb[2][r] = 0.5f * (acc[5][r] + acc[6][r]) + acc[7][r];
+  }
+  if (role == 1) {  // rows 0 (za) and 3 (zb)
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { xch[sub][b][r][lane] = za[b][r]; xch[sub][3 + b][r][lane] = zb[b][r]; }
+  }
+  __syncthreads();
+  if (role == 1) return;
+  float* dst = p.partial + (size_t)slice * 9 * p.Cin * p.Cout;
+  if (ABL & 1) {
+    float sacc = 0.f;
+#pragma unroll
+    for (int b = 0; b < 3; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc += za[b][r] + zb[b][r] + xch[sub][b][r][lane];
+    dst[t] = sacc;
+    return;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int ci = ci0 + cib * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, co = co0 + cob * 32 + li;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const float m0 = xch[sub][b][r][lane], m3 = xch[sub][3 + b][r][lane];  // rows 0, 3 (role 1); za / zb: rows 1, 2
+      const float sm = 0.5f * (za[b][r] + zb[b][r]), df = 0.5f * (za[b][r] - zb[b][r]);
+      dst[((size_t)(0 * 3 + b) * p.Cin + ci) * p.Cout + co] = m0 + sm;
+      dst[((size_t)(1 * 3 + b) * p.Cin + ci) * p.Cout + co] = df;
+      dst[((size_t)(2 * 3 + b) * p.Cin + ci) * p.Cout + co] = sm + m3;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void wwg_reduce(const float* __restrict__ partial, float* __restrict__ dw, long n, int slices) {
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
     float s = 0.f;
@@ -276,6 +440,11 @@ int main(int argc, char** argv) {
   const int grid = blocks * slices;
   auto gemm = [&]() {
 #define WWG(V_, A_) hipLaunchKernelGGL((wwg_kernel<V_, A_>), dim3(grid), dim3(256), 0, 0, p)
+#define WWG8(A_) do { static bool once_ = false; if (!once_) { CK(hipFuncSetAttribute(reinterpret_cast<const void*>(wwg8_kernel<A_>), hipFuncAttributeMaxDynamicSharedMemorySize, 98304)); once_ = true; } hipLaunchKernelGGL((wwg8_kernel<A_>), dim3(grid), dim3(512), 98304, 0, p); } while (0)
+    if (ver == 3) {
+      if (abl == 0) WWG8(0); else if (abl == 1) WWG8(1); else if (abl == 2) WWG8(2); else if (abl == 3) WWG8(3); else if (abl == 4) WWG8(4); else WWG8(7);
+      return;
+    }
     if (ver == 1) WWG(1, 0);
     else if (abl == 0) WWG(2, 0);
     else if (abl == 1) WWG(2, 1);
@@ -294,6 +463,7 @@ int main(int argc, char** argv) {
     hipLaunchKernelGGL(wwg_reduce, dim3((int)((nw + 255) / 256)), dim3(256), 0, 0, dp, dw, (long)nw, slices);
   };
   run();
+  CK(hipGetLastError());
   CK(hipDeviceSynchronize());
   std::vector<float> hw(nw);
   CK(hipMemcpy(hw.data(), dw, nw * 4, hipMemcpyDeviceToHost));

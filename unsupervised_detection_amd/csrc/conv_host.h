@@ -38,13 +38,19 @@ void conv_tune_note_reject();
 float* tune_scratch(size_t floats, int which);
 bool tune_compare(const float* a, const float* b, size_t n, hipStream_t stream, float* diff_out, float* scale_out);
 void wgrad_set_tuning(int on);
-void wgrad_force(int nsplit, int dma);  // debug hook: nsplit > 0 pins the split count (clamped to the capacity), dma 0 / 1 / 2 the staging variant (-1: as tuned)
+// Winograd-domain filter gradient (conv_wgrad_wino.hip): eligibility of a (plain-view) launch, the slice count for `wanted` (0: one
+// workgroup per CU), the GEMM launch into conv_wgrad.hip's slab layout
+bool wgrad_wino_ok(const WgradParams& p);
+int wgrad_wino_slices(const WgradParams& p, int wanted);
+int launch_wgrad_wino(const WgradParams& q, int slices, int ldn, hipStream_t stream);
+int wgrad_last_config();  // split count | variant << 20 of the most recent launch_wgrad_T (variant 3: the Winograd-domain family)
+void wgrad_force(int nsplit, int dma);  // debug hook: nsplit > 0 pins the split count (clamped to the capacity), dma 0 / 1 / 2 the staging variant, 3 the Winograd-domain family where eligible (-1: as tuned)
 int wgrad_tuned_shapes();
 void conv_tune_dump(FILE* f);
 void conv_tune_put(unsigned long long key, int bm, int bn, int ks, int ws, int fold, int tail);
 void wgrad_tune_dump(FILE* f);
 // bumped whenever a kernel family, a tile set or a problem key changes: tuning files of another build are rejected (udet_tune_load)
-#define UDET_TUNE_ABI 4
+#define UDET_TUNE_ABI 5
 void wgrad_tune_put(unsigned long long key, int cfg);  // debugging / tuning hook: bm == 0 and ks < 0 restore the heuristics
 bool conv_setup_dgrad(ConvParams& p, int cls, int N, int H, int W, int kh, int kw, int s, int d);
 int launch_pack_weights(const float* src, float* dst, int T, int R, int C, int Kc, int ldw, int k_split, int k_gap,

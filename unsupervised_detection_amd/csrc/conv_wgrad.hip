@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <vector>
 #include "conv_host.h"
+#include "plan.h"
 
 namespace udet {
 
@@ -646,6 +647,8 @@ size_t wgrad_partial_floats_needed(int T, int Cin, int Cout) {
 }
 
 static int g_force_wsplit = 0, g_force_wdma = -1;  // test / tool hook (libudet_debug.so): pin the split count / staging variant
+static int g_wlast = 0;                             // configuration of the most recent launch_wgrad_T: split count | variant << 20 (3: Winograd family)
+int wgrad_last_config() { return g_wlast; }
 void wgrad_force(int nsplit, int dma) { g_force_wsplit = nsplit > 0 ? nsplit : 0; g_force_wdma = dma; }
 static std::unordered_map<uint64_t, int> g_wcache;  // problem shape -> split count | (LDS-DMA variant: 1 / 2 for a 2- / 3-stage ring) << 20
 static std::mutex g_wcache_mu;
@@ -749,13 +752,20 @@ int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream) {
   // BN-folded layers (generator): the slab reduction also scales and forms dgamma's dot partials, a one-block launch finishes (two launches
   // behind the GEMM; wgrad_reduce_bn_kernel above)
   const bool fused_bn = p.gamma && !g.swapped && !p.ycls && p.ntaps == T && p.Cout <= 128 && p.db && p.dgamma && p.dbeta && p.w && p.b;
+  // Winograd-domain family (conv_wgrad_wino.hip; variant 3 of the configuration word): 3x3 stride-1 layers with whole 64-channel blocks; its K
+  // slices write the same slabs, so everything behind the GEMM is shared
+  const bool wino_ok = !g.swapped && !p.ycls && !plan_knob(UDET_KNOB_NO_WGRAD_WINO) && wgrad_wino_ok(g);
   auto run = [&](int cfg) {
-    const int ns = cfg & 0xfffff;
-    const int dma = dma_ok ? (cfg >> 20) : 0;
+    int ns = cfg & 0xfffff;
+    int dma = cfg >> 20;
+    if (dma == 3 && !wino_ok) dma = 1;
+    if (dma != 3 && !dma_ok) dma = 0;
+    if (dma == 3) ns = wgrad_wino_slices(g, ns > (int)maxs ? (int)maxs : ns);
     WgradParams q = g;
     q.pbias = base;                                        // [ns][bias groups][ldn]
     q.partial = base + (size_t)ns * bgroups * ldn;        // [ns][Mpad][ldn]
-    if (bn == 128) wgrad_launch<128, 128, 2, 2>(q, m_tiles, co_tiles, ns, dma, stream);
+    if (dma == 3) (void)launch_wgrad_wino(q, ns, ldn, stream);
+    else if (bn == 128) wgrad_launch<128, 128, 2, 2>(q, m_tiles, co_tiles, ns, dma, stream);
     else if (bn == 64) wgrad_launch<128, 64, 2, 2>(q, m_tiles, co_tiles, ns, dma, stream);
     else wgrad_launch<128, 32, 4, 1>(q, m_tiles, co_tiles, ns, dma, stream);
     if (fused_bn) {  // reduction + scaling + dot partials, then the one-block finish
@@ -788,7 +798,8 @@ int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream) {
   };
   // autotuned split count (see conv_igemm.hip): kernel + reduction timed together
   {
-    const int f[] = {p.N, p.H, p.W, p.up_shift, p.Cin, p.Cout, p.ntaps, p.OH, p.OW, p.isy, p.ya ? 1 : 0, p.ldx, p.ldy, cap, dma_ok ? 1 : 0, g.swapped, p.ycls, p.f16 ? 1 : 0};
+    const int f[] = {p.N, p.H, p.W, p.up_shift, p.Cin, p.Cout, p.ntaps, p.OH, p.OW, p.isy, p.ya ? 1 : 0, p.ldx, p.ldy, cap, dma_ok ? 1 : 0, g.swapped, p.ycls, p.f16 ? 1 : 0,
+                     p.ntaps > 0 ? p.taps[0].dy : 0, p.ntaps > 0 ? p.taps[0].dx : 0};  // (the first tap's offsets: the dilation, which the Winograd family's tile grid depends on)
     uint64_t key = 1469598103934665603ull;
     for (int v : f) { key ^= (uint64_t)(uint32_t)v; key *= 1099511628211ull; }
     bool have = false;
@@ -823,6 +834,25 @@ int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream) {
           (void)hipEventElapsedTime(&ms, e0, e1);
           if (ms < best_ms) { best_ms = ms; best = cfg; }
         }
+      if (wino_ok) {  // the Winograd-domain family: one workgroup per CU and channel-block pair, or a few more / fewer slices
+        const int blocks = (g.Cin / 64) * (g.Cout / 64);
+        for (int wg : {256, 192, 384}) {
+          const int ns = wgrad_wino_slices(g, (wg + blocks - 1) / blocks);
+          if (ns < 1 || (size_t)ns > maxs) continue;
+          const int cfg = ns | (3 << 20);
+          run(cfg);
+          (void)hipEventRecord(e0, stream);
+          for (int r = 0; r < 3; ++r) run(cfg);
+          (void)hipEventRecord(e1, stream);
+          if (hipEventSynchronize(e1) != hipSuccess) continue;
+          float ms = 0.f;
+          (void)hipEventElapsedTime(&ms, e0, e1);
+          if (getenv("UDET_TUNE_LOG") && atoi(getenv("UDET_TUNE_LOG")) > 1)
+            fprintf(stderr, "[udet tune]   wgrad winograd %d slices: %.1f us against %.1f (N=%d %dx%d Cin=%d Cout=%d)\n", ns, ms / 3 * 1e3f, best_ms / 3 * 1e3f, p.N, p.OH,
+                    p.OW, p.Cin, p.Cout);
+          if (ms < best_ms * 0.97f) { best_ms = ms; best = cfg; }
+        }
+      }
       nsplit = best;
       // the winner's filter / bias gradient must equal the heuristic configuration's (see conv_igemm.hip: candidate verification)
       if (best != h) {
@@ -853,8 +883,14 @@ int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream) {
   }
   if (g_force_wsplit > 0) {
     const int ns = g_force_wsplit > cap ? cap : g_force_wsplit;
-    nsplit = ns | ((g_force_wdma >= 0 ? (dma_ok ? g_force_wdma : 0) : (nsplit >> 20)) << 20);
+    int v = g_force_wdma >= 0 ? g_force_wdma : (nsplit >> 20);
+    if (v == 3 && !wino_ok) v = dma_ok ? 1 : 0;  // (a launch the Winograd family cannot take keeps the direct form)
+    if (v != 3 && !dma_ok) v = 0;
+    nsplit = ns | (v << 20);
   }
+  if ((nsplit >> 20) == 3 && !wino_ok) nsplit = (nsplit & 0xfffff) | ((dma_ok ? 1 : 0) << 20);  // (a cached entry of another build's rules)
+  if ((nsplit >> 20) == 3) nsplit = wgrad_wino_slices(g, (nsplit & 0xfffff) > (int)maxs ? (int)maxs : (nsplit & 0xfffff)) | (3 << 20);
+  g_wlast = nsplit;
   run(nsplit);
   UDET_HIP(hipGetLastError());
   int nbw = (int)((wsz + 255) / 256);

@@ -168,7 +168,7 @@ struct Plan {
 Plan* plan_build(const Config& cfg);
 void plan_debug_upb_min_pixels(long v);  // (libudet_debug)
 // experiment knobs (libudet_debug: udet_debug_knob; tools/ only -- every knob's 0 is the shipped behaviour)
-enum { UDET_KNOB_ENC_A_LANE = 0, UDET_KNOB_REC_DEC_WGRAD_LANE = 1, UDET_KNOB_REC_ENC_WGRAD_LANE = 2, UDET_KNOB_GEN_WGRAD_LATE = 3, UDET_KNOB_COUNT = 8 };
+enum { UDET_KNOB_ENC_A_LANE = 0, UDET_KNOB_REC_DEC_WGRAD_LANE = 1, UDET_KNOB_REC_ENC_WGRAD_LANE = 2, UDET_KNOB_GEN_WGRAD_LATE = 3, UDET_KNOB_NO_WGRAD_WINO = 6, UDET_KNOB_SKIP = 7, UDET_KNOB_COUNT = 8 };
 void plan_debug_knob(int id, long v);
 long plan_knob(int id);
 

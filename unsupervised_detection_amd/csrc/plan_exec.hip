@@ -54,6 +54,14 @@ static double layer_flops(const Layer& L, int N) {
   return 2.0 * N * oh * ow * L.cout * L.cin * taps;
 }
 
+// timing-only ablation (experiment knob UDET_KNOB_SKIP, libudet_debug; results are wrong on purpose): bit 0 generator filter gradients, 1 recover
+// filter gradients, 2 generator backward-data, 3 recover backward-data, 4 PWC-Net forward, 5 generator forward, 6 recover forward
+static inline bool skip_launch(int kind, int net) {
+  const long k = plan_knob(UDET_KNOB_SKIP);
+  if (!k) return false;
+  const int bit = kind == 2 ? (net == NET_GEN ? 0 : 1) : (kind == 1 ? (net == NET_GEN ? 2 : 3) : (net == NET_PWC ? 4 : (net == NET_GEN ? 5 : 6)));
+  return (k >> bit) & 1;
+}
 // ---------------------------------------------------------------- lanes ----
 // Lane 0 is the caller's stream; lanes 1..5 are placed on the plan's candidate streams by place_lanes (lanes that share a hardware
 // queue are the same stream).  While profiling (per-kernel timing) or with UDET_SERIAL=1 every lane collapses onto the caller's
@@ -267,6 +275,7 @@ static int run_fwd_upb(Plan* P, const Layer& L, int N, float* ws, const Lane& ln
 // gradient w.r.t. the low-resolution source of an upb level: dsrc (written) from dU (`du` buffer, channels [0, KcT))
 static int run_dgrad_upb(Plan* P, const Layer& L, int N, int du, int dxhat, int dsrc, float* ws, const Lane& ln) {
   hipStream_t s = ln.s;
+  if (skip_launch(1, L.net)) return UDET_OK;
   const Buf &bu = P->buf(du), &bp = P->buf(dxhat), &bd = P->buf(dsrc);
   const int h = bd.h, w = bd.w;
   prof_begin(P, PROF_CONV_DGRAD, layer_flops(L, N) * 9.0 / 16.0, 0, s, L.name.c_str());
@@ -289,6 +298,7 @@ static int run_dgrad_upb(Plan* P, const Layer& L, int N, int du, int dxhat, int 
 
 static int run_fwd(Plan* P, const Layer& L, int N, float* ws, const Lane& ln, size_t x_extra = 0, size_t y_extra = 0) {
   hipStream_t s = ln.s;
+  if (skip_launch(0, L.net)) return UDET_OK;
   if (L.upb && x_extra == 0 && y_extra == 0) return run_fwd_upb(P, L, N, ws, ln);
   const Buf &bx = P->buf(L.x), &by = P->buf(L.y);
   const int ncls = L.transposed ? conv_dgrad_classes(2, 2 * L.H, 2 * L.W) : 1;
@@ -368,6 +378,7 @@ struct Emit {
 static int run_dgrad(Plan* P, const Layer& L, int N, int dy, bool dy_is_du, int dx, int dx_coff, int accumulate, int res,
                      const Emit& em, float* ws, const Lane& ln) {
   hipStream_t s = ln.s;
+  if (skip_launch(1, L.net)) return UDET_OK;
   const int act_buf = L.y2 >= 0 ? L.y2 : L.y;
   const Buf &bdy = P->buf(dy), &bdx = P->buf(dx), &ba = P->buf(act_buf);
   if (ba.ld != bdy.ld) {
@@ -406,6 +417,7 @@ static int run_dgrad(Plan* P, const Layer& L, int N, int dy, bool dy_is_du, int 
 
 static int run_wgrad(Plan* P, const Layer& L, int N, int dy, bool dy_is_du, const float* w_flat, float* g_flat, float* ws, const Lane& ln) {
   hipStream_t s = ln.s;
+  if (skip_launch(2, L.net)) return UDET_OK;
   const NetParams& np = net_params(L.net);
   const int act_buf = L.y2 >= 0 ? L.y2 : L.y;
   const Buf &bx = P->buf(L.x), &bdy = P->buf(dy), &ba = P->buf(act_buf);
@@ -468,6 +480,7 @@ static int run_wgrad(Plan* P, const Layer& L, int N, int dy, bool dy_is_du, cons
   }
   prof_begin(P, PROF_CONV_WGRAD, layer_flops(L, N), 0, s, L.name.c_str());
   const int rc = launch_wgrad_T(q, L.kh * L.kw, s);
+  if (P->profiling && (wgrad_last_config() >> 20) == 3) P->prof.back()->mfma_scale = 4.0 / 9.0;  // (Winograd-domain family: 16 of 36 products)
   prof_end(P, s);
   return rc;
 }
