@@ -806,7 +806,13 @@ int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream) {
     {
       std::lock_guard<std::mutex> l(g_wcache_mu);
       auto it = g_wcache.find(key);
-      if (it != g_wcache.end()) { nsplit = it->second; have = true; }
+      if (it != g_wcache.end()) {
+        // a cached entry may come from a file (udet_tune_load): only known variants, the slice count inside this launch's capacity
+        const int hv = nsplit, v = it->second >> 20, ns = it->second & 0xfffff;
+        if (v < 0 || v > 3 || ns < 1) nsplit = hv;
+        else nsplit = (v != 3 && ns > cap ? cap : ns) | (v << 20);  // (variant 3 is clamped to its strips / the workspace below)
+        have = true;
+      }
     }
     if (!have && g_wtuning) {
       static hipEvent_t e0 = nullptr, e1 = nullptr;
