@@ -75,6 +75,37 @@ def test_dp_allreduce_mean_world2_gloo():
     assert np.array_equal(res[0][2], res[1][2])  # replicas stay bit-identical after the update
 
 
+def _world1_worker(port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, ROOT)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    from unsupervised_detection_amd.trainer import _dp_active, allreduce_mean_
+    x = torch.arange(8, dtype=torch.float32)
+    os.environ.pop("UDET_DP_WORLD1", None)
+    off = _dp_active(None)
+    os.environ["UDET_DP_WORLD1"] = "1"
+    on = _dp_active(None)
+    y = x.clone()
+    allreduce_mean_(y)  # SUM over one rank, divided by one: the collective really runs
+    q.put((off, on, _dp_active(False), bool(torch.equal(x, y))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_world_size_one_exchanges_only_when_asked_to():
+    """UDET_DP_WORLD1=1 (trainer._dp_active): a one-rank group issues its collectives -- how a one-GPU box executes the RCCL branch
+    (tests/test_bench_gpu.py); without the flag a one-rank group exchanges nothing, and group=False never does."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_world1_worker, args=(29810 + os.getpid() % 150, q))
+    p.start()
+    off, on, never, same = q.get(timeout=120)
+    p.join(60)
+    assert p.exitcode == 0
+    assert off is False and on is True and never is False and same
+
+
 def _tune_worker(rank, world, port, q, tune_file):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
