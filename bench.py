@@ -93,6 +93,44 @@ def cpu_baseline(weights, i1, i2, gpu_first, reps: int, threads: int = 0, tol: f
     return base, parity
 
 
+def parity_after(gpu_after, i1, i2, steps_done, tol=None):
+    """Second parity check, on the weights the warm-up + timed steps produced: oracle forward / losses / both gradient passes on those
+    weights against what the HIP path computes from them right after the timed region (same engine, same tuned kernels)."""
+    from oracle import oracle_torch as O
+    tol = tol or PARITY_TOL
+    pp, pg, pr = ({k: v.clone() for k, v in d.items()} for d in gpu_after["weights"])
+    batch = i1.shape[0]
+
+    class C(O.Flags):
+        batch_size = batch
+    for d in (pg, pr):
+        for k in d:
+            d[k] = d[k].detach().requires_grad_(True)
+    with torch.no_grad():
+        image, flow, _ = O.prepare_inputs(pp, i1, i2, C)
+    rel = lambda a, b: float((a - b).abs().max()) / max(1e-6, float(b.abs().max()))
+    out = O.forward_from_flow(pg, pr, image, gpu_after["flow"], C)
+    res = {"after_steps": steps_done, "adam_step": gpu_after["adam_step"],
+           "weights_rel_change_since_step0": {k: float("%.3e" % v) for k, v in gpu_after["weights_rel_change"].items()},
+           "flow_rel_err": rel(gpu_after["flow"], flow),
+           "mask_max_abs_err": float((gpu_after["mask"] - out["mask"]).abs().max()),
+           "pred_rel_err": rel(gpu_after["pred"], torch.cat([out["pred"], out["pred_c"], out["pred_img"]], 0).detach()),
+           "max_rel_loss_err": max(abs(gpu_after["losses"][k] - float(out[k])) / max(1.0, abs(float(out[k]))) for k in gpu_after["losses"])}
+    # every parameter gradient of both networks: |hip - oracle| relative to max(max|ref tensor|, 1e-3 x the network's largest element)
+    worst = {}
+    for tag, loss, params, got in (("generator", out["generator"], pg, gpu_after["grads"][0]), ("recover", out["recover"], pr, gpu_after["grads"][1])):
+        ref = O.grads_of(loss, params)
+        scale = max(float(v.abs().max()) for v in ref.values())
+        worst[tag] = max(float((got[k] - ref[k]).abs().max()) / max(float(ref[k].abs().max()), 1e-3 * scale) for k in ref)
+    res["grad_max_rel_err"] = {k: float("%.3e" % v) for k, v in worst.items()}
+    res["tolerance"] = tol
+    moved = all(v > 0.0 for v in gpu_after["weights_rel_change"].values()) and gpu_after["adam_step"] >= 2 * steps_done
+    res["optimizer_ran_every_step"] = moved
+    res["ok"] = moved and all(res[k] <= tol for k in ("flow_rel_err", "mask_max_abs_err", "pred_rel_err", "max_rel_loss_err")) and \
+        all(v <= (5 * tol if tol > 1e-3 else tol) for v in worst.values())
+    return res
+
+
 def ensemble_workload(eng, frames_u8, shifts, reps):
     """BASELINE.json configs[3] (test_generator_ensemble.py:47-114, adversarial_learner.py:525-592): per frame, the four
     central crops x `shifts` temporal partners, PWC-Net + generator forward each.  The four crops are the batch of one plan.
@@ -149,6 +187,8 @@ def main():
     ap.add_argument("--tune-cache", default="", help="file of tuned configurations: loaded when it exists (no tuning pass), written otherwise")
     ap.add_argument("--trace-only", action="store_true", help="warm-up + timed steps and nothing else (for rocprofv3 kernel traces: "
                     "with --tune-cache of an earlier run the trace holds steps only)")
+    ap.add_argument("--allow-experiment-build", action="store_true", help="tools/knob_bench.py only: accept libudet_exp.so (the -DUDET_EXPERIMENT "
+                    "build with the lane / work-skipping knobs); the line then says so and its numbers are not product numbers")
     ap.add_argument("--cpu-reps", type=int, default=5)
     ap.add_argument("--cycles", type=int, default=3, help="reference-schedule cycles (1 recover step + 3 generator steps each) timed "
                     "after the headline region; 0 skips that extra measurement")
@@ -218,7 +258,18 @@ def main():
     from unsupervised_detection_amd import weights as W
     from unsupervised_detection_amd._ffi import lib
     from unsupervised_detection_amd.engine import BOTH, Engine, EngineConfig
-    from unsupervised_detection_amd.trainer import TrainState, exchange_alone, train_step
+    from unsupervised_detection_amd.trainer import TrainState, exchange_alone, flush_weights, train_step
+
+    # The work-skipping ablation mask and the lane knobs of earlier rounds are compiled out of libudet.so (csrc/plan.h: plan_knob() is a
+    # constant 0 without -DUDET_EXPERIMENT); the only build that has them exports udet_exp_knob.  A headline number from that build is
+    # refused here, so the line itself says which library produced it.
+    from unsupervised_detection_amd import _ffi as _ffi_mod
+    experiment_build = hasattr(lib, "udet_exp_knob")
+    if experiment_build and not args.allow_experiment_build:
+        raise SystemExit("bench.py: the loaded library exports udet_exp_knob (libudet_exp.so): not the release library")
+    release_library = {"file": os.path.basename(getattr(_ffi_mod, "LIB_PATH", "?")),
+                       "experiment_knobs": "PRESENT (libudet_exp.so: not a product number)" if experiment_build else "compiled out",
+                       "debug_hooks_loaded": "unsupervised_detection_amd._devel" in sys.modules}
 
     extra_streams = [torch.cuda.Stream() for _ in range(args.extra_streams)]
     for s_ in extra_streams:
@@ -309,6 +360,33 @@ def main():
     pairs_per_s = args.batch * world * args.steps / dt
     losses = eng.losses()
     stage("timed region done")
+    # Parity AFTER the timed region (the step-0 check alone does not show that the timed steps did their work): the weights the
+    # K + W steps left behind are the starting point of a second comparison with the oracle -- forward, losses and BOTH backward passes of
+    # the HIP path on them, by the very calls the timed loop makes (eng.forward / eng.backward inside train_step), against the CPU oracle on
+    # the same weights.  Also: how far the timed steps moved the weights (an optimizer that did not run leaves 0).
+    gpu_after = None
+    if w0 is not None:
+        if getattr(st, "_prefetched", None) is not None:  # (drain the pipeline: the check runs its own forward)
+            eng.forward_prefetched(3)
+            st._prefetched = None
+        torch.cuda.synchronize()
+        wa = tuple(W.as_dict(t.cpu().clone(), n) for t, n in ((st.w_pwc, W.NET_PWC), (st.w_gen, W.NET_GEN), (st.w_rec, W.NET_REC)))
+        delta = {}
+        for name, d0, d1 in (("generator", w0[1], wa[1]), ("recover", w0[2], wa[2])):
+            num = sum(float((d1[k] - d0[k]).double().pow(2).sum()) for k in d0) ** 0.5
+            den = sum(float(d0[k].double().pow(2).sum()) for k in d0) ** 0.5
+            delta[name] = num / max(den, 1e-30)
+        flush_weights(st)  # (re-layout of the networks the last step updated -- what the next train_step would do first)
+        eng.forward(img1, img2, 3)
+        g_gen_chk, g_rec_chk = torch.zeros_like(st.w_gen), torch.zeros_like(st.w_rec)
+        eng.backward(BOTH, st.w_gen, st.w_rec, g_gen_chk, g_rec_chk)
+        torch.cuda.synchronize()
+        gpu_after = {k: eng.buffer(k).cpu().clone() for k in ("image", "flow", "mask", "pred")}
+        gpu_after["losses"] = eng.losses()
+        gpu_after["grads"] = (W.as_dict(g_gen_chk.cpu(), W.NET_GEN), W.as_dict(g_rec_chk.cpu(), W.NET_REC))
+        gpu_after["weights"] = wa
+        gpu_after["weights_rel_change"] = delta
+        gpu_after["adam_step"] = int(eng.adam_step)
 
     # the gradient exchange alone, timed after the headline region: the SAME two collectives a BOTH step issues (recover gradients on
     # the communication stream, generator gradients on the compute stream, the compute stream then waits) with nothing to hide behind
@@ -417,6 +495,7 @@ def main():
         exe_flops = sum(l[3] for l in layers if l[0] < 3) * 1e9 or alg_flops
         achieved = exe_flops / (conv_ms * 1e-3) / 1e12
         mfma_flops = sum(l[5] for l in layers if l[0] < 3) * 1e9 or exe_flops
+        alg_bytes = sum(l[4] for l in layers if l[0] < 3) * 1e6  # MB column of the per-layer dump (plan_exec.hip: layer_bytes)
         wino = [l for l in layers if l[0] < 3 and l[5] < l[3] * 0.99]
         top = max((l for l in layers if l[0] < 3), key=lambda l: l[3], default=None)
         traffic, traffic_source = None, None
@@ -487,6 +566,11 @@ def main():
                     # HBM bytes from PMC counters are collected offline (tools/pmc_step.py, separate rocprofv3 --pmc passes, summaries
                     # under profiles/): the committed collection of this build, or the file given with --pmc-json; null without one
                     "traffic": traffic, "traffic_source": traffic_source,
+                    # the comparator of `traffic`: SURVEY Appendix A's per-layer figure (input + output + weights in fp32, nothing fused;
+                    # identical for a layer's forward, backward-data and backward-filter passes) summed over every convolution launch of
+                    # the step -- the executed launches (recover encoder A once) and the reference graph's
+                    "alg_bytes_per_step": int(alg_bytes), "alg_bytes_forward": int(sum(l[4] for l in layers if l[0] == 0) * 1e6),
+                    "traffic_over_algorithmic": round(traffic / alg_bytes, 3) if traffic and alg_bytes else None,
                     "launch_groups_per_step": int(conv_groups), "avg_group_ms": round(conv_ms / max(conv_groups, 1), 4),
                     "conv_ms_per_step_serial": round(conv_ms, 3),
                     # the same launch groups bracketed by hipEventRecord before / after (adds event packets + dispatch gaps)
@@ -550,11 +634,16 @@ def main():
             "reference_schedule": ref_cycle,
             "ensemble": ensemble,
             "losses": {k: round(v, 5) for k, v in losses.items()},
+            "release_library": release_library,
         }
         if w0 is not None:
             out["cpu_baseline"], out["parity_check"] = cpu_baseline(w0, img1.cpu(), img2.cpu(), gpu_first, args.cpu_reps,
                                                                     tol=2e-2 if args.fp16_convs else None)
             if not out["parity_check"]["ok"]:
+                rc = 1
+            out["parity_check_after_timed_region"] = parity_after(gpu_after, img1.cpu(), img2.cpu(), args.steps + args.warmup,
+                                                                  tol=2e-2 if args.fp16_convs else None)
+            if not out["parity_check_after_timed_region"]["ok"]:
                 rc = 1
         else:
             out["cpu_baseline"], out["parity_check"] = None, None

@@ -262,6 +262,12 @@ int udet_apply(udet_plan* plan, int net, float* w, float* g, float* m, float* v,
 /* conv_fp16 plans: synchronises the pending overflow reports and returns how many optimizer updates were dropped so far because
  * their gradients held non-finite values (0 for fp32 plans); never an error by itself */
 long udet_fp16_overflow_count(udet_plan* plan);
+/* Number of optimizer updates applied so far (ONE Adam object for both networks: shared beta powers, adversarial_learner.py:216).
+ * conv_fp16 plans: an update dropped by the overflow guard does not count.  The drop is known on the host only when the apply has
+ * run, so both calls first wait for the plan's pending overflow reports (a stream synchronisation in that mode only) and book them:
+ * the count returned -- e.g. into a checkpoint -- equals the updates that really happened, and a count set here is not decremented
+ * afterwards by the report of an apply that preceded the call.  Applies ENQUEUED between a dropped update and its report used the
+ * advanced count for their bias correction (at most the other network's apply and this network's next): a transient of one step. */
 long udet_get_adam_step(const udet_plan* plan);
 void udet_set_adam_step(udet_plan* plan, long t);
 /* pack + forward + backward + apply for `which` on one GPU (no gradient exchange) */

@@ -27,13 +27,9 @@ int udet_debug_last_wgrad(void);
  * level whose source has at least `v` pixels (batch included); v < 0 restores the default of 8192.  Tests use 0 on small plans. */
 void udet_debug_upb_min_pixels(long v);
 void udet_debug_set_tuning(int on);
-/* experiment knobs read at enqueue time (0 = shipped behaviour; tools/knob_bench.py).  id 0: lane (1..5) that runs the recover net's
- * encoder-A backward chain of a which = 3 backward instead of the recover-loss pass's own stream; id 1: lane of the recover DECODER's filter
- * gradients (shipped: lane 3); id 2: lane of the recover encoders' filter gradients (shipped: lane 2); id 3: the generator's last `v` filter
- * gradients on lane 2; id 6: the Winograd-domain filter-gradient family off; id 7: timing-only ablation mask -- whole launch categories
- * skipped, RESULTS WRONG ON PURPOSE (bit 0 generator filter gradients, 1 recover filter gradients, 2 generator backward-data, 3 recover
- * backward-data, 4 PWC-Net forward, 5 generator forward, 6 recover forward). */
-void udet_debug_knob(int id, long v);
+/* (The experiment knobs of earlier rounds -- lane choices and the work-skipping ablation mask -- are no longer reachable from any library
+ * that links against libudet.so: they are compiled out of it.  `make -C unsupervised_detection_amd/csrc exp` builds libudet_exp.so, the same
+ * sources with -DUDET_EXPERIMENT, which exports udet_exp_knob(id, value); tools/knob_bench.py is its only user.  csrc/plan.h lists the ids.) */
 /* what the most recent convolution launch actually ran: family (0 plain, 1 wave-specialised, 2 LDS-DMA, 3 tile-resident,
  * 6 self-staging LDS-DMA, 7 / 8 direct kernel for two input / two output channels) | tile rows << 8 | split count << 20 | folded split-K << 28 */
 int udet_debug_last_conv(void);

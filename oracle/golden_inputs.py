@@ -72,6 +72,21 @@ def grad_summary(g: np.ndarray):
     return np.concatenate([[np.sqrt((f * f).sum()), f.sum()], np.pad(f[:16], (0, max(0, 16 - f.size)))]).astype(np.float64)
 
 
+GRAD_SUBSET_STRIDE = 64
+
+
+def grad_subset(g: np.ndarray, name: str):
+    """Element-level part of the gradient fixtures (round 6): every 64th element of the flattened tensor, starting at a
+    per-variable offset derived from its name (so that the picks do not line up with the channel strides), or the whole tensor when it
+    has at most 4096 elements.  float32, as the reference computes them.  Tests take the same picks of their own gradient and compare
+    element by element at 1e-3 of the tensor's largest element."""
+    f = np.asarray(g, np.float32).ravel()
+    if f.size <= 4096:
+        return f.copy()
+    off = sum(name.encode()) % GRAD_SUBSET_STRIDE
+    return np.ascontiguousarray(f[off::GRAD_SUBSET_STRIDE])
+
+
 # TensorFlow's own unit-test vectors for the resize kernels (tensorflow/python/ops/image_ops_test.py, r1.13,
 # ResizeImagesTest.testResizeUpAlignCornersFalse / testResizeUpAlignCornersTrue): input [1,3,2,1], expected kernel outputs
 TF_RESIZE_FALSE = dict(

@@ -117,6 +117,25 @@ def _summaries_close(got: np.ndarray, ref: np.ndarray, tol, floor):
     assert float(np.abs(got[2:] - ref[2:]).max()) < tol * scale
 
 
+def _subsets_close(grads: dict, g, tag, tol=1e-3):
+    """Element-level check against the reference fixture (round 6): `grads` = {variable: gradient tensor}; the fixture holds every 64th
+    element of each of the reference's raw gradients (golden_inputs.grad_subset).  |got - ref| <= tol * max(max|ref tensor|, 1e-3 * the
+    network's largest gradient element) -- the criterion of the full-tensor check against the float64 oracle (test_config2_gpu)."""
+    refs = {k: np.asarray(g["rawsub/%s/%s" % (tag, k)], np.float64) for k in grads}
+    net_scale = max(float(np.abs(r).max()) for r in refs.values())
+    n = 0
+    for k, v in grads.items():
+        got = np.asarray(G.grad_subset(np.asarray(v), k), np.float64)
+        ref = refs[k]
+        assert got.shape == ref.shape, (k, got.shape, ref.shape)
+        bound = tol * max(float(np.abs(ref).max()), 1e-3 * net_scale)
+        err = float(np.abs(got - ref).max())
+        assert err <= bound, (tag, k, err, bound)
+        # the clipped gradient the optimizer sees is clip(raw) element by element (loss_utils.py:22-24)
+        n += got.size
+    return n
+
+
 def test_oracle_step_matches_reference_build_train_graph():
     g = gold("step")
     c = G.STEP_CFG
@@ -143,6 +162,7 @@ def test_oracle_step_matches_reference_build_train_graph():
         for k in grads:
             _summaries_close(G.grad_summary(grads[k].numpy()), g["rawgrad/%s/%s" % (tag, k)], 2e-3, floor)
             _summaries_close(G.grad_summary(clipped[k].numpy()), g["grad/%s/%s" % (tag, k)], 2e-3, floor)
+        assert _subsets_close({k: v.numpy() for k, v in grads.items()}, g, tag) > 1000  # element level: every 64th entry of every gradient
 
 
 class Cfg2(O.Flags):
@@ -182,6 +202,7 @@ def test_oracle_step_matches_reference_build_train_graph_at_config2():
         for k in grads:
             _summaries_close(G.grad_summary(grads[k].numpy()), g["rawgrad/%s/%s" % (tag, k)], 2e-3, floor)
             _summaries_close(G.grad_summary(clipped[k].numpy()), g["grad/%s/%s" % (tag, k)], 2e-3, floor)
+        assert _subsets_close({k: v.numpy() for k, v in grads.items()}, g, tag) > 1000  # element level: every 64th entry of every gradient
 
 
 def _flip_flags(cases):
@@ -306,6 +327,8 @@ def test_hip_step_matches_reference_build_train_graph(gpu_env):
         for k, v in d.items():
             _summaries_close(G.grad_summary(v.numpy()), g["rawgrad/%s/%s" % (tag, k)], 2e-3, floor)
             _summaries_close(G.grad_summary(v.clamp(-0.2, 0.2).numpy()), g["grad/%s/%s" % (tag, k)], 2e-3, floor)
+        # element level (round 6): every 64th element of every variable's gradient against the reference's own, 1e-3 of the tensor's scale
+        assert _subsets_close({k: v.numpy() for k, v in d.items()}, g, tag) > 1000
 
 
 @pytest.mark.gpu
@@ -349,6 +372,8 @@ def test_hip_step_matches_reference_build_train_graph_at_config2():
         for k, v in d.items():
             _summaries_close(G.grad_summary(v.numpy()), g["rawgrad/%s/%s" % (tag, k)], 2e-3, floor)
             _summaries_close(G.grad_summary(v.clamp(-0.2, 0.2).numpy()), g["grad/%s/%s" % (tag, k)], 2e-3, floor)
+        # element level (round 6): every 64th element of every variable's gradient against the reference's own, 1e-3 of the tensor's scale
+        assert _subsets_close({k: v.numpy() for k, v in d.items()}, g, tag) > 1000
 
 
 @pytest.mark.gpu

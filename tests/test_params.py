@@ -29,6 +29,23 @@ def test_library_exports_every_declared_symbol():
         assert not hasattr(_ffi.lib, n), f"libudet.so must not export the test hook {n}"
 
 
+def test_release_library_has_no_experiment_knobs():
+    """the work-skipping ablation mask (UDET_KNOB_SKIP) and the lane knobs must not be reachable in libudet.so.  They are
+    compiled out (csrc/plan.h: plan_knob() is a constant 0 without -DUDET_EXPERIMENT): no knob table, no setter, mangled or not."""
+    import subprocess
+    from unsupervised_detection_amd import _ffi
+    assert not hasattr(_ffi.lib, "udet_exp_knob")
+    nm = None
+    for tool in ("nm", "/opt/rocm/lib/llvm/bin/llvm-nm"):
+        try:
+            nm = subprocess.run([tool, "-D", "--defined-only", _ffi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+            break
+        except (OSError, subprocess.CalledProcessError):
+            continue
+    assert nm is not None, "no nm tool"
+    assert "knob" not in nm.lower(), [l for l in nm.splitlines() if "knob" in l.lower()]
+
+
 def test_tune_cache_file_round_trip(tmp_path):
     """udet_tune_save / udet_tune_load (host only): the text form of the autotuner's choices.  A line carries
     `c <key> bm bn ks ws fold tail`; the header names the build's tuning ABI and a file of another build (or anything else) is

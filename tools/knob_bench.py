@@ -1,23 +1,49 @@
 #!/usr/bin/env python3
-"""bench.py with experiment knobs of libudet_debug.so set first:  python tools/knob_bench.py 0=3 -- --steps 30 --no-cpu-baseline ...
-(knob ids: include/udet_debug.h, udet_debug_knob).  A measuring aid, not a product path."""
+"""bench.py on libudet_exp.so with experiment knobs set first:
+
+    make -C unsupervised_detection_amd/csrc exp
+    python tools/knob_bench.py 7=3 -- --steps 30 --no-cpu-baseline ...
+
+The knobs (ids: unsupervised_detection_amd/csrc/plan.h) do not exist in the release library -- plan_knob() is a constant 0 there.
+libudet_exp.so is the same sources built with -DUDET_EXPERIMENT; this script is its only user.  It swaps the library under the package's
+ctypes binding (the product loader itself has no such switch) by executing _ffi.py with the file name replaced.  A measuring aid, not
+a product path: with knob 7 the results are wrong on purpose."""
 import os
 import sys
+import types
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+
+
+def load_experiment_build():
+    pkg = os.path.join(ROOT, "unsupervised_detection_amd")
+    if not os.path.exists(os.path.join(pkg, "libudet_exp.so")):
+        raise SystemExit("libudet_exp.so is missing: make -C unsupervised_detection_amd/csrc exp")
+    import unsupervised_detection_amd  # noqa: F401  (the package itself imports nothing native)
+    path = os.path.join(pkg, "_ffi.py")
+    src = open(path).read().replace('"libudet.so"', '"libudet_exp.so"')
+    mod = types.ModuleType("unsupervised_detection_amd._ffi")
+    mod.__file__ = path
+    mod.__package__ = "unsupervised_detection_amd"
+    sys.modules[mod.__name__] = mod
+    exec(compile(src, path, "exec"), mod.__dict__)
+    import ctypes
+    mod.lib.udet_exp_knob.restype = None
+    mod.lib.udet_exp_knob.argtypes = [ctypes.c_int, ctypes.c_long]
+    return mod.lib
 
 
 def main():
     args = sys.argv[1:]
     cut = args.index("--") if "--" in args else len(args)
     knobs, rest = args[:cut], args[cut + 1:]
-    from unsupervised_detection_amd._devel import dbg
+    lib = load_experiment_build()
     for k in knobs:
         i, v = k.split("=")
-        dbg.udet_debug_knob(int(i), int(v))
+        lib.udet_exp_knob(int(i), int(v))
     import bench
-    sys.argv = [os.path.join(ROOT, "bench.py")] + rest
+    sys.argv = [os.path.join(ROOT, "bench.py")] + rest + ["--allow-experiment-build"]
     return bench.main()
 
 

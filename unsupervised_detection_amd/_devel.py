@@ -24,7 +24,5 @@ dbg.udet_debug_upb_min_pixels.restype = None
 dbg.udet_debug_upb_min_pixels.argtypes = [ctypes.c_long]
 dbg.udet_debug_set_tuning.restype = None
 dbg.udet_debug_set_tuning.argtypes = [ctypes.c_int]
-dbg.udet_debug_knob.restype = None
-dbg.udet_debug_knob.argtypes = [ctypes.c_int, ctypes.c_long]
 dbg.udet_debug_last_wgrad.restype = ctypes.c_int
 dbg.udet_debug_last_wgrad.argtypes = []

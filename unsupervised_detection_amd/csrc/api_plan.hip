@@ -70,8 +70,14 @@ long udet_fp16_overflow_count(udet_plan* h) {
   (void)plan_check_overflow(h->p, true);  // (the error text stays in udet_last_error; the count is the answer here)
   return h->p->ovf_skipped;
 }
-long udet_get_adam_step(const udet_plan* h) { return h->p->adam_t; }
-void udet_set_adam_step(udet_plan* h, long t) { h->p->adam_t = t; }
+long udet_get_adam_step(const udet_plan* h) {
+  plan_settle_adam_step(h->p);  // (fp16 mode: a dropped update still in flight gives its step back first; see udet.h)
+  return h->p->adam_t;
+}
+void udet_set_adam_step(udet_plan* h, long t) {
+  plan_settle_adam_step(h->p);  // reports of applies that preceded the restore are booked against the OLD count, not the restored one
+  h->p->adam_t = t;
+}
 
 int udet_pack_pwc(udet_plan* h, const float* w_pwc, void* ws, void* stream) {
   return plan_pack_pwc(h->p, w_pwc, (float*)ws, (hipStream_t)stream);

@@ -755,7 +755,9 @@ int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream) {
   // Winograd-domain family (conv_wgrad_wino.hip; variant 3 of the configuration word): 3x3 stride-1 layers with whole 64-channel blocks; its K
   // slices write the same slabs, so everything behind the GEMM is shared
   const bool wino_ok = !g.swapped && !p.ycls && !plan_knob(UDET_KNOB_NO_WGRAD_WINO) && wgrad_wino_ok(g);
-  auto run = [&](int cfg) {
+  // returns UDET_OK, or the Winograd-domain family's error code when its GEMM could not be launched AND the direct form that replaces
+  // it here was not wanted by the caller either (never: the fallback below always launches) -- the slabs are never reduced stale
+  auto run = [&](int cfg) -> int {
     int ns = cfg & 0xfffff;
     int dma = cfg >> 20;
     if (dma == 3 && !wino_ok) dma = 1;
@@ -764,7 +766,16 @@ int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream) {
     WgradParams q = g;
     q.pbias = base;                                        // [ns][bias groups][ldn]
     q.partial = base + (size_t)ns * bgroups * ldn;        // [ns][Mpad][ldn]
-    if (dma == 3) (void)launch_wgrad_wino(q, ns, ldn, stream);
+    if (dma == 3 && launch_wgrad_wino(q, ns, ldn, stream) != UDET_OK) {
+      // (eligibility re-check or attribute failure: no GEMM went out.  The direct variant writes the same slab layout -- with the
+      // heuristic slice count inside the capacity -- so the reduction behind it sums fresh partials, never stale workspace)
+      dma = dma_ok ? 1 : 0;
+      ns = nsplit & 0xfffff;
+      if (ns > cap) ns = cap;
+      if (ns < 1) ns = 1;
+      q.partial = base + (size_t)ns * bgroups * ldn;
+    }
+    if (dma == 3) {}
     else if (bn == 128) wgrad_launch<128, 128, 2, 2>(q, m_tiles, co_tiles, ns, dma, stream);
     else if (bn == 64) wgrad_launch<128, 64, 2, 2>(q, m_tiles, co_tiles, ns, dma, stream);
     else wgrad_launch<128, 32, 4, 1>(q, m_tiles, co_tiles, ns, dma, stream);
@@ -787,7 +798,7 @@ int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream) {
       else { if (sl == 8) UDET_RBN(16, 8); else if (sl == 4) UDET_RBN(16, 4); else if (sl == 2) UDET_RBN(16, 2); else UDET_RBN(16, 1); }
 #undef UDET_RBN
       UDET_LAUNCH(wgrad_bn_finish2_kernel, dim3((g.Cout + 31) / 32), dim3(256), 0, stream, q, ldn, ns, nb, pd);
-      return;
+      return UDET_OK;
     }
     const int sl = (ns >= 64 && total * 64 <= 262144) ? 64 : ((ns >= 8 && total * 8 <= 262144) ? 8 : 1);
     const long nbl = (total * sl + 255) / 256;
@@ -795,6 +806,7 @@ int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream) {
     if (sl == 64) UDET_LAUNCH(wgrad_reduce_kernel<64>, dim3(nb), dim3(256), 0, stream, q, ldn, ns);
     else if (sl == 8) UDET_LAUNCH(wgrad_reduce_kernel<8>, dim3(nb), dim3(256), 0, stream, q, ldn, ns);
     else UDET_LAUNCH(wgrad_reduce_kernel<1>, dim3(nb), dim3(256), 0, stream, q, ldn, ns);
+    return UDET_OK;
   };
   // autotuned split count (see conv_igemm.hip): kernel + reduction timed together
   {
@@ -897,7 +909,7 @@ int launch_wgrad_T(WgradParams& p, int T, hipStream_t stream) {
   if ((nsplit >> 20) == 3 && !wino_ok) nsplit = (nsplit & 0xfffff) | ((dma_ok ? 1 : 0) << 20);  // (a cached entry of another build's rules)
   if ((nsplit >> 20) == 3) nsplit = wgrad_wino_slices(g, (nsplit & 0xfffff) > (int)maxs ? (int)maxs : (nsplit & 0xfffff)) | (3 << 20);
   g_wlast = nsplit;
-  run(nsplit);
+  UDET_TRY(run(nsplit));
   UDET_HIP(hipGetLastError());
   int nbw = (int)((wsz + 255) / 256);
   if (nbw > 2048) nbw = 2048;

@@ -23,6 +23,8 @@
 // generator's 64- and 128-channel 3x3 layers (models/nets.py:21-33).
 #include <type_traits>
 
+#include <mutex>
+
 #include "common.h"
 #include "conv_host.h"
 
@@ -114,6 +116,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int j = 0; j < NUV; ++j) *reinterpret_cast<float4*>(&us[buf][(t + j * 512) * 4]) = ru[j];
   };
 
+  // BARRIER CONTRACT of the two role instantiations below: both are the SAME lambda, instantiated for R = 0 / 1, and every
+  // __syncthreads() in it is reached unconditionally with a trip count that depends on workgroup-uniform values only (s_begin, s_end: the
+  // K slice of blockIdx.x) -- never on R, never on a per-wave or per-lane value.  The waves of the two roles therefore execute the same
+  // NUMBER of s_barrier instructions, though at different program counters; gfx950's s_barrier counts arrivals of the workgroup's waves
+  // whatever their PC, which is what makes this legal on this target (the library is gfx950-only).  Any edit that makes a role skip or
+  // add a loop trip (an early `continue`, a role-specific strip range) deadlocks the workgroup: keep role-specific code strictly between
+  // the barriers.
   auto body = [&](auto ROLE) {
     constexpr int R = decltype(ROLE)::value;
     if (s_begin < s_end) {
@@ -266,10 +275,19 @@ int launch_wgrad_wino(const WgradParams& q, int slices, int ldn, hipStream_t str
   }
   g.slices = slices > g.strips ? g.strips : slices;
   g.ldn = ldn;
-  static bool attr = false;
-  if (!attr) {
-    UDET_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_wino8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WWG_LDS));
-    attr = true;
+  // 96 KB of dynamic LDS needs the attribute once per DEVICE (a code object is loaded per device) -- and exactly once under concurrent
+  // first launches: one once_flag per device ordinal
+  {
+    constexpr int MAXDEV = 64;
+    static std::once_flag once[MAXDEV];
+    static hipError_t attr[MAXDEV];
+    int dev = 0;
+    UDET_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= MAXDEV) { set_error("wgrad_wino: device ordinal %d out of range", dev); return UDET_ERR_ARG; }
+    std::call_once(once[dev], [&]() {
+      attr[dev] = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_wino8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WWG_LDS);
+    });
+    UDET_HIP(attr[dev]);
   }
   const int blocks = (q.Cin / 64) * (q.Cout / 64);
   UDET_LAUNCH(conv_wgrad_wino8_kernel, dim3(blocks * g.slices), dim3(512), WWG_LDS, stream, q, g);

@@ -14,7 +14,6 @@ void udet_debug_conv_fp16(int on) { conv_debug_f16(on); }
 void udet_debug_force_wgrad(int nsplit, int dma) { wgrad_force(nsplit, dma); }
 int udet_debug_last_wgrad(void) { return wgrad_last_config(); }
 void udet_debug_upb_min_pixels(long v) { plan_debug_upb_min_pixels(v); }
-void udet_debug_knob(int id, long v) { plan_debug_knob(id, v); }
 void udet_debug_set_tuning(int on) {
   conv_set_tuning(on);
   wgrad_set_tuning(on);

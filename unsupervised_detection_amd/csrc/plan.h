@@ -58,6 +58,9 @@ struct Layer {
   // Recover decoder levels 1-3 ("up-conv algebra", plan_exec.hip): legacy bilinear x2 + 4x4 convolution as four 3x3 convolutions on the
   // ringed low-resolution source `xhat`, ONE segmented launch per pass (ConvParams::nseg): weight sets {interior, last row, last column,
   // corner} back to back (forward: wupb_off, backward-data: wupbT_off), segments and device tap tables built by plan_build
+  // BUFFER CONTRACT: for a upb layer `x` (rec.r{k+1}, the up-sampled tensor) is NOT written by the forward; it is valid only between the
+  // rebuild inside rec_backward (recover-loss pass, filter-gradient lane) and the end of that level's filter gradient.  Debug dumps of it
+  // after a forward show the previous step's data; run_fwd refuses the generic path for these layers.
   bool upb = false;
   bool upb_bwd = false;      // backward-data too (the deepest level has too few low-resolution pixels to fill the chip: forward only)
   bool upb_split = false;    // forward: interior as an ordinary four-class launch + the border segments (see run_fwd_upb)
@@ -167,10 +170,22 @@ struct Plan {
 #define UDET_SMALL_SUMS 1024   // loss_sums
 Plan* plan_build(const Config& cfg);
 void plan_debug_upb_min_pixels(long v);  // (libudet_debug)
-// experiment knobs (libudet_debug: udet_debug_knob; tools/ only -- every knob's 0 is the shipped behaviour)
-enum { UDET_KNOB_ENC_A_LANE = 0, UDET_KNOB_REC_DEC_WGRAD_LANE = 1, UDET_KNOB_REC_ENC_WGRAD_LANE = 2, UDET_KNOB_GEN_WGRAD_LATE = 3, UDET_KNOB_NO_WGRAD_WINO = 6, UDET_KNOB_SKIP = 7, UDET_KNOB_COUNT = 8 };
+// Experiment knobs (tools/knob_bench.py; every knob's 0 is the shipped behaviour).  They exist ONLY in libudet_exp.so, the build of these
+// sources with -DUDET_EXPERIMENT (`make exp`): in the release library plan_knob() is a constant 0, every branch that reads a knob folds
+// away at compile time -- the work-skipping ablation mask (UDET_KNOB_SKIP) included -- and there is no setter to export.
+// id 0: lane (1..5) of the recover net's encoder-A backward chain in a which = 3 backward instead of the recover-loss pass's own stream;
+// 1: lane of the recover DECODER's filter gradients (shipped: 3); 2: lane of the recover encoders' filter gradients (shipped: 2); 3: the
+// generator's last `v` filter gradients on lane 2; 6: the Winograd-domain filter-gradient family off; 7: timing-only ablation mask -- whole
+// launch categories skipped, RESULTS WRONG ON PURPOSE (bit 0 generator filter gradients, 1 recover filter gradients, 2 generator
+// backward-data, 3 recover backward-data, 4 PWC-Net forward, 5 generator forward, 6 recover forward); 8: 1 = the recover encoders unpaired
+// (encoder A on its own launches and lane, as before round 6).
+enum { UDET_KNOB_ENC_A_LANE = 0, UDET_KNOB_REC_DEC_WGRAD_LANE = 1, UDET_KNOB_REC_ENC_WGRAD_LANE = 2, UDET_KNOB_GEN_WGRAD_LATE = 3, UDET_KNOB_NO_WGRAD_WINO = 6, UDET_KNOB_SKIP = 7, UDET_KNOB_NO_PAIRS = 8, UDET_KNOB_COUNT = 12 };
+#ifdef UDET_EXPERIMENT
 void plan_debug_knob(int id, long v);
 long plan_knob(int id);
+#else
+constexpr long plan_knob(int) { return 0; }
+#endif
 
 // execution (all asynchronous on `s`)
 int plan_init_workspace(Plan* P, float* ws, hipStream_t s);
@@ -192,6 +207,7 @@ int plan_backward(Plan* P, int which, const float* w_gen, const float* w_rec, fl
 int plan_apply(Plan* P, int net, float* w, float* g, float* m, float* v, float* ws, hipStream_t s);
 // fp16 mode: reports (once) an optimizer update that was dropped because its gradients were not finite; wait: synchronise first
 int plan_check_overflow(Plan* P, bool wait);
+void plan_settle_adam_step(Plan* P);  // fp16 mode: pending overflow reports booked into adam_t (synchronises); no error raised
 int plan_lane_queues(Plan* P, hipStream_t s, int* queue);  // places the lanes for `s` if necessary; returns the queues in use
 int plan_pin_lanes(Plan* P, hipStream_t main, hipStream_t const* streams, int n);  // host-provided layout for `main` (no probe)
 enum { PROF_CONV_FWD = 0, PROF_CONV_DGRAD = 1, PROF_CONV_WGRAD = 2, PROF_WARP = 3, PROF_CORR = 4, PROF_NCAT = 5 };

@@ -187,9 +187,12 @@ Plan::~Plan() {
 // the tests set 0 so that small plans run the backward form on every level (udet_debug_upb_min_pixels)
 static long g_upb_bwd_min = 8192;
 void plan_debug_upb_min_pixels(long v) { g_upb_bwd_min = v < 0 ? 8192 : v; }
+#ifdef UDET_EXPERIMENT  // libudet_exp.so only (plan.h): the release library has neither the table nor the setter
 static long g_knob[UDET_KNOB_COUNT] = {};
 void plan_debug_knob(int id, long v) { if (id >= 0 && id < UDET_KNOB_COUNT) g_knob[id] = v; }
 long plan_knob(int id) { return id >= 0 && id < UDET_KNOB_COUNT ? g_knob[id] : 0; }
+extern "C" void udet_exp_knob(int id, long v) { plan_debug_knob(id, v); }
+#endif
 
 // Segments and tap tables of the recover decoder's up-conv algebra for a low-resolution source of h x w (plan_exec.hip has the algebra).
 // Merge rows that are all zero in a variant (0 interior, 1 last row / column) carry no tap.

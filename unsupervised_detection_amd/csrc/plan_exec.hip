@@ -53,8 +53,19 @@ static double layer_flops(const Layer& L, int N) {
   if (L.transposed) taps /= 4.0;  // each output pixel of a k4 s2 transposed conv sees 2x2 taps
   return 2.0 * N * oh * ow * L.cout * L.cin * taps;
 }
+// algorithmic HBM bytes of the same convolution (SURVEY Appendix A's definition: input + output + weights + bias in fp32 if nothing is
+// fused; up-sampling layers count their post-resize input, as the appendix does).  The backward-data (dY, dX, W) and backward-filter
+// (X, dY, dW) passes of a layer move the same three tensors, so one figure serves all three directions.
+static double layer_bytes(const Layer& L, int N) {
+  const int up = L.up ? 1 : 0;
+  const double ih = (double)(L.H << up), iw = (double)(L.W << up);
+  double oh, ow;
+  if (L.transposed) { oh = 2.0 * L.H; ow = 2.0 * L.W; }
+  else { oh = (double)(((L.H << up) + L.stride - 1) / L.stride); ow = (double)(((L.W << up) + L.stride - 1) / L.stride); }
+  return 4.0 * (N * ih * iw * L.cin + N * oh * ow * L.cout + (double)L.kh * L.kw * L.cin * L.cout + L.cout);
+}
 
-// timing-only ablation (experiment knob UDET_KNOB_SKIP, libudet_debug; results are wrong on purpose): bit 0 generator filter gradients, 1 recover
+// timing-only ablation (experiment knob UDET_KNOB_SKIP: libudet_exp.so only, a constant false in the release build; results are wrong on purpose): bit 0 generator filter gradients, 1 recover
 // filter gradients, 2 generator backward-data, 3 recover backward-data, 4 PWC-Net forward, 5 generator forward, 6 recover forward
 static inline bool skip_launch(int kind, int net) {
   const long k = plan_knob(UDET_KNOB_SKIP);
@@ -239,7 +250,7 @@ static int run_fwd_upb(Plan* P, const Layer& L, int N, float* ws, const Lane& ln
   hipStream_t s = ln.s;
   const Buf &bs = P->buf(L.src), &bp = P->buf(L.xhat), &by = P->buf(L.y);
   const int h = bs.h, w = bs.w;
-  prof_begin(P, PROF_CONV_FWD, layer_flops(L, N) * 9.0 / 16.0, 0, s, L.name.c_str());
+  prof_begin(P, PROF_CONV_FWD, layer_flops(L, N) * 9.0 / 16.0, layer_bytes(L, N), s, L.name.c_str());
   UDET_TRY(launch_upb_ring(ws + bs.off, bs.ld, N, h, w, ws + bp.off, s));
   ConvParams p;
   memset(&p, 0, sizeof(p));
@@ -278,7 +289,7 @@ static int run_dgrad_upb(Plan* P, const Layer& L, int N, int du, int dxhat, int 
   if (skip_launch(1, L.net)) return UDET_OK;
   const Buf &bu = P->buf(du), &bp = P->buf(dxhat), &bd = P->buf(dsrc);
   const int h = bd.h, w = bd.w;
-  prof_begin(P, PROF_CONV_DGRAD, layer_flops(L, N) * 9.0 / 16.0, 0, s, L.name.c_str());
+  prof_begin(P, PROF_CONV_DGRAD, layer_flops(L, N) * 9.0 / 16.0, layer_bytes(L, N), s, L.name.c_str());
   ConvParams p;
   memset(&p, 0, sizeof(p));
   p.N = N; p.H = 2 * h; p.W = 2 * w;
@@ -300,11 +311,18 @@ static int run_fwd(Plan* P, const Layer& L, int N, float* ws, const Lane& ln, si
   hipStream_t s = ln.s;
   if (skip_launch(0, L.net)) return UDET_OK;
   if (L.upb && x_extra == 0 && y_extra == 0) return run_fwd_upb(P, L, N, ws, ln);
+  if (L.upb) {
+    // BUFFER CONTRACT (round 5 on): the forward never builds the up-sampled input `rec.r{k+1}` of an up-conv level -- Layer::x of such a
+    // layer holds whatever the last recover-loss backward left there (rec_backward rebuilds it for the filter gradient only).  The
+    // generic path below would silently convolve that stale tensor: refuse.
+    set_error("run_fwd(%s): up-conv levels run on their ringed low-resolution source only (rec.r* is not built by the forward)", L.name.c_str());
+    return UDET_ERR_UNSUPPORTED;
+  }
   const Buf &bx = P->buf(L.x), &by = P->buf(L.y);
   const int ncls = L.transposed ? conv_dgrad_classes(2, 2 * L.H, 2 * L.W) : 1;
   // (the measurement pass books the multiply-adds the launch executes: 16 of the reference's 36 tap products per low-resolution
   // pixel for the up-sampling layers)
-  prof_begin(P, PROF_CONV_FWD, layer_flops(L, N) * ((L.up && L.wu_off) ? 4.0 / 9.0 : 1.0), 0, s, L.name.c_str());
+  prof_begin(P, PROF_CONV_FWD, layer_flops(L, N) * ((L.up && L.wu_off) ? 4.0 / 9.0 : 1.0), layer_bytes(L, N), s, L.name.c_str());
   // 2-channel heads: the direct kernel (conv_thin.hip) through the ordinary launch below wherever it is eligible; otherwise
   // (fp16 mode) the GEMM + gather formulation
   bool direct_head = false;
@@ -386,7 +404,7 @@ static int run_dgrad(Plan* P, const Layer& L, int N, int dy, bool dy_is_du, int 
     return UDET_ERR_SHAPE;
   }
   const int up = L.up ? 1 : 0;
-  prof_begin(P, PROF_CONV_DGRAD, layer_flops(L, N) * ((L.up && L.wuT_off) ? 4.0 / 9.0 : 1.0), 0, s, L.name.c_str());
+  prof_begin(P, PROF_CONV_DGRAD, layer_flops(L, N) * ((L.up && L.wuT_off) ? 4.0 / 9.0 : 1.0), layer_bytes(L, N), s, L.name.c_str());
   const bool upeff = L.up && L.wuT_off;  // gradient w.r.t. the LOW-resolution input in one launch (no up-sampled gradient, no pooling)
   for (int cls = 0; cls < (upeff ? 1 : conv_dgrad_classes(L.stride, L.H << up, L.W << up)); ++cls) {
     ConvParams p;
@@ -471,14 +489,14 @@ static int run_wgrad(Plan* P, const Layer& L, int N, int dy, bool dy_is_du, cons
     const float *w_ = q.w, *b_ = q.b, *gamma_ = q.gamma;
     float *dgamma_ = q.dgamma, *dbeta_ = q.dbeta;
     q.w = q.b = q.gamma = nullptr; q.dgamma = q.dbeta = nullptr;
-    prof_begin(P, PROF_CONV_WGRAD, layer_flops(L, N) * 4.0 / 9.0, 0, s, L.name.c_str());
+    prof_begin(P, PROF_CONV_WGRAD, layer_flops(L, N) * 4.0 / 9.0, layer_bytes(L, N), s, L.name.c_str());
     int rc = launch_wgrad_T(q, 16, s);
     if (rc == UDET_OK) rc = launch_wgrad_up_combine(deff, dw, L.cin, L.cout, s);
     if (rc == UDET_OK) rc = launch_bn_finalize(dw, 9, L.cin, L.cout, w_, b_, gamma_, BN_C, pd, db, dgamma_, dbeta_, s);
     prof_end(P, s);
     return rc;
   }
-  prof_begin(P, PROF_CONV_WGRAD, layer_flops(L, N), 0, s, L.name.c_str());
+  prof_begin(P, PROF_CONV_WGRAD, layer_flops(L, N), layer_bytes(L, N), s, L.name.c_str());
   const int rc = launch_wgrad_T(q, L.kh * L.kw, s);
   if (P->profiling && (wgrad_last_config() >> 20) == 3) P->prof.back()->mfma_scale = 4.0 / 9.0;  // (Winograd-domain family: 16 of 36 products)
   prof_end(P, s);
@@ -1120,6 +1138,15 @@ static int overflow_consume(Plan* P, int net, bool wait) {
     if (P->adam_t > 0) --P->adam_t;  // the dropped update did not happen: it does not count (see plan_apply)
   }
   return UDET_OK;
+}
+
+// fp16 mode: waits for the pending per-network reports and books dropped updates (adam_t gives their step back) WITHOUT raising the
+// pending UDET_ERR_OVERFLOW -- that stays for the next call on the plan.  udet_get_adam_step / udet_set_adam_step go through here, so a
+// count read for a checkpoint is never one ahead of the updates that really happened, and a count restored from one is not decremented
+// by the report of an apply that preceded the restore.
+void plan_settle_adam_step(Plan* P) {
+  if (!P->cfg.conv_fp16) return;
+  for (int net = 1; net <= 2; ++net) (void)overflow_consume(P, net, true);
 }
 
 int plan_check_overflow(Plan* P, bool wait) {
