@@ -27,6 +27,17 @@ int udet_debug_last_wgrad(void);
  * level whose source has at least `v` pixels (batch included); v < 0 restores the default of 8192.  Tests use 0 on small plans. */
 void udet_debug_upb_min_pixels(long v);
 void udet_debug_set_tuning(int on);
+/* pair launches (two convolutions of the same geometry in ONE launch: the recover net's two encoders, csrc/conv_igemm.hip launch_conv_pair):
+ * on = 1 pairs every compatible couple whatever the tuner thinks, 0 never pairs, -1 restores (tuned / heuristic choice);
+ * udet_debug_last_pair: 1 when the most recent pair call went out as one launch */
+void udet_debug_force_pair(int on);
+int udet_debug_last_pair(void);
+/* two forward convolutions (same shape parameters; cin a multiple of 8; batches na / nb; HWIO weights) through the pair launcher;
+ * workspace >= (2 * k*k*cin*roundup(cout,4) + 4 Mi + 8192) floats */
+#include <stddef.h>
+int udet_debug_conv2d_pair(const float* xa, const float* xb, const float* wa, const float* wb, const float* ba, const float* bb, float* ya, float* yb,
+                           int na, int nb, int h, int w, int cin, int cout, int k, int stride, int dilation, int act, float alpha, void* workspace,
+                           size_t workspace_bytes, void* stream);
 /* (The experiment knobs of earlier rounds -- lane choices and the work-skipping ablation mask -- are no longer reachable from any library
  * that links against libudet.so: they are compiled out of it.  `make -C unsupervised_detection_amd/csrc exp` builds libudet_exp.so, the same
  * sources with -DUDET_EXPERIMENT, which exports udet_exp_knob(id, value); tools/knob_bench.py is its only user.  csrc/plan.h lists the ids.) */

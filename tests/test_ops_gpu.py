@@ -440,6 +440,59 @@ def test_conv_tail_split(ops, force_conv, family, stride):
     assert (dx - gx.float()).abs().max() < 2e-4 * max(1.0, float(gx.abs().max()))
 
 
+PAIR_CASES = [
+    # na, nb, h, w, cin, cout, k, stride, dilation  -- the recover encoders' own couples (nets.py:57-75: image encoder on the B images, flow
+    # encoder on the 3B samples of the batched calls) and ragged / split-K / one-tile variants
+    (4, 12, 24, 48, 64, 64, 3, 1, 1),     # aconv31 + bconv31
+    (4, 12, 24, 48, 64, 128, 3, 2, 1),    # aconv4 + bconv4 (stride 2, SAME padding (0, 1))
+    (4, 12, 6, 12, 128, 128, 3, 1, 1),    # aconv51 + bconv51: 288 + 864 pixels -- K slices through the second pass
+    (1, 3, 13, 9, 16, 24, 5, 2, 1),       # odd grid, 5x5, ragged N tile, more taps than channels per stage
+    (2, 2, 17, 31, 8, 40, 3, 1, 2),       # equal batches, dilation 2, 8 channels (packed taps)
+    (3, 1, 8, 8, 32, 2, 3, 1, 1),         # two output channels, first problem the larger one
+]
+
+
+@pytest.mark.parametrize("case", PAIR_CASES)
+def test_conv_pair_launch(ops, case):
+    """Two convolutions of the same geometry (separate inputs / weights / biases / outputs, different batches) in ONE launch
+    (launch_conv_pair, conv_igemm_dma_pair_kernel): each result against the float64 oracle, and bit-identical to the same two problems
+    launched apart on the same kernel family."""
+    import ctypes
+    from unsupervised_detection_amd._devel import dbg
+    na, nb, h, w, cin, cout, k, s, d = case
+    xs = [rnd(n, h, w, cin, seed=300 + i) for i, n in enumerate((na, nb))]
+    ws = [rnd(k, k, cin, cout, seed=310 + i, scale=(2.0 / (k * k * cin)) ** 0.5) for i in range(2)]
+    bs = [rnd(cout, seed=320 + i, scale=0.1) for i in range(2)]
+    refs = [O.leaky_relu(O.conv2d_same(x.double(), wt.double(), b.double(), s, d), 0.2).float() for x, wt, b in zip(xs, ws, bs)]
+    oh, ow = refs[0].shape[1:3]
+    g = [t.cuda() for t in xs + ws + bs]
+    ws_bytes = (2 * k * k * cin * ((cout + 3) // 4 * 4 + 64) + (4 << 20) + 16384) * 4
+    work = torch.zeros(ws_bytes, dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def run(force):
+        ys = [torch.full((n, oh, ow, cout), float("nan"), device="cuda") for n in (na, nb)]
+        try:
+            dbg.udet_debug_force_pair(force)
+            rc = dbg.udet_debug_conv2d_pair(g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(), g[3].data_ptr(), g[4].data_ptr(), g[5].data_ptr(),
+                                            ys[0].data_ptr(), ys[1].data_ptr(), na, nb, h, w, cin, cout, k, s, d, 1, ctypes.c_float(0.2),
+                                            work.data_ptr(), ws_bytes, stream)
+            paired = dbg.udet_debug_last_pair()
+        finally:
+            dbg.udet_debug_force_pair(-1)
+        assert rc == 0
+        torch.cuda.synchronize()
+        return [y.cpu() for y in ys], paired
+
+    got, paired = run(1)
+    assert paired == 1, "the pair did not go out as one launch"
+    apart, paired0 = run(0)
+    assert paired0 == 0
+    for y, y0, ref in zip(got, apart, refs):
+        assert float((y - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()))
+        assert float((y0 - ref).abs().max()) < 1e-4 * max(1.0, float(ref.abs().max()))
+
+
 def test_bad_arguments_raise(ops):
     x = torch.zeros(1, 4, 4, 6, device="cuda")
     with pytest.raises(ValueError):

@@ -17,6 +17,7 @@ sys.path.insert(0, ROOT)
 
 
 def load_experiment_build():
+    import torch  # noqa: F401  (before any libudet*.so: one HIP runtime per process, see _ffi.py)
     pkg = os.path.join(ROOT, "unsupervised_detection_amd")
     if not os.path.exists(os.path.join(pkg, "libudet_exp.so")):
         raise SystemExit("libudet_exp.so is missing: make -C unsupervised_detection_amd/csrc exp")

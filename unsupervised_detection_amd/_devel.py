@@ -26,3 +26,9 @@ dbg.udet_debug_set_tuning.restype = None
 dbg.udet_debug_set_tuning.argtypes = [ctypes.c_int]
 dbg.udet_debug_last_wgrad.restype = ctypes.c_int
 dbg.udet_debug_last_wgrad.argtypes = []
+dbg.udet_debug_force_pair.restype = None
+dbg.udet_debug_force_pair.argtypes = [ctypes.c_int]
+dbg.udet_debug_last_pair.restype = ctypes.c_int
+dbg.udet_debug_last_pair.argtypes = []
+dbg.udet_debug_conv2d_pair.restype = ctypes.c_int
+dbg.udet_debug_conv2d_pair.argtypes = [ctypes.c_void_p] * 8 + [ctypes.c_int] * 10 + [ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]

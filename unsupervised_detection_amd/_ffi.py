@@ -9,6 +9,11 @@ from __future__ import annotations
 import ctypes
 import os
 
+# PyTorch-ROCm bundles its own HIP runtime (torch/lib/libamdhip64.so); libudet.so names the runtime by soname.  Loaded AFTER torch the
+# library binds to the runtime torch already initialised; loaded first it would bring /opt/rocm's copy in, torch would add its own, and
+# whichever initialises second sees "no ROCm-capable device".  Hence: torch first, always.
+import torch  # noqa: F401  (load order, see above)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libudet.so")
 

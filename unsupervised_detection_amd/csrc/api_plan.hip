@@ -170,13 +170,14 @@ int udet_autotune(udet_plan* h, const float* w_gen, const float* w_rec, float* g
   UDET_HIP(hipStreamSynchronize(s));
   return rc;
 }
-int udet_tuned_shapes(void) { return conv_tuned_shapes() + wgrad_tuned_shapes(); }
+int udet_tuned_shapes(void) { return conv_tuned_shapes() + wgrad_tuned_shapes() + conv_pair_tuned_shapes(); }
 int udet_tune_save(const char* path) {
   FILE* f = path ? fopen(path, "w") : nullptr;
   if (!f) { set_error("tune_save: cannot open %s", path ? path : "(null)"); return UDET_ERR_ARG; }
   fprintf(f, "udet-tune 2 abi %d\n", UDET_TUNE_ABI);
   conv_tune_dump(f);
   wgrad_tune_dump(f);
+  conv_pair_tune_dump(f);
   fclose(f);
   return UDET_OK;
 }
@@ -197,6 +198,7 @@ int udet_tune_load(const char* path) {
     int g = 0, nf = sscanf(line, "c %llu %d %d %d %d %d %d", &key, &a, &b, &c, &d, &e, &g);
     if (nf == 6 || nf == 7) { conv_tune_put(key, a, b, c, d, e, nf == 7 ? g : 0); ++n; }
     else if (sscanf(line, "w %llu %d", &key, &a) == 2) { wgrad_tune_put(key, a); ++n; }
+    else if (sscanf(line, "p %llu %d %d %d %d", &key, &a, &b, &c, &d) == 5) { conv_pair_tune_put(key, a, b, c, d); ++n; }
   }
   fclose(f);
   return n;

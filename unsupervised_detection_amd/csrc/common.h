@@ -186,6 +186,9 @@ struct ConvParams {
 #define UDET_MAX_TICKETS 4096
 
 int launch_conv(ConvParams& p, hipStream_t stream);
+// two independent problems of the same geometry (batch / operands / epilogue may differ) in ONE launch where the LDS-DMA family can take
+// both and the tuner found that faster; otherwise launch_conv(a), launch_conv(b).  a.partial == b.partial: the lane's split-K scratch.
+int launch_conv_pair(ConvParams& a, ConvParams& b, hipStream_t stream);
 // y[n, oy, ox, y_coff+co] = bias[co] + sum_{taps t of the pixel's parity class} Z[n, qy+dy_t, qx+dx_t, widx_t*Cout+co]
 // (zero outside Z's grid); g describes taps / classes / output lattice exactly like a convolution launch
 int launch_tap_gather(const ConvParams& g, const float* z, int ldz, hipStream_t stream);

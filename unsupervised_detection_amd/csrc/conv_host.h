@@ -49,8 +49,14 @@ int wgrad_tuned_shapes();
 void conv_tune_dump(FILE* f);
 void conv_tune_put(unsigned long long key, int bm, int bn, int ks, int ws, int fold, int tail);
 void wgrad_tune_dump(FILE* f);
+void conv_pair_tune_dump(FILE* f);  // "p <pair key> bm bn ks ws" (ws < 0: the two problems stay apart)
+void conv_pair_tune_put(unsigned long long key, int bm, int bn, int ks, int ws);
+int conv_pair_tuned_shapes();
+void conv_pair_clear_tuning();
+void conv_force_pair(int on);  // test hook: 1 = pair every compatible couple, 0 = never, -1 = as tuned / heuristic
+int conv_last_pair();          // 1: the most recent launch_conv_pair went out as ONE launch
 // bumped whenever a kernel family, a tile set or a problem key changes: tuning files of another build are rejected (udet_tune_load)
-#define UDET_TUNE_ABI 5
+#define UDET_TUNE_ABI 6
 void wgrad_tune_put(unsigned long long key, int cfg);  // debugging / tuning hook: bm == 0 and ks < 0 restore the heuristics
 bool conv_setup_dgrad(ConvParams& p, int cls, int N, int H, int W, int kh, int kw, int s, int d);
 int launch_pack_weights(const float* src, float* dst, int T, int R, int C, int Kc, int ldw, int k_split, int k_gap,

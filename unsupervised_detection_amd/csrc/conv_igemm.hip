@@ -18,6 +18,7 @@
 // (models/utils/convolution_utils.py:46,81; models/PWCNet/model_pwcnet.py:161-165,286,484-504,562-574).
 #include <stdlib.h>
 
+#include <functional>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -538,8 +539,10 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 2) void conv_igemm_kernel(
 // (conflict-free under the swizzle) and walk K in the permuted order {4g+e : g = 2*kk+half}, which the B fragment
 // reads ([k][n] rows, ds_read_b32) follow.  Same flat-K / parity-class / split-K semantics as conv_igemm_kernel.
 // ---------------------------------------------------------------------------------------------------------------
-template <int BM, int BN, int WAVES_M, int WAVES_N, int NS, bool F16 = false>
-__global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void conv_igemm_dma_kernel(const ConvParams p) {
+// (the body takes the workgroup's x index and the x extent of ITS problem as arguments: a pair launch -- conv_igemm_dma_pair_kernel below --
+// runs two problems of the same tile configuration in one grid, each workgroup seeing only its own problem's parameter block)
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NS, bool F16>
+__device__ __forceinline__ void conv_igemm_dma_body(const ConvParams& p, const int bid_x, const int grid_x) {
   static_assert(NS >= 2 && NS <= 4, "stages");
   static_assert(WAVES_M * WAVES_N == 4, "4 MFMA waves");
   constexpr int BK = 32;
@@ -566,10 +569,10 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void conv_igemm_dma_kernel(co
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
   const int li = lane & 31, lh = lane >> 5;
 
-  int bid = blockIdx.x;
+  int bid = bid_x;
   int kz = blockIdx.z, knz = p.ksplit;  // K slice of this workgroup / slices of its tile
   {
-    int nwg = gridDim.x;
+    int nwg = grid_x;
     if (p.tail_ks > 1) {  // tail split: the x-blocks past tail_full are cut into tail_ks slices, the others run whole
       nwg = p.tail_full;
       knz = 1;
@@ -864,7 +867,27 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void conv_igemm_dma_kernel(co
   }
   igemm_store<TM, TN, WTM, WTN>(p, acc, rowoff, wm, wn, li, lh, n0, tc.prow0 + m0, Mtot, knz > 1, slab_off,
                                 xpose_scratch<sizeof(As), sizeof(Bs)>(&As[0][0][0], &Bs[0][0][0], wave));
-  if (p.ksplit > 1 && p.fold) splitk_fold<BM, BN, 256>(p, rowoff, &s_last, t, n0, tc.prow0 + m0, Mtot, blockIdx.y * gridDim.x + bid);
+  if (p.ksplit > 1 && p.fold) splitk_fold<BM, BN, 256>(p, rowoff, &s_last, t, n0, tc.prow0 + m0, Mtot, blockIdx.y * grid_x + bid);
+}
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NS, bool F16 = false>
+__global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void conv_igemm_dma_kernel(const ConvParams p) {
+  conv_igemm_dma_body<BM, BN, WAVES_M, WAVES_N, NS, F16>(p, blockIdx.x, gridDim.x);
+}
+// Two problems in ONE launch ("pair launch", round 6): same tile configuration, same N blocks and K slices, independent operands --
+// x-blocks [0, xa) belong to problem 0, the rest to problem 1.  The recover net's two encoders (nets.py:57-75: aconv_k / bconv_k, same
+// geometry per level, separate weights, different batch) and their backward-data passes run this way: each of those launches fills a
+// fraction of the chip and costs a launch boundary, two of them side by side cost hardly more than the larger one.  The parameter
+// blocks stay in the kernel-argument segment (2 x 1752 bytes of the 4 KB): the workgroup picks its block with one scalar select.
+struct ConvPair {
+  ConvParams p[2];
+  int xa;
+};
+static_assert(sizeof(ConvPair) <= 4000, "kernel-argument segment");
+template <int BM, int BN, int WAVES_M, int WAVES_N, int NS>
+__global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void conv_igemm_dma_pair_kernel(const ConvPair pp) {
+  const int second = __builtin_amdgcn_readfirstlane((int)blockIdx.x >= pp.xa ? 1 : 0);
+  conv_igemm_dma_body<BM, BN, WAVES_M, WAVES_N, NS, false>(pp.p[second], (int)blockIdx.x - (second ? pp.xa : 0),
+                                                             second ? (int)gridDim.x - pp.xa : pp.xa);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1194,6 +1217,48 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue4_kernel(const ConvPa
     if (n + 2 < p.Cout) conv_epilogue(p, off, n + 2, v.z);
     if (n + 3 < p.Cout) conv_epilogue(p, off, n + 3, v.w);
   }
+}
+
+// second pass of a pair launch: blocks [0, nba) reduce problem 0's slabs, the rest problem 1's (each as conv_splitk_epilogue4_kernel)
+__device__ __forceinline__ void splitk_epilogue4_body(const ConvParams& p, const int bid_x, const int grid_x) {
+  const int Mall = p.Mall;
+  const int nq = p.ldp >> 2;
+  const long total = (long)Mall * nq;
+  const size_t slab = (size_t)Mall * p.ldp;
+  const bool vec = epilogue4_out_ok(p);
+  for (long e = (long)bid_x * 256 + threadIdx.x; e < total; e += (long)grid_x * 256) {
+    const int ma = (int)(e / nq), n = (int)(e - (long)ma * nq) * 4;
+    const float* src = p.partial + (size_t)ma * p.ldp + n;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    int s = 0;
+    for (; s + 3 < p.ksplit; s += 4) {  // (the summation order of conv_splitk_epilogue4_kernel: slab by slab)
+      const float4 a0 = *reinterpret_cast<const float4*>(src + (size_t)s * slab);
+      const float4 a1 = *reinterpret_cast<const float4*>(src + (size_t)(s + 1) * slab);
+      const float4 a2 = *reinterpret_cast<const float4*>(src + (size_t)(s + 2) * slab);
+      const float4 a3 = *reinterpret_cast<const float4*>(src + (size_t)(s + 3) * slab);
+      v.x += a0.x; v.y += a0.y; v.z += a0.z; v.w += a0.w;
+      v.x += a1.x; v.y += a1.y; v.z += a1.z; v.w += a1.w;
+      v.x += a2.x; v.y += a2.y; v.z += a2.z; v.w += a2.w;
+      v.x += a3.x; v.y += a3.y; v.z += a3.z; v.w += a3.w;
+    }
+    for (; s < p.ksplit; ++s) {
+      const float4 a0 = *reinterpret_cast<const float4*>(src + (size_t)s * slab);
+      v.x += a0.x; v.y += a0.y; v.z += a0.z; v.w += a0.w;
+    }
+    const int off = row_pixel_off(p, ma);
+    if (vec) {
+      if (n < p.Cout) conv_epilogue4(p, off, n, v);
+      continue;
+    }
+    if (n < p.Cout) conv_epilogue(p, off, n, v.x);
+    if (n + 1 < p.Cout) conv_epilogue(p, off, n + 1, v.y);
+    if (n + 2 < p.Cout) conv_epilogue(p, off, n + 2, v.z);
+    if (n + 3 < p.Cout) conv_epilogue(p, off, n + 3, v.w);
+  }
+}
+__global__ __launch_bounds__(256) void conv_splitk_epilogue4_pair_kernel(const ConvPair pp) {
+  const int second = __builtin_amdgcn_readfirstlane((int)blockIdx.x >= pp.xa ? 1 : 0);
+  splitk_epilogue4_body(pp.p[second], (int)blockIdx.x - (second ? pp.xa : 0), second ? (int)gridDim.x - pp.xa : pp.xa);
 }
 
 // x-blocks of a launch: M tiles of every class / segment
@@ -1666,7 +1731,8 @@ static ConvCfg tune_cfg_impl(ConvParams& p, hipStream_t stream) {
 static int g_debug_f16 = 0;  // test hook: fp16 multiplication for the single-operator entry points too
 void conv_debug_f16(int on) { g_debug_f16 = on; }
 int conv_debug_f16_on() { return g_debug_f16; }
-int launch_conv(ConvParams& p, hipStream_t stream) {
+// argument checks + the derived fields every kernel family reads (Mall, fast divisors, uniform-cursor flags, segment rows)
+static int conv_prepare(ConvParams& p) {
   if (g_debug_f16) p.f16 = 1;
   if (p.f16 && !(p.f16_xscale > 0.f)) p.f16_xscale = 1.f;
   // the tuning pass repeats every launch hundreds of times on random data, accumulating launches included: its "gradients" are far
@@ -1719,6 +1785,10 @@ int launch_conv(ConvParams& p, hipStream_t stream) {
   // stages (self-staging kernel); bit 2: Kc in {4, 8, 16}, 32 / Kc whole taps per 32-wide stage (wave-specialised kernel)
   p.kfast = 0;
   if (p.up_shift == 0) p.kfast = p.Kc >= 32 ? 3 : ((p.Kc >= 16 ? 2 : 0) | ((p.Kc == 4 || p.Kc == 8 || p.Kc == 16) ? 4 : 0));
+  return UDET_OK;
+}
+int launch_conv(ConvParams& p, hipStream_t stream) {
+  UDET_TRY(conv_prepare(p));
   ConvCfg c;
   bool have = false;
   const uint64_t key = conv_key(p);
@@ -1800,6 +1870,237 @@ int launch_conv(ConvParams& p, hipStream_t stream) {
   g_last_cfg = (c.ws & 0xff) | ((c.bm & 0xfff) << 8) | ((c.ks & 0xff) << 20) | ((c.ks > 1 && c.fold && c.ws != 3 && p.tickets ? 1 : 0) << 28) |
                ((c.ks > 1 && c.tail > 0 ? 1 : 0) << 29);
   return run_cfg(p, c, stream);
+}
+
+
+// ---- pair launches (two problems, one grid; conv_igemm_dma_pair_kernel) -----------------------------------------------------------------
+// Eligible: two unsegmented fp32 problems the LDS-DMA family can take, with the same K depth, output width, tap geometry, class
+// structure and strides (batch, operands, epilogue may differ).  The pair has ONE configuration (tile, K slices, stage ring), tuned as
+// a unit and cached under the pair's own key; ws < 0 in the cache = "these two are faster apart".
+static std::unordered_map<uint64_t, ConvCfg> g_pair_cache;
+static int g_force_pair = -1;  // test hook (libudet_debug): 1 pairs whatever the tuner thinks, 0 never pairs
+void conv_force_pair(int on) { g_force_pair = on; }
+static int g_last_pair = 0;
+int conv_last_pair() { return g_last_pair; }
+static bool pair_compatible(const ConvParams& a, const ConvParams& b) {
+  if (a.nseg || b.nseg || a.f16 || b.f16 || a.up_shift || b.up_shift || !dma_ok(a) || !dma_ok(b)) return false;
+  if (a.Kc != b.Kc || a.Cout != b.Cout || a.ldw != b.ldw || a.ntaps != b.ntaps || a.ncls != b.ncls) return false;
+  if (a.isy != b.isy || a.isx != b.isx || a.osy != b.osy || a.osx != b.osx || a.kfast != b.kfast) return false;
+  if (!a.partial || a.partial != b.partial) return false;  // (one scratch region, carved in two below)
+  for (int c = 0; c <= a.ncls; ++c)
+    if (a.cls_tap[c] != b.cls_tap[c]) return false;
+  for (int t = 0; t < a.ntaps; ++t)
+    if (a.taps[t].dy != b.taps[t].dy || a.taps[t].dx != b.taps[t].dx) return false;
+  return true;
+}
+static uint64_t pair_key(const ConvParams& a, const ConvParams& b) {
+  uint64_t h = conv_key(a) * 1099511628211ull ^ conv_key(b);
+  h ^= 0x9e3779b97f4a7c15ull;
+  return h * 1099511628211ull;
+}
+void conv_pair_tune_dump(FILE* f) {
+  std::lock_guard<std::mutex> l(g_cache_mu);
+  for (auto& kv : g_pair_cache) fprintf(f, "p %llu %d %d %d %d\n", (unsigned long long)kv.first, kv.second.bm, kv.second.bn, kv.second.ks, kv.second.ws);
+}
+void conv_pair_tune_put(unsigned long long key, int bm, int bn, int ks, int ws) {
+  std::lock_guard<std::mutex> l(g_cache_mu);
+  g_pair_cache[(uint64_t)key] = ConvCfg{bm, bn, ks, ws, 0, 0};
+}
+int conv_pair_tuned_shapes() { std::lock_guard<std::mutex> l(g_cache_mu); return (int)g_pair_cache.size(); }
+void conv_pair_clear_tuning() { std::lock_guard<std::mutex> l(g_cache_mu); g_pair_cache.clear(); }
+
+template <int BM, int BN, int WAVES_M, int WAVES_N>
+static int launch_pair_cfg(ConvParams& a, ConvParams& b, int ws, hipStream_t stream) {
+  ConvPair pp;
+  pp.p[0] = a; pp.p[1] = b;
+  pp.xa = conv_xblocks(a, BM);
+  dim3 grid(pp.xa + conv_xblocks(b, BM), (a.Cout + BN - 1) / BN, a.ksplit > 1 ? a.ksplit : 1);
+  if (ws == 4) UDET_LAUNCH((conv_igemm_dma_pair_kernel<BM, BN, WAVES_M, WAVES_N, 3>), grid, dim3(512), 0, stream, pp);
+  else UDET_LAUNCH((conv_igemm_dma_pair_kernel<BM, BN, WAVES_M, WAVES_N, 2>), grid, dim3(512), 0, stream, pp);
+  UDET_HIP(hipGetLastError());
+  if (a.ksplit > 1) {
+    const long na = ((long)a.Mall * (a.ldp >> 2) + 255) / 256, nb = ((long)b.Mall * (b.ldp >> 2) + 255) / 256;
+    pp.xa = (int)(na > 2048 ? 2048 : na);
+    const int xb = (int)(nb > 2048 ? 2048 : nb);
+    UDET_LAUNCH(conv_splitk_epilogue4_pair_kernel, dim3(pp.xa + xb), dim3(256), 0, stream, pp);
+    UDET_HIP(hipGetLastError());
+  }
+  return UDET_OK;
+}
+// slab capacity of a pair: both problems' K slices side by side in the launch lane's scratch
+static int pair_max_ksplit(const ConvParams& a, const ConvParams& b) {
+  const int nchunks = (max_class_taps(a) * a.Kc + 31) / 32;
+  int ks = nchunks / 2 > 64 ? 64 : nchunks / 2;
+  const size_t per_split = ((size_t)a.Mall + b.Mall) * ((a.Cout + 3) & ~3) + 64;
+  while (ks > 1 && per_split * ks > a.partial_cap) --ks;
+  return ks < 1 ? 1 : ks;
+}
+static int run_pair_cfg(ConvParams& a, ConvParams& b, const ConvCfg& c, hipStream_t stream) {
+  const int cap = pair_max_ksplit(a, b);
+  const int ks = c.ks > cap ? cap : (c.ks < 1 ? 1 : c.ks);
+  for (ConvParams* q : {&a, &b}) {
+    q->ksplit = ks; q->fold = 0; q->tail_full = 0; q->tail_ks = 0; q->tail_prow0 = 0;
+    q->ldp = (q->Cout + 3) & ~3;
+  }
+  float* const base = a.partial;
+  if (ks > 1) {
+    if ((reinterpret_cast<uintptr_t>(base) & 15) != 0) { set_error("conv pair: unaligned split-K scratch"); return UDET_ERR_ALIGN; }
+    size_t off = (size_t)ks * a.Mall * a.ldp;
+    off = (off + 15) & ~(size_t)15;
+    b.partial = base + off;
+  }
+  int rc;
+  if (c.bm == 256 && c.bn == 32) rc = launch_pair_cfg<256, 32, 4, 1>(a, b, c.ws, stream);
+  else if (c.bm == 128 && c.bn == 32) rc = launch_pair_cfg<128, 32, 4, 1>(a, b, c.ws, stream);
+  else if (c.bm == 128 && c.bn == 64) rc = launch_pair_cfg<128, 64, 2, 2>(a, b, c.ws, stream);
+  else if (c.bm == 64 && c.bn == 64) rc = launch_pair_cfg<64, 64, 2, 2>(a, b, c.ws, stream);
+  else if (c.bm == 128 && c.bn == 96) rc = launch_pair_cfg<128, 96, 4, 1>(a, b, c.ws, stream);
+  else if (c.bm == 128 && c.bn == 128) rc = launch_pair_cfg<128, 128, 2, 2>(a, b, c.ws, stream);
+  else { set_error("conv pair: no kernel for tile %dx%d", c.bm, c.bn); rc = UDET_ERR_UNSUPPORTED; }
+  b.partial = base;
+  return rc;
+}
+static ConvCfg pair_heuristic(const ConvParams& a, const ConvParams& b) {
+  ConvCfg c = heuristic_cfg(b.Mall >= a.Mall ? b : a);
+  c.ws = 2; c.fold = 0; c.tail = 0;
+  const long tiles = cfg_tiles(a, c.bm, c.bn) + cfg_tiles(b, c.bm, c.bn);
+  c.ks = 1;
+  if (tiles < 256) {
+    const int cap = pair_max_ksplit(a, b), half = cap / 2 > 0 ? cap / 2 : 1;
+    const int ks = (int)((512 + tiles - 1) / tiles);
+    c.ks = ks > half ? half : ks;
+  }
+  return c;
+}
+static float time_calls(const std::function<int()>& fn, int reps, hipStream_t stream) {
+  static hipEvent_t e0 = nullptr, e1 = nullptr;
+  if (!e0) { (void)hipEventCreate(&e0); (void)hipEventCreate(&e1); }
+  if (fn() != UDET_OK) return 1e30f;
+  (void)hipEventRecord(e0, stream);
+  for (int r = 0; r < reps; ++r) (void)fn();
+  (void)hipEventRecord(e1, stream);
+  if (hipEventSynchronize(e1) != hipSuccess) return 1e30f;
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  return ms / reps;
+}
+static ConvCfg tune_pair(ConvParams& a, ConvParams& b, hipStream_t stream) {
+  const int acc_a = a.accumulate, acc_b = b.accumulate;
+  a.accumulate = b.accumulate = 0;  // (see tune_cfg: repeated accumulation would grow the data)
+  // what the two cost apart, each on its own tuned configuration (launch_conv tunes a shape the first time it sees it)
+  auto apart = [&]() -> int { ConvParams x = a, y = b; int rc = launch_conv(x, stream); return rc != UDET_OK ? rc : launch_conv(y, stream); };
+  (void)apart();
+  float t_apart = time_calls(apart, 5, stream);
+  t_apart = 0.5f * (t_apart + time_calls(apart, 5, stream));
+  static const int TILES[6][2] = {{256, 32}, {128, 32}, {128, 64}, {64, 64}, {128, 96}, {128, 128}};
+  const int kcap = pair_max_ksplit(a, b);
+  ConvCfg best = {0, 0, 1, -1, 0, 0};
+  float best_ms = 1e30f;
+  for (auto& t : TILES) {
+    const int bm = t[0], bn = t[1];
+    if (a.Cout <= 32 && bn != 32) continue;
+    if (a.Cout > 32 && a.Cout <= 64 && bn > 64) continue;
+    if (a.Cout > 64 && a.Cout <= 96 && bn != 96 && bn != 32) continue;
+    if (a.Cout > 96 && bn < 64) continue;
+    if (a.Cout > 96 && bn == 96 && a.Cout % 96 != 0 && a.Cout <= 128) continue;
+    const long tiles = cfg_tiles(a, bm, bn) + cfg_tiles(b, bm, bn);
+    std::vector<int> kss;
+    for (int ks = 1; ks <= kcap; ks *= 2) kss.push_back(ks);
+    if (tiles < 512)
+      for (int k = 1; k <= 4; ++k) {
+        const int ks = (int)(256L * k / tiles);
+        if (ks >= 3 && ks <= kcap && (ks & (ks - 1)) != 0 && std::find(kss.begin(), kss.end(), ks) == kss.end()) kss.push_back(ks);
+      }
+    for (int ks : kss) {
+      if (ks > 1 && (tiles >= 512 || tiles * ks > 4096)) continue;
+      if (tiles * ks < 96 && ks * 2 <= kcap) continue;
+      for (int ws : {2, 4}) {
+        const ConvCfg c = {bm, bn, ks, ws, 0, 0};
+        float ms = time_calls([&]() { return run_pair_cfg(a, b, c, stream); }, 3, stream);
+        if (ms < best_ms * 1.1f) ms = 0.5f * (ms + time_calls([&]() { return run_pair_cfg(a, b, c, stream); }, 6, stream));
+        if (ms < best_ms) { best_ms = ms; best = c; }
+      }
+    }
+  }
+  // verification: each problem's output of the pair launch against its own stand-alone launch on the built-in configuration
+  bool ok = best.ws >= 0;
+  float diff = 0.f, scale = 0.f;
+  for (int which = 0; ok && which < 2; ++which) {
+    ConvParams& p = which ? b : a;
+    const int ld = (p.Cout + 3) & ~3;
+    const size_t n = (size_t)p.N * p.OH * p.OW * ld;
+    float* r0 = tune_scratch(n, 0);
+    float* r1 = tune_scratch(n, 1);
+    if (!r0 || !r1) { ok = false; break; }
+    (void)hipMemsetAsync(r0, 0, n * sizeof(float), stream);
+    (void)hipMemsetAsync(r1, 0, n * sizeof(float), stream);
+    ConvParams q = p;
+    q.ldy = ld; q.y_coff = 0; q.accumulate = 0; q.y2 = nullptr; q.uo = nullptr;
+    q.y = r0;
+    int rc = run_cfg(q, heuristic_cfg(q), stream);
+    ConvParams qa = a, qb = b;
+    ConvParams& qq = which ? qb : qa;
+    qq.ldy = ld; qq.y_coff = 0; qq.accumulate = 0; qq.y2 = nullptr; qq.uo = nullptr; qq.y = r1;
+    if (rc == UDET_OK) rc = run_pair_cfg(qa, qb, best, stream);
+    ok = rc == UDET_OK && tune_compare(r0, r1, n, stream, &diff, &scale);
+  }
+  if (best.ws >= 0 && !ok) {
+    fprintf(stderr, "[udet tune] REJECTED pair N=%d+%d %dx%d Kc=%d taps=%d cls=%d Cout=%d: %dx%d ks=%d ws=%d differs from the stand-alone "
+            "launches (max|diff| %.3e, scale %.3e); launching them apart\n", a.N, b.N, a.OHq, a.OWq, a.Kc, a.ntaps, a.ncls, a.Cout, best.bm, best.bn,
+            best.ks, best.ws, diff, scale);
+    conv_tune_note_reject();
+    best.ws = -1;
+  }
+  if (getenv("UDET_TUNE_LOG"))
+    fprintf(stderr, "[udet tune] pair N=%d+%d %dx%d Kc=%d taps=%d cls=%d Cout=%d -> %dx%d ks=%d ws=%d  %.1f us, apart %.1f us%s\n", a.N, b.N, a.OHq,
+            a.OWq, a.Kc, a.ntaps, a.ncls, a.Cout, best.bm, best.bn, best.ks, best.ws, best_ms * 1e3f, t_apart * 1e3f,
+            best_ms < t_apart * 0.97f ? "" : " (kept apart)");
+  if (!(best_ms < t_apart * 0.97f)) best.ws = -1;
+  a.accumulate = acc_a; b.accumulate = acc_b;
+  return best;
+}
+// Both problems in one launch where that is eligible and (tuned) faster; otherwise the two ordinary launches, a first.
+int launch_conv_pair(ConvParams& a, ConvParams& b, hipStream_t stream) {
+  g_last_pair = 0;
+  UDET_TRY(conv_prepare(a));
+  UDET_TRY(conv_prepare(b));
+  const bool forced_family = g_force_bm || g_force_ws >= 0 || g_force_ks >= 0;  // (a test pins a family for single launches: respect it)
+  if (g_force_pair == 0 || (forced_family && g_force_pair != 1) || !pair_compatible(a, b)) {
+    UDET_TRY(launch_conv(a, stream));
+    return launch_conv(b, stream);
+  }
+  ConvCfg c;
+  bool have = false;
+  const uint64_t key = pair_key(a, b);
+  {
+    std::lock_guard<std::mutex> l(g_cache_mu);
+    auto it = g_pair_cache.find(key);
+    if (it != g_pair_cache.end()) { c = it->second; have = true; }
+  }
+  if (have && c.ws >= 0) {  // (an entry from a file: instantiated tiles and ring depths only)
+    static const int TILES[6][2] = {{256, 32}, {128, 32}, {128, 64}, {64, 64}, {128, 96}, {128, 128}};
+    bool tile = false;
+    for (auto& t : TILES) tile = tile || (c.bm == t[0] && c.bn == t[1]);
+    if (!tile || (c.ws != 2 && c.ws != 4)) c = pair_heuristic(a, b);
+    if (c.ks < 1) c.ks = 1;
+  }
+  if (!have) {
+    if (g_tuning) {
+      c = tune_pair(a, b, stream);
+      std::lock_guard<std::mutex> l(g_cache_mu);
+      g_pair_cache[key] = c;
+    } else {
+      c = pair_heuristic(a, b);
+    }
+  }
+  if (g_force_pair == 1 && c.ws < 0) c = pair_heuristic(a, b);
+  if (c.ws < 0) {
+    UDET_TRY(launch_conv(a, stream));
+    return launch_conv(b, stream);
+  }
+  g_last_pair = 1;
+  g_last_cfg = (c.ws & 0xff) | ((c.bm & 0xfff) << 8) | ((c.ks & 0xff) << 20) | (1 << 30);
+  return run_pair_cfg(a, b, c, stream);
 }
 
 }  // namespace udet

@@ -200,7 +200,7 @@ int plan_prefetch(Plan* P, const float* img1, const float* img2, float* ws, hipS
 int plan_prefetch_consume(Plan* P, float* ws, hipStream_t s);
 int plan_generator_forward(Plan* P, float* ws, hipStream_t s);
 int plan_generator_layers(Plan* P, float* ws, hipStream_t s);
-int plan_recover_forward(Plan* P, int ncalls, float* ws, hipStream_t s, bool inputs_prepacked = false, bool skip_enc_a = false);
+int plan_recover_forward(Plan* P, int ncalls, float* ws, hipStream_t s, bool inputs_prepacked = false, bool skip_enc_a = false, bool enc_a_input_packed = false);
 int plan_losses(Plan* P, float* ws, hipStream_t s);
 // which: 1 generator loss -> MaskNet, 2 recover loss -> FlownetS, 3 both (the two passes run concurrently)
 int plan_backward(Plan* P, int which, const float* w_gen, const float* w_rec, float* g_gen, float* g_rec, float* ws, hipStream_t s);

@@ -503,6 +503,82 @@ static int run_wgrad(Plan* P, const Layer& L, int N, int dy, bool dy_is_du, cons
   return rc;
 }
 
+// ---- pair launches (launch_conv_pair, conv_igemm.hip): the recover net's two encoders (nets.py:57-75) -----------------------------
+// aconv_k and bconv_k have the same geometry per level, separate weights and (shared image encoder) different batch sizes; their
+// forward launches and their backward-data launches are independent of each other.  One launch per level carries both.
+// (experiment knob UDET_KNOB_NO_PAIRS, libudet_exp.so only: bit 0 forward pairs off, bit 1 backward-data pairs off)
+static bool pairs_on(const Plan* P, int dir = 0) { return !P->cfg.conv_fp16 && !((plan_knob(UDET_KNOB_NO_PAIRS) >> dir) & 1); }
+// the parameter block run_fwd launches for a PLAIN forward layer (no transposed / up-sampling / head / up-conv form)
+static void fwd_params(Plan* P, const Layer& L, int N, float* ws, int slot, ConvParams& p) {
+  const Buf &bx = P->buf(L.x), &by = P->buf(L.y);
+  memset(&p, 0, sizeof(p));
+  conv_setup_fwd(p, N, L.H, L.W, L.kh, L.kw, L.stride, L.dil);
+  p.x = ws + bx.off; p.ldx = bx.ld; p.x_coff = L.x_coff;
+  p.wp = ws + L.wp_off; p.Kc = L.Kc; p.ldw = L.ldw; p.bias = ws + L.bias_f_off;
+  p.y = ws + by.off; p.ldy = by.ld; p.y_coff = L.y_coff; p.Cout = L.cout;
+  p.act = L.act; p.alpha = L.alpha;
+  if (L.res >= 0) { p.res = ws + P->buf(L.res).off; p.ldres = P->buf(L.res).ld; p.res_coff = L.res_coff; }
+  if (L.y2 >= 0) { p.y2 = ws + P->buf(L.y2).off; p.ldy2 = P->buf(L.y2).ld; p.y2_coff = 0; }
+  fill_common(P, p, ws, slot);
+}
+static bool plain_fwd_layer(const Layer& L) { return !L.transposed && !L.up && !L.upb && !L.col2im; }
+static int run_fwd_pair(Plan* P, const Layer& La, int Na, const Layer& Lb, int Nb, float* ws, const Lane& ln) {
+  if (!pairs_on(P) || !plain_fwd_layer(La) || !plain_fwd_layer(Lb)) {
+    UDET_TRY(run_fwd(P, La, Na, ws, ln));
+    return run_fwd(P, Lb, Nb, ws, ln);
+  }
+  if (skip_launch(0, La.net)) return UDET_OK;
+  ConvParams a, b;
+  fwd_params(P, La, Na, ws, ln.slot, a);
+  fwd_params(P, Lb, Nb, ws, ln.slot, b);
+  prof_begin(P, PROF_CONV_FWD, layer_flops(La, Na) + layer_flops(Lb, Nb), layer_bytes(La, Na) + layer_bytes(Lb, Nb), ln.s, (La.name + "+" + Lb.name).c_str());
+  const int rc = launch_conv_pair(a, b, ln.s);
+  prof_end(P, ln.s);
+  return rc;
+}
+// the parameter block of a layer's backward-data launch when that is ONE launch on a materialised dU (run_dgrad's common case)
+static bool dgrad_params(Plan* P, const Layer& L, int N, int dy, int dx, int dx_coff, int accumulate, const Emit& em, float* ws, int slot, ConvParams& p) {
+  if (L.up || L.upb || L.transposed || conv_dgrad_classes(L.stride, L.H, L.W) != 1) return false;
+  const Buf &bdy = P->buf(dy), &bdx = P->buf(dx);
+  memset(&p, 0, sizeof(p));
+  if (!conv_setup_dgrad(p, 0, N, L.H, L.W, L.kh, L.kw, L.stride, L.dil)) return false;
+  p.x = ws + bdy.off; p.ldx = bdy.ld; p.x_coff = L.y_coff;
+  p.wp = ws + L.wpT_off; p.Kc = L.KcT; p.ldw = L.ldwT; p.kreal = L.cout;
+  p.y = ws + bdx.off; p.ldy = bdx.ld; p.y_coff = dx_coff; p.Cout = L.cin;
+  p.accumulate = accumulate;
+  if (em.ubuf >= 0) {
+    const Buf &bu = P->buf(em.ubuf), &bua = P->buf(em.abuf);
+    p.uo = ws + bu.off; p.ldu = bu.ld; p.u_coff = dx_coff;
+    p.ua = ws + bua.off; p.ldua = bua.ld; p.ua_coff = dx_coff;
+    p.uact = em.act; p.ualpha = em.alpha; p.u_c0 = em.c0; p.u_c1 = em.c1;
+  }
+  if (L.winoT_off) { p.wino_u = ws + L.winoT_off; p.wino_np = L.winoT_np; }
+  fill_common(P, p, ws, slot);
+  p.f16_xscale = UDET_F16_GRAD_SCALE;
+  return true;
+}
+struct DgradJob {
+  const Layer* L;
+  int N, dy, dx, dx_coff, accumulate;
+  Emit em;
+};
+// both jobs read a materialised dU (dy_is_du) and carry no residual operand
+static int run_dgrad_pair(Plan* P, const DgradJob& ja, const DgradJob& jb, float* ws, const Lane& ln) {
+  ConvParams a, b;
+  if (!pairs_on(P, 1) || !dgrad_params(P, *ja.L, ja.N, ja.dy, ja.dx, ja.dx_coff, ja.accumulate, ja.em, ws, ln.slot, a) ||
+      !dgrad_params(P, *jb.L, jb.N, jb.dy, jb.dx, jb.dx_coff, jb.accumulate, jb.em, ws, ln.slot, b)) {
+    UDET_TRY(run_dgrad(P, *ja.L, ja.N, ja.dy, true, ja.dx, ja.dx_coff, ja.accumulate, -1, ja.em, ws, ln));
+    return run_dgrad(P, *jb.L, jb.N, jb.dy, true, jb.dx, jb.dx_coff, jb.accumulate, -1, jb.em, ws, ln);
+  }
+  if (skip_launch(1, ja.L->net)) return UDET_OK;
+  a.wino_u = b.wino_u = nullptr;  // (pair launches are implicit-GEMM launches)
+  prof_begin(P, PROF_CONV_DGRAD, layer_flops(*ja.L, ja.N) + layer_flops(*jb.L, jb.N), layer_bytes(*ja.L, ja.N) + layer_bytes(*jb.L, jb.N), ln.s,
+             (ja.L->name + "+" + jb.L->name).c_str());
+  const int rc = launch_conv_pair(a, b, ln.s);
+  prof_end(P, ln.s);
+  return rc;
+}
+
 // ------------------------------------------------------- init / packing ----
 int plan_init_workspace(Plan* P, float* ws, hipStream_t s) {
   UDET_HIP(hipMemsetAsync(ws, 0, P->arena_floats * sizeof(float), s));
@@ -746,26 +822,33 @@ static const char* ENC_NAMES[9] = {"conv1", "conv2", "conv3", "conv31", "conv4",
 
 // The image branch of recover_net (nets.py:57-65): image replicated for the `ncalls` invocations + encoder A.  It
 // depends on nothing but the image, so the step runs it beside PWC-Net / the generator.
-static int plan_rec_image_branch(Plan* P, int ncalls, float* ws, const Lane& ln) {
+// encoder A's skip tensors (the slab segments aconv1/2/31/41/51 and aconv6), computed for the B images, fanned out to the other calls' samples
+static int share_enc_a_output(Plan* P, const Layer& L, int ncalls, float* ws, hipStream_t s) {
+  const Buf& y = P->buf(L.y);
+  if (ncalls > 1 && (y.name.find("concat") != std::string::npos || y.name == "rec.conv6"))
+    return launch_share_samples(ws + y.off, (long)P->cfg.batch * y.h * y.w, y.ld, L.y_coff, L.cout, ncalls, s);
+  return UDET_OK;
+}
+// with_layers = false (pair mode, round 6): only the encoder's input is packed here; its nine layers ride in encoder B's launches
+// (plan_recover_forward), one pair launch per level
+static int plan_rec_image_branch(Plan* P, int ncalls, float* ws, const Lane& ln, bool with_layers = true) {
   const Config& c = P->cfg;
   if (ncalls < 1) return UDET_OK;
   const long Ppix = (long)c.batch * c.img_h * c.img_w;
-  // every call sees the same image: encoder A runs once on the B images, then the tensors the decoder reads (the slab
-  // segments aconv1/2/31/41/51 and aconv6) are fanned out to the other calls' samples
+  // every call sees the same image: encoder A runs once on the B images, then the tensors the decoder reads are fanned out
   UDET_TRY(launch_pack_imgin(ws + P->buf(P->bid("image")).off, ws + P->buf(P->bid("rec.imgin")).off, Ppix, 1, ln.s));
+  if (!with_layers) return UDET_OK;
   for (int i = 0; i < 9; ++i) {
     const Layer& L = *find_layer(P->rec, std::string("a") + ENC_NAMES[i]);
     UDET_TRY(run_fwd(P, L, c.batch, ws, ln));
-    const Buf& y = P->buf(L.y);
-    if (ncalls > 1 && (y.name.find("concat") != std::string::npos || y.name == "rec.conv6"))
-      UDET_TRY(launch_share_samples(ws + y.off, (long)c.batch * y.h * y.w, y.ld, L.y_coff, L.cout, ncalls, ln.s));
+    UDET_TRY(share_enc_a_output(P, L, ncalls, ws, ln.s));
   }
   P->enc_a_shared = true;
   return UDET_OK;
 }
 
 // mask, recover inputs, `ncalls` batched recover invocations (nets.py:45-110; adversarial_learner.py:107-131)
-int plan_recover_forward(Plan* P, int ncalls, float* ws, hipStream_t s, bool inputs_prepacked, bool skip_enc_a) {
+int plan_recover_forward(Plan* P, int ncalls, float* ws, hipStream_t s, bool inputs_prepacked, bool skip_enc_a, bool enc_a_input_packed) {
   const Config& c = P->cfg;
   const int B = c.batch, N = ncalls * B;
   const long Ppix = (long)B * c.img_h * c.img_w;
@@ -774,15 +857,27 @@ int plan_recover_forward(Plan* P, int ncalls, float* ws, hipStream_t s, bool inp
     UDET_TRY(launch_mask_rec_inputs(ws + P->buf(P->bid("gen.a17")).off, ws + P->buf(P->bid("flow")).off,
                                     ws + P->buf(P->bid("mask")).off, ws + P->buf(P->bid("rec.fin")).off, Ppix, ncalls, s));
   if (ncalls < 1) return UDET_OK;
-  if (!skip_enc_a) {
-    if (inputs_prepacked) {  // caller-packed images may differ between the calls: per-sample encoder
-      for (int i = 0; i < 9; ++i) UDET_TRY(run_fwd(P, *find_layer(P->rec, std::string("a") + ENC_NAMES[i]), N, ws, L0));
-      P->enc_a_shared = false;
-    } else {
-      UDET_TRY(plan_rec_image_branch(P, ncalls, ws, L0));
+  if (!skip_enc_a && pairs_on(P)) {
+    // pair mode: level by level, encoder A (the B images -- or, caller-packed inputs, every sample) and encoder B (the N samples of the
+    // batched calls) in ONE launch (run_fwd_pair); the image encoder's input was packed by the caller of this function or is packed here
+    if (!inputs_prepacked && !enc_a_input_packed) UDET_TRY(plan_rec_image_branch(P, ncalls, ws, L0, false));
+    for (int i = 0; i < 9; ++i) {
+      const Layer& La = *find_layer(P->rec, std::string("a") + ENC_NAMES[i]);
+      UDET_TRY(run_fwd_pair(P, La, inputs_prepacked ? N : B, *find_layer(P->rec, std::string("b") + ENC_NAMES[i]), N, ws, L0));
+      if (!inputs_prepacked) UDET_TRY(share_enc_a_output(P, La, ncalls, ws, s));
     }
+    P->enc_a_shared = !inputs_prepacked;
+  } else {
+    if (!skip_enc_a) {
+      if (inputs_prepacked) {  // caller-packed images may differ between the calls: per-sample encoder
+        for (int i = 0; i < 9; ++i) UDET_TRY(run_fwd(P, *find_layer(P->rec, std::string("a") + ENC_NAMES[i]), N, ws, L0));
+        P->enc_a_shared = false;
+      } else {
+        UDET_TRY(plan_rec_image_branch(P, ncalls, ws, L0));
+      }
+    }
+    for (int i = 0; i < 9; ++i) UDET_TRY(run_fwd(P, *find_layer(P->rec, std::string("b") + ENC_NAMES[i]), N, ws, L0));
   }
-  for (int i = 0; i < 9; ++i) UDET_TRY(run_fwd(P, *find_layer(P->rec, std::string("b") + ENC_NAMES[i]), N, ws, L0));
   for (int k = 5; k >= 1; --k) {
     // the up-sampled tensor rec.r{k+1}: the forward of an up-conv level (Layer::upb) reads the ringed low-resolution source instead, and
     // nothing else in the forward or in either backward-data pass reads it -- only the level's filter gradient does, which builds it
@@ -845,7 +940,9 @@ int plan_forward(Plan* P, const float* img1, const float* img2, int ncalls, floa
     e_img = next_event(P);
     (void)hipEventRecord(e_img, LI.s);
   }
-  UDET_TRY(plan_rec_image_branch(P, ncalls, ws, LI));
+  // pair mode: lane 1 only packs the image encoder's input; its layers run inside encoder B's launches (plan_recover_forward)
+  const bool paired = pairs_on(P);
+  UDET_TRY(plan_rec_image_branch(P, ncalls, ws, LI, !paired));
   if (img1) {
     UDET_TRY(pwc_forward_on(P, img1, img2, ws, L0, lane_of(P, s, 2)));
     UDET_TRY(plan_prepare_flow(P, "flow", ws, s));
@@ -853,7 +950,7 @@ int plan_forward(Plan* P, const float* img1, const float* img2, int ncalls, floa
   if (e_img) (void)hipStreamWaitEvent(s, e_img, 0);
   UDET_TRY(plan_generator_forward(P, ws, s));
   order_after(P, LI, L0);
-  UDET_TRY(plan_recover_forward(P, ncalls, ws, s, false, true));
+  UDET_TRY(plan_recover_forward(P, ncalls, ws, s, false, !paired, paired));
   if (ncalls == 3) UDET_TRY(plan_losses(P, ws, s));
   return UDET_OK;
 }
@@ -943,7 +1040,10 @@ static int rec_backward(Plan* P, int N, const char* dp, bool with_wgrad, bool ne
   }
   // encoders, deepest first.  gradient buffers mirror the forward buffers of each conv's output / input.
   if (a_own_lane) order_after(P, LD, LA);  // (everything the decoder wrote)
-  for (int i = 8; i >= 0; --i)
+  const bool pair_enc = pairs_on(P, 1) && with_wgrad && !a_own_lane;
+  for (int i = 8; i >= 0; --i) {
+    DgradJob job[2];
+    int njob = 0;
     for (const char* e : {"a", "b"}) {
       // encoder A sees only the image: without parameter gradients (generator-loss pass) nothing upstream needs it
       if (e[0] == 'a' && !with_wgrad) continue;
@@ -976,8 +1076,17 @@ static int rec_backward(Plan* P, int N, const char* dp, bool with_wgrad, bool ne
         const Buf& d = P->buf(dx);
         UDET_TRY(launch_fold_samples(ws + d.off, (long)c.batch * d.h * d.w, d.ld, L->x_coff, L->cin, ncopies, se));
       }
+      if (pair_enc) {  // (both encoders' launches of this level go out together below: everything either of them waits for is enqueued)
+        job[njob].L = L; job[njob].N = Ne; job[njob].dy = du; job[njob].dx = dx; job[njob].dx_coff = L->x_coff;
+        job[njob].accumulate = slab_in ? 1 : 0; job[njob].em = em;
+        ++njob;
+        continue;
+      }
       UDET_TRY(run_dgrad(P, *L, Ne, du, true, dx, L->x_coff, slab_in ? 1 : 0, -1, em, ws, LE));
     }
+    if (njob == 2) UDET_TRY(run_dgrad_pair(P, job[0], job[1], ws, LD));
+    else if (njob == 1) UDET_TRY(run_dgrad(P, *job[0].L, job[0].N, job[0].dy, true, job[0].dx, job[0].dx_coff, job[0].accumulate, -1, job[0].em, ws, LD));
+  }
   if (a_own_lane) order_after(P, LA, LD);
   if (with_wgrad && LWdec.s != LW.s) order_after(P, LWdec, LD);
   return UDET_OK;
