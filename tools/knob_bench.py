@@ -16,23 +16,31 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def load_experiment_build():
+def load_library(lib_path):
+    """The package's ctypes binding on ANOTHER build of the library (tools only; the product loader has no such switch)."""
     import torch  # noqa: F401  (before any libudet*.so: one HIP runtime per process, see _ffi.py)
     pkg = os.path.join(ROOT, "unsupervised_detection_amd")
-    if not os.path.exists(os.path.join(pkg, "libudet_exp.so")):
-        raise SystemExit("libudet_exp.so is missing: make -C unsupervised_detection_amd/csrc exp")
+    lib_path = os.path.abspath(lib_path)
+    if not os.path.exists(lib_path):
+        raise SystemExit("%s is missing (experiment build: make -C unsupervised_detection_amd/csrc exp)" % lib_path)
     import unsupervised_detection_amd  # noqa: F401  (the package itself imports nothing native)
     path = os.path.join(pkg, "_ffi.py")
-    src = open(path).read().replace('"libudet.so"', '"libudet_exp.so"')
+    src = open(path).read().replace('os.path.join(_HERE, "libudet.so")', repr(lib_path))
+    assert repr(lib_path) in src
     mod = types.ModuleType("unsupervised_detection_amd._ffi")
     mod.__file__ = path
     mod.__package__ = "unsupervised_detection_amd"
     sys.modules[mod.__name__] = mod
     exec(compile(src, path, "exec"), mod.__dict__)
-    import ctypes
-    mod.lib.udet_exp_knob.restype = None
-    mod.lib.udet_exp_knob.argtypes = [ctypes.c_int, ctypes.c_long]
     return mod.lib
+
+
+def load_experiment_build():
+    import ctypes
+    lib = load_library(os.path.join(ROOT, "unsupervised_detection_amd", "libudet_exp.so"))
+    lib.udet_exp_knob.restype = None
+    lib.udet_exp_knob.argtypes = [ctypes.c_int, ctypes.c_long]
+    return lib
 
 
 def main():

@@ -15,6 +15,7 @@
 #include <cstring>
 #include <cmath>
 #include <vector>
+#include <algorithm>
 #include <type_traits>
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -33,6 +34,7 @@ struct WinoParams {
   int BY, BX;  // workgroup blocks per sub-lattice image
   const float* zero16;
   float alpha;  // leaky slope
+  long long* ts;  // optional [workgroup][8] time stamps (round 6: where the ~13 us of per-launch fixed cost go; v4 kernel only)
 };
 
 #define CHECK(x)                                                                      \
@@ -733,6 +735,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   static_assert(W1 >= 0 && 4 * W0 + 4 * W1 == NW, "weight split");
   constexpr int STAGE = IN_BYTES + W_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  long long* const tsb = p.ts ? p.ts + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8 : nullptr;
+  auto stamp = [&](int i) {
+    if (tsb && threadIdx.x == 0) { tsb[i] = (i == 0 || i == 7) ? (long long)wall_clock64() : (long long)__builtin_readcyclecounter(); }
+  };
+  stamp(0);
+  stamp(1);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int role = wave >> 2, sub = wave & 3;
@@ -776,6 +784,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   }
   __syncthreads();
+  stamp(2);
   const float* ubase0 = p.u + (size_t)nb * (W_BYTES / 4);
   const size_t ustride = (size_t)gridDim.y * (W_BYTES / 4);
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -847,6 +856,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    stamp(3);
     ld_row(smem, R == 0 ? 1 : 0, ra);
     ld_row(smem, 2, rb);
     ld_bf(smem, I0, bf0);
@@ -925,6 +935,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   else body(std::integral_constant<int, 1>());
 
   // ---- output transform: column sums of the own rows, the roles' halves meet in LDS ----
+  stamp(4);
   __syncthreads();
   float* exch = reinterpret_cast<float*>(smem) + sub * (16 * 4 * 64);  // [r][4][lane]
   float s[2][2][16];  // [own row 0/1][b][r]
@@ -946,6 +957,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   __syncthreads();
   if (role == 1) return;
+  stamp(5);
   const int co = nb * BN + wn * 32 + li;
   const float bias = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
 #pragma unroll
@@ -968,6 +980,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       }
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  stamp(6);
+  stamp(7);
 }
 
 // U = G g G^T, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1];  layout [kg][nb][pos][half][BN][4]
@@ -1052,6 +1067,40 @@ static float run(const Shape& s, const float* x, int ldx, const float* w, const 
   CHECK(hipEventSynchronize(e1));
   float ms = 0.f;
   CHECK(hipEventElapsedTime(&ms, e0, e1));
+  if (V2 == 4 && getenv("WINO_TS")) {
+    const size_t nblk = (size_t)grid.x * grid.y;
+    long long* ts;
+    CHECK(hipMalloc(&ts, nblk * 8 * sizeof(long long)));
+    CHECK(hipMemset(ts, 0, nblk * 8 * sizeof(long long)));
+    WinoParams q = p;
+    q.ts = ts;
+    hipEvent_t a, b;
+    CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+    CHECK(hipEventRecord(a, 0));
+    hipLaunchKernelGGL(kern, grid, block, shmem, 0, q);
+    CHECK(hipEventRecord(b, 0));
+    CHECK(hipEventSynchronize(b));
+    float kms = 0.f;
+    CHECK(hipEventElapsedTime(&kms, a, b));
+    std::vector<long long> h(nblk * 8);
+    CHECK(hipMemcpy(h.data(), ts, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    // stamps: 0 wall clock (100 MHz) at entry, 1 cycle counter at entry, 2 after the halo zero-fill + tables, 3 first stage landed,
+    // 4 K loop done, 5 roles exchanged, 6 stores acknowledged, 7 wall clock at exit
+    long long w0 = h[0], w1 = h[7];
+    for (size_t i = 0; i < nblk; ++i) { w0 = std::min(w0, h[i * 8]); w1 = std::max(w1, h[i * 8 + 7]); }
+    double seg[5] = {0, 0, 0, 0, 0}, segmax[5] = {0, 0, 0, 0, 0}, first = 0, firstmax = 0, dur = 0;
+    for (size_t i = 0; i < nblk; ++i) {
+      for (int k = 0; k < 5; ++k) { const double v = (double)(h[i * 8 + k + 2] - h[i * 8 + k + 1]); seg[k] += v; segmax[k] = std::max(segmax[k], v); }
+      const double st = (double)(h[i * 8] - w0) * 10.0;  // ns
+      first += st; firstmax = std::max(firstmax, st);
+      dur += (double)(h[i * 8 + 7] - h[i * 8]) * 10.0;
+    }
+    printf("\n      [ts] event-bracket %.1f us; first entry -> last exit %.1f us; workgroup entry after the first: mean %.1f us max %.1f us; workgroup lifetime mean %.1f us\n",
+           kms * 1e3, (double)(w1 - w0) * 0.01, first / nblk * 1e-3, firstmax * 1e-3, dur / nblk * 1e-3);
+    const char* nm[5] = {"zero-fill+tables", "first stage lands", "K loop", "role exchange", "transform+stores"};
+    for (int k = 0; k < 5; ++k) printf("      [ts] %-18s mean %8.0f cycles  max %8.0f\n", nm[k], seg[k] / nblk, segmax[k]);
+    CHECK(hipFree(ts));
+  }
   printf("    %s<%d,%d,%d,%d> sched %d abl %d grid %dx%d lds %d KB S=%d: ", V2 == 4 ? "v4" : V2 == 3 ? "v3" : (V2 ? "v2" : "v1"), WTY, WTX, WN, NS, SCHED, ABL, grid.x, grid.y, shmem / 1024, S);
   return ms * 1e3f / reps;
 }

@@ -19,6 +19,7 @@
 #include <stdlib.h>
 
 #include <functional>
+#include <type_traits>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -176,32 +177,59 @@ __device__ __forceinline__ void igemm_store(const ConvParams& p, floatx16 (&acc)
   // slab: this workgroup holds a K slice; its partial tile goes to p.partial + slab_off + (class row) * ldp
   if (xp != nullptr && !(slab && p.fold) && (slab ? (reinterpret_cast<uintptr_t>(p.partial) & 15) == 0 : epilogue4_out_ok(p))) {
     const int lane = lh * 32 + li, rr = lane >> 3, c4 = (lane & 7) * 4;
+    // (round 6) the bias quad of a column block does not depend on the row: loaded once per block, not once per quad behind the previous
+    // quad's store; the two passes of a half block request their per-pixel operands together; the activation is selected once, outside
+    // the loops (conv_epilogue.h: epi4_*, EpiAct -- per element it cost five scalar branches)
+    float4 bias[TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int j = 0; j < TN; ++j) {
+      const int nb = n0 + wn * WTN + j * 32 + c4;
+      bias[j] = (!slab && nb < p.Cout) ? epi4_bias(p, nb) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const EpiAct ea = epi_act(p);
+    // (PLAIN: a launch with neither residual nor accumulate nor dU emission -- or a K slice writing its slab -- has NO global load in
+    // its store loop; with one, every wait for it also drains the stores issued before it: loads and stores share vmcnt on gfx950)
+    auto tile = [&](auto ELU, auto PLAIN_) {
+      constexpr bool PLAIN = decltype(PLAIN_)::value;
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int nb = n0 + wn * WTN + j * 32 + c4;
+      for (int i = 0; i < TM; ++i) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {  // accumulator registers 8h .. 8h+7 are rows 16h .. 16h+15 of the block
-          __builtin_amdgcn_wave_barrier();
+        for (int j = 0; j < TN; ++j) {
+          const int nb = n0 + wn * WTN + j * 32 + c4;
 #pragma unroll
-          for (int r = 0; r < 8; ++r) xp[((r & 3) + 8 * (r >> 2) + 4 * lh) * UDET_XP + li] = acc[i][j][8 * h + r];
-          __builtin_amdgcn_wave_barrier();  // same wave: LDS serves its instructions in order, only the compiler must not reorder
-#pragma unroll 1
-          for (int pass = 0; pass < 2; ++pass) {
-            const int row = wm * WTM + i * 32 + h * 16 + pass * 8 + rr;
-            const int off = rowoff[row];
-            const float4 v = *reinterpret_cast<const float4*>(&xp[(pass * 8 + rr) * UDET_XP + c4]);
-            if (off < 0) continue;
-            if (slab) {
-              if (nb < p.ldp) *reinterpret_cast<float4*>(p.partial + (slab_off + (long)(prow0 + row) * p.ldp + nb)) = v;
-            } else if (nb < p.Cout) {
-              conv_epilogue4(p, off, nb, v);
+          for (int h = 0; h < 2; ++h) {  // accumulator registers 8h .. 8h+7 are rows 16h .. 16h+15 of the block
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 8; ++r) xp[((r & 3) + 8 * (r >> 2) + 4 * lh) * UDET_XP + li] = acc[i][j][8 * h + r];
+            __builtin_amdgcn_wave_barrier();  // same wave: LDS serves its instructions in order, only the compiler must not reorder
+            int off[2];
+            float4 v[2];
+            Epi4Req rq[2];
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+              const int row = wm * WTM + i * 32 + h * 16 + pass * 8 + rr;
+              off[pass] = rowoff[row];
+              v[pass] = *reinterpret_cast<const float4*>(&xp[(pass * 8 + rr) * UDET_XP + c4]);
+              if (!PLAIN && !slab && off[pass] >= 0 && nb < p.Cout) epi4_request(p, off[pass], nb, rq[pass]);
+            }
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+              const int row = wm * WTM + i * 32 + h * 16 + pass * 8 + rr;
+              if (off[pass] < 0) continue;
+              if (slab) {
+                if (nb < p.ldp) *reinterpret_cast<float4*>(p.partial + (slab_off + (long)(prow0 + row) * p.ldp + nb)) = v[pass];
+              } else if (nb < p.Cout) {
+                if (PLAIN) epi4_finish_plain<decltype(ELU)::value>(p, off[pass], nb, v[pass], bias[j], ea.slope);
+                else epi4_finish<decltype(ELU)::value>(p, off[pass], nb, v[pass], bias[j], rq[pass], ea);
+              }
             }
           }
         }
       }
-    }
+    };
+    const bool plain = slab || epi4_plain(p);
+    if (!slab && p.act == ACT_ELU) { if (plain) tile(std::true_type(), std::true_type()); else tile(std::true_type(), std::false_type()); }
+    else { if (plain) tile(std::false_type(), std::true_type()); else tile(std::false_type(), std::false_type()); }
     return;
   }
 #pragma unroll
@@ -1659,7 +1687,7 @@ static ConvCfg tune_cfg_impl(ConvParams& p, hipStream_t stream) {
     if (ms < (a < b ? a : b) * 0.97f) { a = b = ms; best = d; }
   }
   if (conv_wino_ok(p)) {  // Winograd F(2x2,3x3): 2.25x fewer multiplications; K slices where the tiles do not fill the chip
-    for (int v = 0; v < 4; ++v) {  // (bit 0: tile shape, bit 1: four / eight waves)
+    for (int v = 0; v < 5; ++v) {  // (bit 0: tile shape, bit 1: four / eight waves; 4: the half-size form, two workgroups per CU)
       if (!conv_wino_variant_ok(p, v)) continue;
       const long wgs = conv_wino_workgroups(p, v);
       const int cap = conv_wino_max_ksplit(p, v);
@@ -1805,7 +1833,7 @@ int launch_conv(ConvParams& p, hipStream_t stream) {
     for (auto& t : TILES) tile = tile || (c.bm == t[0] && c.bn == t[1]);
     if (c.ws == 3) tile = (c.bm == 4 || c.bm == 8) && (c.bn == 16 || c.bn == 32);
     if (c.ws == 7 || c.ws == 8) tile = true;  // (the direct 2-channel kernels carry no tile; eligibility is re-checked below)
-    if (c.ws == 9) tile = c.bm >= 0 && c.bm <= 3;  // (Winograd: bm carries the variant; eligibility is re-checked below)
+    if (c.ws == 9) tile = c.bm >= 0 && c.bm <= 4;  // (Winograd: bm carries the variant; eligibility is re-checked below)
     if (!tile || c.ws < 0 || c.ws > 9) {
       c = heuristic_cfg(p);
     } else {
@@ -1860,7 +1888,7 @@ int launch_conv(ConvParams& p, hipStream_t stream) {
       }
       if (g_wino_scratch && launch_wino_from_packed(p, g_wino_scratch, np9, stream) == UDET_OK) { p.wino_u = g_wino_scratch; p.wino_np = np9; }
     }
-    const int v9 = g_force_bm & 3;
+    const int v9 = (g_force_bm & 7) == 4 ? 4 : (g_force_bm & 3);
     if (conv_wino_ok(p) && (conv_wino_variant_ok(p, v9) || conv_wino_variant_ok(p, v9 ^ 1))) {
       c.ws = 9; c.bm = conv_wino_variant_ok(p, v9) ? v9 : (v9 ^ 1); c.bn = 0; c.fold = 0; c.tail = 0;
       if (g_force_ks < 0) c.ks = 1;

@@ -42,6 +42,22 @@ namespace udet {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
+// libudet_exp.so only (tools/wino_stamps.py): per-workgroup time stamps of the Winograd kernels -- where a launch's fixed cost goes.
+// [workgroup < 512][8]: 0 entry, 1 halo zero-fill + tables done, 2 first stage landed, 3 K loop done, 4 tile in LDS (output transform
+// done), 5 stores issued, 6 stores acknowledged (shader cycles)
+#ifdef UDET_EXPERIMENT
+__device__ long long g_wino_ts[512 * 8];
+#define WINO_STAMP(i)                                                                                  \
+  do {                                                                                                 \
+    if (threadIdx.x == 0 && blockIdx.x < 512 && blockIdx.z == 0) g_wino_ts[blockIdx.x * 8 + (i)] = (long long)__builtin_readcyclecounter(); \
+  } while (0)
+extern "C" int udet_exp_wino_stamps(long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_wino_ts), (size_t)(n < 512 * 8 ? n : 512 * 8) * sizeof(long long));
+}
+#else
+#define WINO_STAMP(i) do {} while (0)
+#endif
+
 static constexpr int wino_row_slots(int pw) { return (pw + 3) / 8 * 8 + 4; }  // smallest S >= pw with S % 8 == 4
 
 template <int WTY, int WTX, int WN>
@@ -65,6 +81,94 @@ struct WinoGeom {
   static_assert(S % 8 == 4 && S >= PW && HP >= CS, "row stride");
   static_assert(LDS_BYTES >= 4 * 128 * 32 * 4 && LDS_BYTES <= 160 * 1024, "the epilogue transposes 16 KB per wave through the stage buffers");
 };
+
+// A wave's 4 x 8 tile block -- 128 output pixels x 32 channels in `xp` ([tile pixel][32 channels], the LDS transpose of the output
+// transform) -- through the epilogue into memory, or into its K slice's slab.  Plain launches keep FOUR quads in flight per lane (bias
+// loaded once, per-pixel operands requested before the first store: conv_epilogue.h, epi4_*): one quad at a time, each iteration waited
+// out a global-load latency behind the previous iteration's store -- ~10 us of the 55 us a 16-stage generator layer took.
+__device__ __forceinline__ void wino_store_block(const ConvParams& p, const float* xp, int lane, int n4, int n, int d, int sy, int sx, int Hs, int Ws,
+                                                 int Yb, int Xb) {
+  const bool slab = p.ksplit > 1;
+  const bool vec = slab ? ((reinterpret_cast<uintptr_t>(p.partial) & 15) == 0 && (p.ldp & 3) == 0) : epilogue4_out_ok(p);
+  const int c4 = (lane & 7) * 4;
+  if (!slab && vec) {
+    if (n4 >= p.Cout) return;
+    const float4 bias = epi4_bias(p, n4);
+    const EpiAct ea = epi_act(p);
+    // pixel of quad P of the block (-1: outside the grid)
+    auto pix = [&](int P) {
+      const int m = P >> 2, a = (P >> 1) & 1, b = P & 1;
+      const int oy = Yb + 2 * (m >> 3) + a, ox = Xb + 2 * (m & 7) + b;
+      return (oy >= Hs || ox >= Ws) ? -1 : (n * p.H + sy + d * oy) * p.W + sx + d * ox;
+    };
+    auto loop = [&](auto ELU) {  // (the activation is selected HERE, once -- not per element inside the loop: conv_epilogue.h, EpiAct)
+      if (epi4_plain(p)) {  // store-only launches: nothing in the loop waits for memory
+#pragma unroll 1
+        for (int k0 = 0; k0 < 16; k0 += 4) {  // four LDS reads in flight, then four stores
+          float4 v[4];
+          int off[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int P = (k0 + u) * 8 + (lane >> 3);
+            v[u] = *reinterpret_cast<const float4*>(&xp[P * 32 + c4]);
+            off[u] = pix(P);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (off[u] >= 0) epi4_finish_plain32<decltype(ELU)::value>(p, off[u], n4, v[u], bias, ea.slope);  // (conv_wino_ok: 32-bit offsets)
+        }
+        return;
+      }
+      // residual / accumulate / dU emission: the operands of EIGHT quads are requested before the first of them is stored (every wait
+      // for a load also drains the stores issued before it: twice per tile here instead of once per quad)
+#pragma unroll 1
+      for (int k0 = 0; k0 < 16; k0 += 8) {
+        float4 v[8];
+        int off[8];
+        Epi4Req rq[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int P = (k0 + u) * 8 + (lane >> 3);
+          v[u] = *reinterpret_cast<const float4*>(&xp[P * 32 + c4]);
+          off[u] = pix(P);
+          if (off[u] >= 0) epi4_request(p, off[u], n4, rq[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (off[u] >= 0) epi4_finish<decltype(ELU)::value>(p, off[u], n4, v[u], bias, rq[u], ea);
+      }
+    };
+    if (p.act == ACT_ELU) loop(std::true_type());
+    else loop(std::false_type());
+    return;
+  }
+  const long slab_off = (long)blockIdx.z * p.N * p.H * p.W * p.ldp;
+#pragma unroll 1
+  for (int k = 0; k < 16; ++k) {
+    const int P = k * 8 + (lane >> 3);
+    const int m = P >> 2, a = (P >> 1) & 1, b = P & 1;
+    const int oy = Yb + 2 * (m >> 3) + a, ox = Xb + 2 * (m & 7) + b;
+    const float4 v = *reinterpret_cast<const float4*>(&xp[P * 32 + c4]);
+    if (oy >= Hs || ox >= Ws) continue;
+    const int off = (n * p.H + sy + d * oy) * p.W + sx + d * ox;
+    if (slab) {
+      float* dst = p.partial + (slab_off + (long)off * p.ldp + n4);
+      if (vec) {
+        if (n4 < p.ldp) *reinterpret_cast<float4*>(dst) = v;
+      } else {
+        if (n4 < p.ldp) dst[0] = v.x;
+        if (n4 + 1 < p.ldp) dst[1] = v.y;
+        if (n4 + 2 < p.ldp) dst[2] = v.z;
+        if (n4 + 3 < p.ldp) dst[3] = v.w;
+      }
+      continue;
+    }
+    if (n4 < p.Cout) conv_epilogue(p, off, n4, v.x);
+    if (n4 + 1 < p.Cout) conv_epilogue(p, off, n4 + 1, v.y);
+    if (n4 + 2 < p.Cout) conv_epilogue(p, off, n4 + 2, v.z);
+    if (n4 + 3 < p.Cout) conv_epilogue(p, off, n4 + 3, v.w);
+  }
+}
 
 template <int WTY, int WTX, int WN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_wino_kernel(const ConvParams p, const int dil,
@@ -276,39 +380,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
   }
   __builtin_amdgcn_wave_barrier();  // same wave: LDS serves its instructions in order, only the compiler must not reorder
-  const bool slab = p.ksplit > 1;
-  const bool vec = slab ? ((reinterpret_cast<uintptr_t>(p.partial) & 15) == 0 && (p.ldp & 3) == 0) : epilogue4_out_ok(p);
-  const int c4 = (lane & 7) * 4, n4 = nb * BN + wn * 32 + c4;
-  const long slab_off = (long)blockIdx.z * p.N * p.H * p.W * p.ldp;
-#pragma unroll 1
-  for (int k = 0; k < 16; ++k) {
-    const int P = k * 8 + (lane >> 3);
-    const int m = P >> 2, a = (P >> 1) & 1, b = P & 1;
-    const int oy = Y0 + 2 * (wty * 4 + (m >> 3)) + a, ox = X0 + 2 * (wtx * 8 + (m & 7)) + b;
-    const float4 v = *reinterpret_cast<const float4*>(&xp[P * 32 + c4]);
-    if (oy >= Hs || ox >= Ws) continue;
-    const int off = (n * p.H + sy + d * oy) * p.W + sx + d * ox;
-    if (slab) {
-      float* dst = p.partial + (slab_off + (long)off * p.ldp + n4);
-      if (vec) {
-        if (n4 < p.ldp) *reinterpret_cast<float4*>(dst) = v;
-      } else {
-        if (n4 < p.ldp) dst[0] = v.x;
-        if (n4 + 1 < p.ldp) dst[1] = v.y;
-        if (n4 + 2 < p.ldp) dst[2] = v.z;
-        if (n4 + 3 < p.ldp) dst[3] = v.w;
-      }
-      continue;
-    }
-    if (vec) {
-      if (n4 < p.Cout) conv_epilogue4(p, off, n4, v);
-    } else {
-      if (n4 < p.Cout) conv_epilogue(p, off, n4, v.x);
-      if (n4 + 1 < p.Cout) conv_epilogue(p, off, n4 + 1, v.y);
-      if (n4 + 2 < p.Cout) conv_epilogue(p, off, n4 + 2, v.z);
-      if (n4 + 3 < p.Cout) conv_epilogue(p, off, n4 + 3, v.w);
-    }
-  }
+  wino_store_block(p, xp, lane, nb * BN + wn * 32 + (lane & 7) * 4, n, d, sy, sx, Hs, Ws, Y0 + 8 * wty, X0 + 16 * wtx);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -335,6 +407,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   constexpr int W1 = (NW - 4 * W0) / 4;                     // ... of a role-1 wave
   static_assert(W1 >= 0 && 4 * W0 + 4 * W1 == NW, "weight split");
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  WINO_STAMP(0);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int role = wave >> 2, sub = wave & 3;
@@ -390,6 +463,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
   }
   __syncthreads();
+  WINO_STAMP(1);
   const int np = p.wino_np;
   const float* ubase = p.wino_u + (size_t)nb * BN * 4;
   const size_t ustride = (size_t)32 * np * 4;  // floats per stage
@@ -456,6 +530,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    WINO_STAMP(2);
     ld_row(smem, R == 0 ? 1 : 0, ra);
     ld_row(smem, 2, rb);
     ld_bf(smem, I0, bf0);
@@ -520,6 +595,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   else body(std::integral_constant<int, 1>());
 
   // ---- output transform: column sums of the own position rows; the roles' halves meet in LDS ([r][4][lane] per wave tile) ----
+  WINO_STAMP(3);
   __syncthreads();
   float* xp = reinterpret_cast<float*>(smem) + sub * (128 * 32);  // 16 KB per wave tile: the exchange, then the transposing store
   float s[2][2][16];                                              // [own row 0 / 1][b][r]
@@ -558,39 +634,245 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int q = 0; q < 4; ++q) xp[(m * 4 + q) * 32 + li] = yv[r][q];
   }
   __builtin_amdgcn_wave_barrier();  // same wave: LDS serves its instructions in order, only the compiler must not reorder
-  const bool slab = p.ksplit > 1;
-  const bool vec = slab ? ((reinterpret_cast<uintptr_t>(p.partial) & 15) == 0 && (p.ldp & 3) == 0) : epilogue4_out_ok(p);
-  const int c4 = (lane & 7) * 4, n4 = nb * BN + wn * 32 + c4;
-  const long slab_off = (long)blockIdx.z * p.N * p.H * p.W * p.ldp;
-#pragma unroll 1
-  for (int k = 0; k < 16; ++k) {
-    const int P = k * 8 + (lane >> 3);
-    const int m = P >> 2, a = (P >> 1) & 1, b = P & 1;
-    const int oy = Y0 + 2 * (wty * 4 + (m >> 3)) + a, ox = X0 + 2 * (wtx * 8 + (m & 7)) + b;
-    const float4 v = *reinterpret_cast<const float4*>(&xp[P * 32 + c4]);
-    if (oy >= Hs || ox >= Ws) continue;
-    const int off = (n * p.H + sy + d * oy) * p.W + sx + d * ox;
-    if (slab) {
-      float* dst = p.partial + (slab_off + (long)off * p.ldp + n4);
-      if (vec) {
-        if (n4 < p.ldp) *reinterpret_cast<float4*>(dst) = v;
-      } else {
-        if (n4 < p.ldp) dst[0] = v.x;
-        if (n4 + 1 < p.ldp) dst[1] = v.y;
-        if (n4 + 2 < p.ldp) dst[2] = v.z;
-        if (n4 + 3 < p.ldp) dst[3] = v.w;
-      }
-      continue;
-    }
-    if (vec) {
-      if (n4 < p.Cout) conv_epilogue4(p, off, n4, v);
-    } else {
-      if (n4 < p.Cout) conv_epilogue(p, off, n4, v.x);
-      if (n4 + 1 < p.Cout) conv_epilogue(p, off, n4 + 1, v.y);
-      if (n4 + 2 < p.Cout) conv_epilogue(p, off, n4 + 2, v.z);
-      if (n4 + 3 < p.Cout) conv_epilogue(p, off, n4 + 3, v.w);
+  WINO_STAMP(4);
+  wino_store_block(p, xp, lane, nb * BN + wn * 32 + (lane & 7) * 4, n, d, sy, sx, Hs, Ws, Y0 + 8 * wty, X0 + 16 * wtx);
+#ifdef UDET_EXPERIMENT
+  WINO_STAMP(5);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  WINO_STAMP(6);
+#endif
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Half-size form (round 6): 32 tiles x 64 channels per workgroup, FOUR waves = the two roles of the eight-wave form x two channel
+// halves, a TWO-buffer LDS ring of 39 KB stages -- 78 KB per workgroup, so that TWO workgroups share a CU (two waves per SIMD again,
+// now of different workgroups at different points of their stages).  Written for the launches the other forms leave half the chip
+// idle on: the generator's 128-channel layers at 48 x 96 (models/nets.py:23-31) are 72 blocks of 64 tiles x 2 channel blocks = 144
+// workgroups on 256 CUs, each alone on its CU at ~0.6 of the CU's matrix rate; as 288 half-size workgroups every CU has work and
+// the 32 CUs that hold two run them interleaved.  One barrier per stage: stage k + 1's DMA goes out when the barrier that ended
+// stage k - 1 has released its buffer, and has the whole of stage k (32 MFMAs per wave) to land.
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct WinoHalfGeom {
+  static constexpr int NS = 2, TH = 4, TW = 8;
+  static constexpr int PH = 2 * TH + 2, PW = 2 * TW + 2;  // 10 x 18 halo pixels
+  static constexpr int CS = PW / 2, S = wino_row_slots(PW), HP = S / 2;
+  static constexpr int IN_SLOTS = 2 * PH * S;              // 400
+  static constexpr int IN_WINSTR = (IN_SLOTS + 63) / 64;   // 7 wave-instructions of 64 slots
+  static constexpr int IN_INSTR = (IN_WINSTR + 3) / 4;     // per wave (the last round is partly filled)
+  static constexpr int IN_BYTES = IN_WINSTR * 1024;
+  static constexpr int BN = 64;
+  static constexpr int W_BYTES = 16 * 2 * BN * 16;         // 32 KB
+  static constexpr int NW = W_BYTES / 1024;                // 32 weight wave-instructions per stage, 8 per wave
+  static constexpr int STAGE = IN_BYTES + W_BYTES;         // 39 KB
+  static constexpr int LDS_BYTES = NS * STAGE;             // 78 KB: two workgroups per CU
+  static_assert(LDS_BYTES >= 4 * 128 * 32 * 4 && 2 * LDS_BYTES <= 160 * 1024, "epilogue scratch / two workgroups per CU");
+};
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_wino_half_kernel(const ConvParams p, const int dil, const int BY,
+                                                                                                       const int BX) {
+  typedef WinoHalfGeom G;
+  constexpr int TH = G::TH, TW = G::TW, PH = G::PH, S = G::S, HP = G::HP, CS = G::CS;
+  constexpr int IN_INSTR = G::IN_INSTR, IN_BYTES = G::IN_BYTES, BN = G::BN, STAGE = G::STAGE, NW = G::NW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int role = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, lh = lane >> 5;
+
+  int bid = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int NB = (p.Cout + BN - 1) / BN;
+  const int nb = bid % NB;
+  bid /= NB;
+  const int d = dil;
+  const int bx = bid % BX;
+  int rem = bid / BX;
+  const int by = rem % BY;
+  rem /= BY;
+  const int sx = rem % d;
+  rem /= d;
+  const int sy = rem % d;
+  const int n = rem / d;
+  const int Hs = (p.H - sy + d - 1) / d, Ws = (p.W - sx + d - 1) / d;
+  const int Y0 = by * 2 * TH, X0 = bx * 2 * TW;
+  const int nkg_all = p.Kc >> 3;
+  int kg0 = 0, kg1 = nkg_all;
+  if (p.ksplit > 1) {
+    kg0 = (int)((long)nkg_all * blockIdx.z / p.ksplit);
+    kg1 = (int)((long)nkg_all * (blockIdx.z + 1) / p.ksplit);
+  }
+  const int nkg = kg1 - kg0;
+
+  // input DMA: wave-instruction j = i * 4 + wave covers slots [64 j, 64 j + 64); byte offsets + EXEC masks as in the other forms
+  unsigned in_voff[IN_INSTR];
+  unsigned long long in_mask[IN_INSTR];
+#pragma unroll
+  for (int i = 0; i < IN_INSTR; ++i) {
+    const int j = i * 4 + wave;
+    const int Lx = j * 64 + lane;
+    const int quad = Lx / (PH * S), r2 = Lx - quad * (PH * S);
+    const int row = r2 / S, s = r2 - row * S;
+    const int par = s / HP, cs = s - par * HP;
+    const int col = 2 * cs + par;
+    const int yy = Y0 - 1 + row, xx = X0 - 1 + col;
+    const bool in_stage = j < G::IN_WINSTR;
+    const bool ok = in_stage && quad < 2 && cs < CS && yy >= 0 && yy < Hs && xx >= 0 && xx < Ws;
+    in_voff[i] = ok ? (unsigned)(((n * p.H + sy + d * yy) * p.W + sx + d * xx) * p.ldx + p.x_coff + quad * 4) * 4u : 0u;
+    in_mask[i] = __ballot(ok);
+    if (!ok && in_stage) {
+#pragma unroll
+      for (int b = 0; b < G::NS; ++b) *reinterpret_cast<float4*>(smem + b * STAGE + Lx * 16) = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
+  __syncthreads();
+  const int np = p.wino_np;
+  const float* ubase = p.wino_u + (size_t)nb * BN * 4;
+  const size_t ustride = (size_t)32 * np * 4;  // floats per stage
+  const unsigned w_voff = (unsigned)lane * 16;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  auto dma_stage = [&](int kg, int buf) {  // this wave's share of a stage: its input rounds, then 8 of the 32 weight instructions
+#pragma unroll
+    for (int i = 0; i < IN_INSTR; ++i) {
+      if (i * 4 + wave < G::IN_WINSTR)
+        asm volatile("s_mov_b32 m0, %2\n\ts_mov_b64 exec, %3\n\tglobal_load_lds_dwordx4 %0, %1\n\ts_mov_b64 exec, -1" ::"v"(in_voff[i]), "s"(p.x + kg * 8),
+                     "s"(lds0 + buf * STAGE + (i * 4 + wave) * 1024), "s"(in_mask[i])
+                     : "m0");
+    }
+#pragma unroll
+    for (int i = 0; i < NW / 4; ++i) {
+      const int w = i * 4 + wave;
+      const float* us = ubase + (size_t)kg * ustride + (size_t)w * np * 4;
+      asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(w_voff), "s"(us), "s"(lds0 + buf * STAGE + IN_BYTES + w * 1024) : "m0");
+    }
+  };
+
+  floatx16 acc[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[q][r] = 0.f;
+
+  const int ty = li >> 3, tx = li & 7;
+  const int a_base = ((lh * PH + 2 * ty) * S + tx) * 16;
+  const int b_base = IN_BYTES + (lh * BN + wn * 32 + li) * 16;
+  auto ld_row = [&](const char* sb, int r, float4 (&dst)[4]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dst[c] = *reinterpret_cast<const float4*>(sb + a_base + (r * S + (c & 1) * HP + (c >> 1)) * 16);
+  };
+  auto ld_bf = [&](const char* sb, int i, float4 (&dst)[4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dst[q] = *reinterpret_cast<const float4*>(sb + b_base + (4 * i + q) * (2 * BN * 16));
+  };
+  auto comp = [](const float4& v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); };
+
+  // (both role instantiations execute the same number of barriers: the trip count nkg is workgroup-uniform -- see the barrier contract
+  // note in conv_wgrad_wino.hip)
+  auto body = [&](auto ROLE) {
+    constexpr int R = decltype(ROLE)::value;
+    constexpr int I0 = R == 0 ? 1 : 0, I1 = R == 0 ? 2 : 3;  // position rows of phase 0 / phase 1
+    float4 ra[4], rb[4], rc[4], rd[4], bf0[4], bf1[4];
+    float v1[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) ra[c] = rb[c] = rc[c] = rd[c] = bf0[c] = bf1[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (nkg > 0) dma_stage(kg0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    for (int k = 0; k < nkg; ++k) {
+      const char* sb = smem + (k & 1) * STAGE;
+      if (k + 1 < nkg) dma_stage(kg0 + k + 1, (k + 1) & 1);  // (that buffer held stage k - 1: released by the barrier below)
+      ld_row(sb, R == 0 ? 1 : 0, ra);
+      ld_row(sb, 2, rb);
+      ld_bf(sb, I0, bf0);
+      if (R == 1) { ld_row(sb, 1, rc); ld_row(sb, 3, rd); }
+      ld_bf(sb, I1, bf1);
+      __builtin_amdgcn_sched_barrier(0);
+      // ---------------- phase 0 ----------------
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float t[4], v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float a = comp(ra[c], j), b = comp(rb[c], j);
+          t[c] = R == 0 ? a + b : a - b;  // row 1: d1 + d2; row 0: d0 - d2
+        }
+        v[0] = t[0] - t[2]; v[1] = t[1] + t[2]; v[2] = t[2] - t[1]; v[3] = t[1] - t[3];
+        if (R == 0) {  // row 2: d2 - d1, kept for phase 1
+          float u[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) u[c] = comp(rb[c], j) - comp(ra[c], j);
+          v1[j][0] = u[0] - u[2]; v1[j][1] = u[1] + u[2]; v1[j][2] = u[2] - u[1]; v1[j][3] = u[1] - u[3];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[q], comp(bf0[q], j), acc[q], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // ---------------- phase 1 ----------------
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float v[4];
+        if (R == 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = v1[j][q];
+        } else {
+          float t[4];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) t[c] = comp(rc[c], j) - comp(rd[c], j);  // row 3: d1 - d3
+          v[0] = t[0] - t[2]; v[1] = t[1] + t[2]; v[2] = t[2] - t[1]; v[3] = t[1] - t[3];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[4 + q] = __builtin_amdgcn_mfma_f32_32x32x2f32(v[q], comp(bf1[q], j), acc[4 + q], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // stage k + 1 has landed (this wave's share); every wave is done reading stage k
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+  };
+  if (role == 0) body(std::integral_constant<int, 0>());
+  else body(std::integral_constant<int, 1>());
+
+  // ---- output transform: as in the eight-wave form (the roles' column sums meet in LDS), one 16 KB scratch per channel half ----
+  float* xp = reinterpret_cast<float*>(smem) + wn * (128 * 32);
+  float s[2][2][16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      s[h][0][r] = acc[h * 4 + 0][r] + acc[h * 4 + 1][r] + acc[h * 4 + 2][r];
+      s[h][1][r] = acc[h * 4 + 1][r] - acc[h * 4 + 2][r] - acc[h * 4 + 3][r];
+    }
+  if (role == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      xp[(r * 4 + 0) * 64 + lane] = s[0][0][r];
+      xp[(r * 4 + 1) * 64 + lane] = s[0][1][r];
+      xp[(r * 4 + 2) * 64 + lane] = s[1][0][r];
+      xp[(r * 4 + 3) * 64 + lane] = s[1][1][r];
+    }
+  }
+  __syncthreads();
+  if (role == 1) return;
+  float yv[16][4];
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const float s0 = xp[(r * 4 + b) * 64 + lane], s3 = xp[(r * 4 + 2 + b) * 64 + lane];
+      yv[r][b] = s0 + (s[0][b][r] + s[1][b][r]);
+      yv[r][2 + b] = (s[0][b][r] - s[1][b][r]) - s3;
+    }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) xp[(m * 4 + q) * 32 + li] = yv[r][q];
+  }
+  __builtin_amdgcn_wave_barrier();
+  wino_store_block(p, xp, lane, nb * BN + wn * 32 + (lane & 7) * 4, n, d, sy, sx, Hs, Ws, Y0, X0);
 }
 
 // ---- weight transform: U = G g G^T, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1] -------------------------------------------------------
@@ -683,15 +965,15 @@ bool conv_wino_ok(const ConvParams& p) {
   if ((long)p.N * p.H * p.W * (long)p.ldy >= (1L << 31) || (long)p.N * p.H * p.W * (long)p.ldx >= (1L << 30)) return false;
   return conv_wino_geometry(p, &d, w);
 }
-static int variant_bn(int v) { return (v & 1) == 0 ? 64 : 32; }  // bit 0: tile shape, bit 1: the eight-wave form
+static int variant_bn(int v) { return v == 4 ? 64 : ((v & 1) == 0 ? 64 : 32); }  // bit 0: tile shape, bit 1: the eight-wave form; 4: the half-size form
 bool conv_wino_variant_ok(const ConvParams& p, int v) {
-  if (v < 0 || v > 3) return false;
+  if (v < 0 || v > 4) return false;
   const int bn = variant_bn(v);
   if (p.wino_np % bn != 0) return false;
   return p.Cout > bn / 2 || bn == 32;  // (a block twice as wide as the layer only multiplies zeros)
 }
 static void variant_blocks(const ConvParams& p, int v, int d, int* BY, int* BX) {
-  const int th = 8, tw = (v & 1) ? 16 : 8;  // tiles per workgroup
+  const int th = v == 4 ? 4 : 8, tw = (v & 1) ? 16 : 8;  // tiles per workgroup
   const int Hs = (p.H + d - 1) / d, Ws = (p.W + d - 1) / d;
   *BY = (Hs + 2 * th - 1) / (2 * th);
   *BX = (Ws + 2 * tw - 1) / (2 * tw);
@@ -726,6 +1008,17 @@ static int launch_variant(const ConvParams& p, int d, int BY, int BX, hipStream_
   UDET_HIP(hipGetLastError());
   return UDET_OK;
 }
+static int launch_half(const ConvParams& p, int d, int BY, int BX, hipStream_t stream) {
+  typedef WinoHalfGeom G;
+  static std::once_flag once;
+  static hipError_t attr = hipSuccess;
+  std::call_once(once, [&]() { attr = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wino_half_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES); });
+  UDET_HIP(attr);
+  dim3 grid(p.N * d * d * BY * BX * ((p.Cout + G::BN - 1) / G::BN), 1, p.ksplit > 1 ? p.ksplit : 1);
+  UDET_LAUNCH(conv_wino_half_kernel, grid, dim3(256), G::LDS_BYTES, stream, p, d, BY, BX);
+  UDET_HIP(hipGetLastError());
+  return UDET_OK;
+}
 int launch_conv_wino(ConvParams& p, int variant, int ks, hipStream_t stream) {
   int d, w[9], BY, BX;
   if (!conv_wino_ok(p) || !conv_wino_geometry(p, &d, w) || !conv_wino_variant_ok(p, variant)) {
@@ -742,6 +1035,7 @@ int launch_conv_wino(ConvParams& p, int variant, int ks, hipStream_t stream) {
   if (variant == 0) rc = launch_variant<2, 1, 2, false>(p, d, BY, BX, stream);
   else if (variant == 1) rc = launch_variant<2, 2, 1, false>(p, d, BY, BX, stream);
   else if (variant == 2) rc = launch_variant<2, 1, 2, true>(p, d, BY, BX, stream);
+  else if (variant == 4) rc = launch_half(p, d, BY, BX, stream);
   else rc = launch_variant<2, 2, 1, true>(p, d, BY, BX, stream);
   if (rc != UDET_OK) return rc;
   if (p.ksplit > 1) return launch_splitk_second_pass(p, stream);
