@@ -34,6 +34,21 @@ namespace udet {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef _Float16 halfx4 __attribute__((ext_vector_type(4)));
 
+// libudet_exp.so only (tools/igemm_stamps.py): per-workgroup cycle stamps of the LDS-DMA kernel -- 0 entry, 1 tables done, 2 first stage
+// landed, 3 K loop done, 4 tile stored (issued), 5 stores acknowledged
+#ifdef UDET_EXPERIMENT
+__device__ long long g_igemm_ts[1024 * 8];
+#define IGEMM_STAMP(i)                                                                                                               \
+  do {                                                                                                                               \
+    if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && bid_x < 1024) g_igemm_ts[bid_x * 8 + (i)] = (long long)__builtin_readcyclecounter(); \
+  } while (0)
+extern "C" int udet_exp_igemm_stamps(long long* host, int n) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_igemm_ts), (size_t)(n < 1024 * 8 ? n : 1024 * 8) * sizeof(long long));
+}
+#else
+#define IGEMM_STAMP(i) do {} while (0)
+#endif
+
 // Flat-K cursor.  K runs channel-block-major: for every block of CB = min(Kc,32) input channels all taps of the launch,
 // then the next channel block (the last block may be narrower).  A workgroup therefore re-visits its ~3 input rows
 // for all taps of one channel block while they are still in L1/L2, instead of streaming the whole channel depth once
@@ -590,6 +605,7 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvParams& p, const i
   __shared__ int tap_w[UDET_MAX_TAPS];
   __shared__ int s_last;
 
+  IGEMM_STAMP(0);
   const int tid = threadIdx.x;
   const int role = __builtin_amdgcn_readfirstlane(tid >> 8);  // 0 = MFMA waves, 1 = staging waves
   const int t = tid & 255;
@@ -620,6 +636,7 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvParams& p, const i
   const int OHWq = tc.OHWq, Mtot = tc.Mtot /* of this class / segment */, m0 = tc.m0, tap0 = tc.tap0, ntc = tc.ntc, ooy = tc.ooy, oox = tc.oox;
   const int n0 = blockIdx.y * BN;
   const int Hs = p.H >> p.up_shift, Ws = p.W >> p.up_shift;
+  IGEMM_STAMP(6);
 
   for (int i = tid; i < ntc; i += 512) {
     const ConvTap tp = conv_tap(p, tap0 + i);
@@ -649,7 +666,9 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvParams& p, const i
   }
   // slab of this slice: regular split-K keeps whole-output slabs, the tail split only the rows from tail_prow0 on
   const long slab_off = p.tail_ks > 1 ? ((long)kz * (p.Mall - p.tail_prow0) - p.tail_prow0) * p.ldp : (long)kz * p.Mall * p.ldp;
+  IGEMM_STAMP(7);
   __syncthreads();
+  IGEMM_STAMP(1);
 
   if (role == 1) {
     // ------------------------------------------------ staging waves ------------------------------------------------
@@ -876,6 +895,7 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvParams& p, const i
     }
   };
   handover();
+  IGEMM_STAMP(2);
   {
     int buf = 0;
     for (int c = c_begin; c < c_end; ++c) {
@@ -884,6 +904,7 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvParams& p, const i
       buf = buf + 1 == NS ? 0 : buf + 1;
     }
   }
+  IGEMM_STAMP(3);
   if (F16 && xscale != 1.f) {
     const float inv = 1.f / xscale;
 #pragma unroll
@@ -896,6 +917,11 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvParams& p, const i
   igemm_store<TM, TN, WTM, WTN>(p, acc, rowoff, wm, wn, li, lh, n0, tc.prow0 + m0, Mtot, knz > 1, slab_off,
                                 xpose_scratch<sizeof(As), sizeof(Bs)>(&As[0][0][0], &Bs[0][0][0], wave));
   if (p.ksplit > 1 && p.fold) splitk_fold<BM, BN, 256>(p, rowoff, &s_last, t, n0, tc.prow0 + m0, Mtot, blockIdx.y * grid_x + bid);
+#ifdef UDET_EXPERIMENT
+  IGEMM_STAMP(4);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  IGEMM_STAMP(5);
+#endif
 }
 template <int BM, int BN, int WAVES_M, int WAVES_N, int NS, bool F16 = false>
 __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void conv_igemm_dma_kernel(const ConvParams p) {

@@ -12,7 +12,10 @@
 // Same ConvParams contract as conv_igemm (tap list, NN x2 read, TF SAME padding through the tap offsets).  The four
 // output-parity classes of a stride-2 backward-data pass / transposed convolution are blockIdx.z: each class is a stride-1
 // convolution over the dY grid with its own taps (and its own halo geometry) whose outputs land on one sub-lattice.
+#include <type_traits>
+
 #include "common.h"
+#include "conv_epilogue.h"
 
 namespace udet {
 
@@ -339,13 +342,56 @@ __global__ __launch_bounds__(256) void conv_tile_kernel(const ConvParams p, cons
       }
     }
   };
+  const EpiAct ea = epi_act(p);
   if (plain) {
     float* ycol = p.y + p.y_coff + nn;
     const int xstep = p.osx * p.ldy;
-    rows([&](int row, int ox, float v) { ycol[(size_t)row * p.ldy + (size_t)ox * xstep] = act_fwd(v + bias, p.act, p.alpha); });
-  } else {
-    rows([&](int row, int ox, float v) { tile_epilogue(p, row + ox * p.osx, nn, v); });
+    // (the activation is selected once, not per element: conv_epilogue.h, EpiAct)
+    if (p.act == ACT_ELU) rows([&](int row, int ox, float v) { ycol[(size_t)row * p.ldy + (size_t)ox * xstep] = act_fwd_c<true>(v + bias, ea.slope); });
+    else rows([&](int row, int ox, float v) { ycol[(size_t)row * p.ldy + (size_t)ox * xstep] = act_fwd_c<false>(v + bias, ea.slope); });
+    return;
   }
+  // Residual / accumulate / second output / dU emission (the stride-2 backward-data launches): ONE ROW of the thread's outputs at a time,
+  // every operand of the row requested before the row's first store.  Element by element (round 5) each load waited behind the previous
+  // element's stores -- loads and stores share vmcnt on gfx950, a wait for the one drains the other: 16 drains per row instead of one.
+  const bool emit_u = p.uo && nn >= p.u_c0 && nn < p.u_c1;
+  auto generic = [&](auto ELU) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int oy = oy0 + wave * TM + i;
+      if (oy >= p.OHq) continue;
+      const int row = (n * p.OH + oy * p.osy + ooy) * p.OW + oox;
+      constexpr int NE = NW == 32 ? 16 : 8;
+      float rs[NE], ac[NE], ua[NE];
+      int off[NE];
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        const int ox = NW == 32 ? ox0 + (e & 3) + 8 * (e >> 2) + 4 * grp : ox0 + (e >> 2) * 16 + grp * 4 + (e & 3);
+        off[e] = ox < p.OWq ? row + ox * p.osx : -1;
+        rs[e] = ac[e] = ua[e] = 0.f;
+        if (off[e] >= 0) {
+          if (p.res) rs[e] = p.res[(size_t)off[e] * p.ldres + p.res_coff + nn];
+          if (p.accumulate) ac[e] = p.y[(size_t)off[e] * p.ldy + p.y_coff + nn];
+          if (emit_u) ua[e] = p.ua[(size_t)off[e] * p.ldua + p.ua_coff + nn];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < NE; ++e) {
+        if (off[e] < 0) continue;
+        float v;
+        if constexpr (NW == 32) v = acc[i].v[e];
+        else v = acc[i].v[e >> 2][e & 3];
+        v = act_fwd_c<decltype(ELU)::value>(v + bias, ea.slope);
+        if (p.y2) p.y2[(size_t)off[e] * p.ldy2 + p.y2_coff + nn] = v;
+        if (p.res) v += rs[e];
+        if (p.accumulate) v += ac[e];
+        p.y[(size_t)off[e] * p.ldy + p.y_coff + nn] = v;
+        if (emit_u) p.uo[(size_t)off[e] * p.ldu + p.u_coff + nn] = v * act_dfo_c(ua[e], ea);
+      }
+    }
+  };
+  if (p.act == ACT_ELU) generic(std::true_type());
+  else generic(std::false_type());
 }
 
 // LDS bytes of the tile kernel for this launch at tile height th (0: not eligible); the maximum over the parity classes
