@@ -643,16 +643,8 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvParams& p, const i
     tap_yx[i] = make_int2(tp.dy, tp.dx);
     tap_w[i] = tp.widx;
   }
-  for (int r = tid; r < BM; r += 512) {
-    const int m = m0 + r;
-    int off = -1;
-    if (m < Mtot) {
-      const int n = (int)fdiv(m, tc.fd_ohw), rem = m - n * OHWq;
-      const int qy = (int)fdiv(rem, tc.fd_ow), qx = rem - qy * tc.OWq;
-      off = (n * p.OH + qy * p.osy + ooy) * p.OW + qx * p.osx + oox;
-    }
-    rowoff[r] = off;
-  }
+  // (the output row offsets are read by the tile store only: the MFMA waves fill them while they wait for the first stage -- below --
+  // instead of in front of the barrier every wave's first DMA waits behind: round 6, tools/igemm_stamps.py)
   const int Kc = p.Kc;
   // kfast (Kc >= 32, no up-sampled read): a stage is ONE (channel block, tap) pair -- the last, narrower block is padded with zero
   // lanes instead of straddling into the next tap -- so the K cursor is wave-uniform (see the staging waves)
@@ -667,8 +659,8 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvParams& p, const i
   // slab of this slice: regular split-K keeps whole-output slabs, the tail split only the rows from tail_prow0 on
   const long slab_off = p.tail_ks > 1 ? ((long)kz * (p.Mall - p.tail_prow0) - p.tail_prow0) * p.ldp : (long)kz * p.Mall * p.ldp;
   IGEMM_STAMP(7);
-  __syncthreads();
-  IGEMM_STAMP(1);
+  // (the barrier that publishes the tap tables sits inside the two role paths: the staging waves reach it only after their per-row
+  // address arithmetic, which needs no table -- that work runs beside the kernel-argument / tap-table latency instead of behind it)
 
   if (role == 1) {
     // ------------------------------------------------ staging waves ------------------------------------------------
@@ -817,6 +809,7 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvParams& p, const i
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     };
+    __syncthreads();  // tap tables visible (the MFMA waves' counterpart: in front of their accumulator set-up)
     int issued = c_begin, ibuf = 0;
     for (int s = 0; s < NS - 1 && issued < c_end; ++s) {
       issue(ibuf);
@@ -836,6 +829,8 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvParams& p, const i
   }
 
   // -------------------------------------------------- MFMA waves --------------------------------------------------
+  __syncthreads();  // (pairs with the staging waves' barrier above)
+  IGEMM_STAMP(1);
   floatx16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -894,6 +889,16 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvParams& p, const i
       if constexpr (!F16) __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);
     }
   };
+  for (int r = t; r < BM; r += 256) {  // rows of the tile -> output pixel offsets (visible to every MFMA wave behind the hand-over barriers)
+    const int m = m0 + r;
+    int off = -1;
+    if (m < Mtot) {
+      const int n = (int)fdiv(m, tc.fd_ohw), rem = m - n * OHWq;
+      const int qy = (int)fdiv(rem, tc.fd_ow), qx = rem - qy * tc.OWq;
+      off = (n * p.OH + qy * p.osy + ooy) * p.OW + qx * p.osx + oox;
+    }
+    rowoff[r] = off;
+  }
   handover();
   IGEMM_STAMP(2);
   {
