@@ -1173,10 +1173,19 @@ int plan_backward(Plan* P, int which, const float* w_gen, const float* w_rec, fl
     const Lane LWE = lane_of(P, s, le > 0 && le < Plan::NLANE ? le : 2);
     UDET_TRY(backward_recover(P, w_rec, g_rec, ws, L0, LWE, la > 0 ? &LA : nullptr, &LWD));
     if (LWE.s != L2.s) order_after(P, LWE, L0);
-    const int nlate = (int)plan_knob(UDET_KNOB_GEN_WGRAD_LATE);
-    UDET_TRY(backward_generator(P, w_gen, g_gen, ws, L1, L3, nlate > 0 ? &L2 : nullptr, nlate));
+    // The filter gradients of the generator's first four layers (the LAST ones the generator-loss pass reaches: conv4_downsample ... conv1) run
+    // on lane 2 instead of lane 3: they are the tail of the step, and lane 2 -- the recover encoders' filter gradients -- has long drained by
+    // then, so the two queues finish the tail side by side.  Round 6 sweep, three runs each on one box (ms per step): 0 layers 8.274,
+    // 2: 8.224, 3: 8.218, 4: 8.216, 6: 8.236, 8: 8.278.  (Round 3 measured the same move as a loss -- the kernels behind it were slower then.)
+    // (experiment knob, libudet_exp.so only: v > 0 that many layers, v < 0 none)
+    const long kl = plan_knob(UDET_KNOB_GEN_WGRAD_LATE);
+    const int nlate = kl > 0 ? (int)kl : (kl < 0 ? 0 : 4);
+    // the recover gradients are final HERE (rec_backward joined its filter-gradient lanes): their event is recorded before the generator's
+    // late filter gradients are enqueued on lane 2, so a communication stream waiting on it still starts under the generator-loss pass
     order_after(P, L2, L0);
     mark(NET_REC);
+    UDET_TRY(backward_generator(P, w_gen, g_gen, ws, L1, L3, nlate > 0 ? &L2 : nullptr, nlate));
+    order_after(P, L2, L0);
     order_after(P, L1, L0);
     order_after(P, L3, L0);
     mark(NET_GEN);
