@@ -16,7 +16,8 @@ dbg = lib  # (the experiment build carries the udet_debug_* hooks itself; libude
 dbg.udet_debug_force_conv.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
 dbg.udet_debug_force_conv.restype = None
 
-NAMES = ["zero-fill + tables", "first stage lands", "K loop", "roles exchange + output transform", "store loop issue", "stores acknowledged"]
+NAMES = ["zero-fill + tables", "first stage lands", "K loop", "exchange + output transform + store loop (both roles)", "stores acknowledged"]
+IDX = [0, 1, 2, 3, 5, 6]  # stamps of csrc/conv_wino.hip (4 is unused since both roles store)
 
 
 def main():
@@ -33,10 +34,10 @@ def main():
             torch.cuda.synchronize()
             buf = (ctypes.c_longlong * (144 * 8))()
             assert lib.udet_exp_wino_stamps(buf, 144 * 8) == 0
-            seg = [0.0] * 6
+            seg = [0.0] * 5
             for blk in range(144):
-                for k in range(6):
-                    seg[k] += (buf[blk * 8 + k + 1] - buf[blk * 8 + k]) / 144.0
+                for k in range(5):
+                    seg[k] += (buf[blk * 8 + IDX[k + 1]] - buf[blk * 8 + IDX[k]]) / 144.0
             print("%s, %d K stage(s): " % (act, cin // 8) + "; ".join("%s %.0f" % (nm, v) for nm, v in zip(NAMES, seg)) + "  (cycles, mean of 144 workgroups)")
     dbg.udet_debug_force_conv(0, 0, -1)
 

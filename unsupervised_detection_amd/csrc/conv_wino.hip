@@ -170,6 +170,130 @@ __device__ __forceinline__ void wino_store_block(const ConvParams& p, const floa
   }
 }
 
+// The same for ONE pixel row of the wave tile's 2x2 tiles (the role-split kernels: role 0 stores the upper row a = 0 of every tile, role 1
+// the lower one): `tp` holds [q = tile * 2 + b][32 channels], 64 pixels -- eight quads per lane.
+__device__ __forceinline__ void wino_store_rows(const ConvParams& p, const float* tp, int lane, int n4, int n, int d, int sy, int sx, int Hs, int Ws, int Yb,
+                                                int Xb, int a) {
+  const bool slab = p.ksplit > 1;
+  const bool vec = slab ? ((reinterpret_cast<uintptr_t>(p.partial) & 15) == 0 && (p.ldp & 3) == 0) : epilogue4_out_ok(p);
+  const int c4 = (lane & 7) * 4;
+  auto pix = [&](int q) {  // pixel of quad q (-1: outside the grid)
+    const int m = q >> 1, b = q & 1;
+    const int oy = Yb + 2 * (m >> 3) + a, ox = Xb + 2 * (m & 7) + b;
+    return (oy >= Hs || ox >= Ws) ? -1 : (n * p.H + sy + d * oy) * p.W + sx + d * ox;
+  };
+  if (!slab && vec) {
+    if (n4 >= p.Cout) return;
+    const float4 bias = epi4_bias(p, n4);
+    const EpiAct ea = epi_act(p);
+    auto loop = [&](auto ELU) {
+      if (epi4_plain(p)) {
+#pragma unroll 1
+        for (int k0 = 0; k0 < 8; k0 += 4) {
+          float4 v[4];
+          int off[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int q = (k0 + u) * 8 + (lane >> 3);
+            v[u] = *reinterpret_cast<const float4*>(&tp[q * 32 + c4]);
+            off[u] = pix(q);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (off[u] >= 0) epi4_finish_plain32<decltype(ELU)::value>(p, off[u], n4, v[u], bias, ea.slope);
+        }
+        return;
+      }
+      float4 v[8];  // residual / accumulate / dU emission: every operand of the wave's eight quads is requested before the first store
+      int off[8];
+      Epi4Req rq[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int q = u * 8 + (lane >> 3);
+        v[u] = *reinterpret_cast<const float4*>(&tp[q * 32 + c4]);
+        off[u] = pix(q);
+        if (off[u] >= 0) epi4_request(p, off[u], n4, rq[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (off[u] >= 0) epi4_finish<decltype(ELU)::value>(p, off[u], n4, v[u], bias, rq[u], ea);
+    };
+    if (p.act == ACT_ELU) loop(std::true_type());
+    else loop(std::false_type());
+    return;
+  }
+  const long slab_off = (long)blockIdx.z * p.N * p.H * p.W * p.ldp;
+#pragma unroll 1
+  for (int k = 0; k < 8; ++k) {
+    const int q = k * 8 + (lane >> 3), off = pix(q);
+    const float4 v = *reinterpret_cast<const float4*>(&tp[q * 32 + c4]);
+    if (off < 0) continue;
+    if (slab) {
+      float* dst = p.partial + (slab_off + (long)off * p.ldp + n4);
+      if (vec) {
+        if (n4 < p.ldp) *reinterpret_cast<float4*>(dst) = v;
+      } else {
+        if (n4 < p.ldp) dst[0] = v.x;
+        if (n4 + 1 < p.ldp) dst[1] = v.y;
+        if (n4 + 2 < p.ldp) dst[2] = v.z;
+        if (n4 + 3 < p.ldp) dst[3] = v.w;
+      }
+      continue;
+    }
+    if (n4 < p.Cout) conv_epilogue(p, off, n4, v.x);
+    if (n4 + 1 < p.Cout) conv_epilogue(p, off, n4 + 1, v.y);
+    if (n4 + 2 < p.Cout) conv_epilogue(p, off, n4 + 2, v.z);
+    if (n4 + 3 < p.Cout) conv_epilogue(p, off, n4 + 3, v.w);
+  }
+}
+// Output transform + store of the role-split kernels (eight-wave and half-size forms).  acc[0..3] / acc[4..7] = the wave's two position rows
+// ({1, 2} role 0, {0, 3} role 1) of a 32-tile x 32-channel wave tile; `area` = 16 KB of LDS shared by the tile's two role waves.  Round 6:
+// BOTH roles store -- role 0 computes the upper pixel row of every 2x2 tile, Y0 = s0 + (s1 + s2), role 1 the lower one, Y1 = (s1 - s2) - s3
+// (s_i: column sums of position row i): role 0 sends s1 - s2 and receives s0, role 1 the reverse -- half the exchange of the earlier form,
+// in which role 1 sent both of its rows and left, and twice the waves on the transposition and the store loop (same values, bit for bit).
+// Every wave of the workgroup must call it (two workgroup barriers inside).
+__device__ __forceinline__ void wino_roles_epilogue(const ConvParams& p, floatx16 (&acc)[8], float* area, int role, int lane, int n4, int n, int d, int sy, int sx,
+                                                    int Hs, int Ws, int Yb, int Xb) {
+  const int li = lane & 31, lh = lane >> 5;
+  float* const mine = area + role * 2048;          // [r][b][lane]: what this role sends
+  const float* const theirs = area + (1 - role) * 2048;
+  float keep[16][2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float s[2][2];  // [own row 0 / 1][b]
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      s[h][0] = acc[h * 4 + 0][r] + acc[h * 4 + 1][r] + acc[h * 4 + 2][r];
+      s[h][1] = acc[h * 4 + 1][r] - acc[h * 4 + 2][r] - acc[h * 4 + 3][r];
+    }
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      // role 0 (rows 1, 2): keeps s1 + s2, sends s1 - s2; role 1 (rows 0, 3): sends s0, keeps s3
+      keep[r][b] = role == 0 ? s[0][b] + s[1][b] : s[1][b];
+      mine[(r * 2 + b) * 64 + lane] = role == 0 ? s[0][b] - s[1][b] : s[0][b];
+    }
+  }
+  __syncthreads();
+  float y[16][2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const float o = theirs[(r * 2 + b) * 64 + lane];
+      y[r][b] = role == 0 ? o + keep[r][b] : o - keep[r][b];
+    }
+  __syncthreads();  // (the transposition below overwrites the exchange area)
+  float* const tp = area + role * 2048;  // [q = tile * 2 + b][32 channels]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;  // tile of the wave's 4 x 8 block held by accumulator register r
+#pragma unroll
+    for (int b = 0; b < 2; ++b) tp[(m * 2 + b) * 32 + li] = y[r][b];
+  }
+  __builtin_amdgcn_wave_barrier();  // same wave: LDS serves its instructions in order, only the compiler must not reorder
+  wino_store_rows(p, tp, lane, n4, n, d, sy, sx, Hs, Ws, Yb, Xb, role);
+}
+
 template <int WTY, int WTX, int WN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv_wino_kernel(const ConvParams p, const int dil,
                                                                                                   const int BY, const int BX) {
@@ -594,48 +718,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (role == 0) body(std::integral_constant<int, 0>());
   else body(std::integral_constant<int, 1>());
 
-  // ---- output transform: column sums of the own position rows; the roles' halves meet in LDS ([r][4][lane] per wave tile) ----
+  // ---- output transform + store: both roles (wino_roles_epilogue) ----
   WINO_STAMP(3);
-  __syncthreads();
-  float* xp = reinterpret_cast<float*>(smem) + sub * (128 * 32);  // 16 KB per wave tile: the exchange, then the transposing store
-  float s[2][2][16];                                              // [own row 0 / 1][b][r]
-#pragma unroll
-  for (int r = 0; r < 16; ++r)
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      s[h][0][r] = acc[h * 4 + 0][r] + acc[h * 4 + 1][r] + acc[h * 4 + 2][r];
-      s[h][1][r] = acc[h * 4 + 1][r] - acc[h * 4 + 2][r] - acc[h * 4 + 3][r];
-    }
-  if (role == 1) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      xp[(r * 4 + 0) * 64 + lane] = s[0][0][r];  // s0[b]
-      xp[(r * 4 + 1) * 64 + lane] = s[0][1][r];
-      xp[(r * 4 + 2) * 64 + lane] = s[1][0][r];  // s3[b]
-      xp[(r * 4 + 3) * 64 + lane] = s[1][1][r];
-    }
-  }
-  __syncthreads();
-  if (role == 1) return;
-  float yv[16][4];  // [r][pixel a * 2 + b]
-#pragma unroll
-  for (int r = 0; r < 16; ++r)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const float s0 = xp[(r * 4 + b) * 64 + lane], s3 = xp[(r * 4 + 2 + b) * 64 + lane];
-      yv[r][b] = s0 + (s[0][b][r] + s[1][b][r]);
-      yv[r][2 + b] = (s[0][b][r] - s[1][b][r]) - s3;
-    }
-  __builtin_amdgcn_wave_barrier();
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;  // tile of the wave's 4 x 8 block held by accumulator register r
-#pragma unroll
-    for (int q = 0; q < 4; ++q) xp[(m * 4 + q) * 32 + li] = yv[r][q];
-  }
-  __builtin_amdgcn_wave_barrier();  // same wave: LDS serves its instructions in order, only the compiler must not reorder
-  WINO_STAMP(4);
-  wino_store_block(p, xp, lane, nb * BN + wn * 32 + (lane & 7) * 4, n, d, sy, sx, Hs, Ws, Y0 + 8 * wty, X0 + 16 * wtx);
+  __syncthreads();  // (every wave has read its last fragments: the stage buffers are free)
+  wino_roles_epilogue(p, acc, reinterpret_cast<float*>(smem) + sub * 4096, role, lane, nb * BN + wn * 32 + (lane & 7) * 4, n, d, sy, sx, Hs, Ws, Y0 + 8 * wty,
+                      X0 + 16 * wtx);
 #ifdef UDET_EXPERIMENT
   WINO_STAMP(5);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -834,45 +921,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   if (role == 0) body(std::integral_constant<int, 0>());
   else body(std::integral_constant<int, 1>());
 
-  // ---- output transform: as in the eight-wave form (the roles' column sums meet in LDS), one 16 KB scratch per channel half ----
-  float* xp = reinterpret_cast<float*>(smem) + wn * (128 * 32);
-  float s[2][2][16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r)
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      s[h][0][r] = acc[h * 4 + 0][r] + acc[h * 4 + 1][r] + acc[h * 4 + 2][r];
-      s[h][1][r] = acc[h * 4 + 1][r] - acc[h * 4 + 2][r] - acc[h * 4 + 3][r];
-    }
-  if (role == 1) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      xp[(r * 4 + 0) * 64 + lane] = s[0][0][r];
-      xp[(r * 4 + 1) * 64 + lane] = s[0][1][r];
-      xp[(r * 4 + 2) * 64 + lane] = s[1][0][r];
-      xp[(r * 4 + 3) * 64 + lane] = s[1][1][r];
-    }
-  }
-  __syncthreads();
-  if (role == 1) return;
-  float yv[16][4];
-#pragma unroll
-  for (int r = 0; r < 16; ++r)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const float s0 = xp[(r * 4 + b) * 64 + lane], s3 = xp[(r * 4 + 2 + b) * 64 + lane];
-      yv[r][b] = s0 + (s[0][b][r] + s[1][b][r]);
-      yv[r][2 + b] = (s[0][b][r] - s[1][b][r]) - s3;
-    }
-  __builtin_amdgcn_wave_barrier();
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int m = (r & 3) + 8 * (r >> 2) + 4 * lh;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) xp[(m * 4 + q) * 32 + li] = yv[r][q];
-  }
-  __builtin_amdgcn_wave_barrier();
-  wino_store_block(p, xp, lane, nb * BN + wn * 32 + (lane & 7) * 4, n, d, sy, sx, Hs, Ws, Y0, X0);
+  // ---- output transform + store: both roles (wino_roles_epilogue), one 16 KB area per channel half ----
+  wino_roles_epilogue(p, acc, reinterpret_cast<float*>(smem) + wn * 4096, role, lane, nb * BN + wn * 32 + (lane & 7) * 4, n, d, sy, sx, Hs, Ws, Y0, X0);
 }
 
 // ---- weight transform: U = G g G^T, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1] -------------------------------------------------------
