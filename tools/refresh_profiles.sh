@@ -32,4 +32,12 @@ python bench.py --fp16-convs --cycles 0 --ensemble-frames 0 > "$O/bench_fp16_con
 python bench.py --batch 2 --cycles 0 --ensemble-frames 0 --no-cpu-baseline > "$O/bench_fp32_batch2.json" 2> /dev/null
 UDET_DP_WORLD1=1 python bench.py --tune-cache "$O/tune.txt" --cycles 0 --ensemble-frames 0 --no-cpu-baseline > "$O/bench_rccl_world1.json" 2> "$O/bench_rccl_world1.err"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-value -o /tmp/mfma_peak tools/mfma_peak.hip 2> /dev/null && /tmp/mfma_peak > "$O/mfma_peak.txt" 2>&1
+# 6. round 6: the F(4x4,3x3) prototype with its ablations, the fixed-cost anatomy of the Winograd / LDS-DMA launches (libudet_exp.so:
+#    make -C unsupervised_detection_amd/csrc exp), the Winograd per-stage / intercept fit
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -fno-slp-vectorize -o /tmp/wino43_bench tools/wino43_bench.hip 2> /dev/null && W43_TS=1 W43_ABL=1 /tmp/wino43_bench dc_conv21 conv2_1 conv2_3 dc_conv31 gen.conv5 > "$O/wino43_proto.txt" 2>&1
+if [ -f unsupervised_detection_amd/libudet_exp.so ]; then
+  python tools/wino_stamps.py 2> /dev/null | grep -v amdgpu.ids > "$O/launch_anatomy.txt"
+  python tools/igemm_stamps.py 2> /dev/null | grep -v amdgpu.ids | grep -v "d=8" >> "$O/launch_anatomy.txt"
+fi
+python tools/wino_fixed_cost.py 2> /dev/null | grep -v amdgpu.ids > "$O/wino_fixed_cost.txt"
 ls -la "$O"

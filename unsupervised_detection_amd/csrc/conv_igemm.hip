@@ -186,65 +186,74 @@ __device__ __forceinline__ int row_pixel_off(const ConvParams& p, int ma) {
 // ~15 % of the run time of a mid-size layer.  With `xp` (16 x UDET_XP floats of LDS per wave) the tile goes through LDS half a
 // 32x32 block at a time and leaves as float4 rows: 8 lanes x 16 B per pixel, epilogue arithmetic once per quad, and the
 // store loop is not unrolled (4 x 2 copies of its body instead of 256).
+// the float4 path of igemm_store for one (activation, operand) variant: a plain function template, NOT a lambda inside igemm_store --
+// with a generic lambda instantiated four ways hipcc copied the whole 1752-byte kernel-argument block to scratch in every kernel with a
+// tile larger than 64 x 64 (1760 bytes of scratch per lane; round 6)
+template <int TM, int TN, int WTM, int WTN, bool ELU, bool PLAIN>
+__device__ __forceinline__ void igemm_store_quads(const ConvParams& p, floatx16 (&acc)[TM][TN], const int* rowoff, int wm, int wn, int li, int lh, int n0,
+                                                  int prow0, bool slab, long slab_off, float* xp) {
+  const int lane = lh * 32 + li, rr = lane >> 3, c4 = (lane & 7) * 4;
+  // the bias quad of a column block does not depend on the row: loaded once per block, not once per quad behind the previous quad's
+  // store; the two passes of a half block request their per-pixel operands together; the activation is selected once, by the caller
+  // (conv_epilogue.h: epi4_*, EpiAct -- per element it cost five scalar branches).  PLAIN: a launch with neither residual nor accumulate
+  // nor dU emission -- or a K slice writing its slab -- has NO global load in its store loop; with one, every wait for it also drains the
+  // stores issued before it (loads and stores share vmcnt on gfx950)
+  float4 bias[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int nb = n0 + wn * WTN + j * 32 + c4;
+    bias[j] = (!slab && nb < p.Cout) ? epi4_bias(p, nb) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const EpiAct ea = epi_act(p);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int nb = n0 + wn * WTN + j * 32 + c4;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {  // accumulator registers 8h .. 8h+7 are rows 16h .. 16h+15 of the block
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 8; ++r) xp[((r & 3) + 8 * (r >> 2) + 4 * lh) * UDET_XP + li] = acc[i][j][8 * h + r];
+        __builtin_amdgcn_wave_barrier();  // same wave: LDS serves its instructions in order, only the compiler must not reorder
+        int off[2];
+        float4 v[2];
+        Epi4Req rq[2];
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+          const int row = wm * WTM + i * 32 + h * 16 + pass * 8 + rr;
+          off[pass] = rowoff[row];
+          v[pass] = *reinterpret_cast<const float4*>(&xp[(pass * 8 + rr) * UDET_XP + c4]);
+          if (!PLAIN && !slab && off[pass] >= 0 && nb < p.Cout) epi4_request(p, off[pass], nb, rq[pass]);
+        }
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+          const int row = wm * WTM + i * 32 + h * 16 + pass * 8 + rr;
+          if (off[pass] < 0) continue;
+          if (slab) {
+            if (nb < p.ldp) *reinterpret_cast<float4*>(p.partial + (slab_off + (long)(prow0 + row) * p.ldp + nb)) = v[pass];
+          } else if (nb < p.Cout) {
+            if (PLAIN) epi4_finish_plain<ELU>(p, off[pass], nb, v[pass], bias[j], ea.slope);
+            else epi4_finish<ELU>(p, off[pass], nb, v[pass], bias[j], rq[pass], ea);
+          }
+        }
+      }
+    }
+  }
+}
 template <int TM, int TN, int WTM, int WTN>
 __device__ __forceinline__ void igemm_store(const ConvParams& p, floatx16 (&acc)[TM][TN], const int* rowoff, int wm, int wn, int li,
                                             int lh, int n0, int prow0, int Mtot, bool slab, long slab_off, float* xp = nullptr) {
   // slab: this workgroup holds a K slice; its partial tile goes to p.partial + slab_off + (class row) * ldp
   if (xp != nullptr && !(slab && p.fold) && (slab ? (reinterpret_cast<uintptr_t>(p.partial) & 15) == 0 : epilogue4_out_ok(p))) {
-    const int lane = lh * 32 + li, rr = lane >> 3, c4 = (lane & 7) * 4;
-    // (round 6) the bias quad of a column block does not depend on the row: loaded once per block, not once per quad behind the previous
-    // quad's store; the two passes of a half block request their per-pixel operands together; the activation is selected once, outside
-    // the loops (conv_epilogue.h: epi4_*, EpiAct -- per element it cost five scalar branches)
-    float4 bias[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int nb = n0 + wn * WTN + j * 32 + c4;
-      bias[j] = (!slab && nb < p.Cout) ? epi4_bias(p, nb) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    const EpiAct ea = epi_act(p);
-    // (PLAIN: a launch with neither residual nor accumulate nor dU emission -- or a K slice writing its slab -- has NO global load in
-    // its store loop; with one, every wait for it also drains the stores issued before it: loads and stores share vmcnt on gfx950)
-    auto tile = [&](auto ELU, auto PLAIN_) {
-      constexpr bool PLAIN = decltype(PLAIN_)::value;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int nb = n0 + wn * WTN + j * 32 + c4;
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {  // accumulator registers 8h .. 8h+7 are rows 16h .. 16h+15 of the block
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int r = 0; r < 8; ++r) xp[((r & 3) + 8 * (r >> 2) + 4 * lh) * UDET_XP + li] = acc[i][j][8 * h + r];
-            __builtin_amdgcn_wave_barrier();  // same wave: LDS serves its instructions in order, only the compiler must not reorder
-            int off[2];
-            float4 v[2];
-            Epi4Req rq[2];
-#pragma unroll
-            for (int pass = 0; pass < 2; ++pass) {
-              const int row = wm * WTM + i * 32 + h * 16 + pass * 8 + rr;
-              off[pass] = rowoff[row];
-              v[pass] = *reinterpret_cast<const float4*>(&xp[(pass * 8 + rr) * UDET_XP + c4]);
-              if (!PLAIN && !slab && off[pass] >= 0 && nb < p.Cout) epi4_request(p, off[pass], nb, rq[pass]);
-            }
-#pragma unroll
-            for (int pass = 0; pass < 2; ++pass) {
-              const int row = wm * WTM + i * 32 + h * 16 + pass * 8 + rr;
-              if (off[pass] < 0) continue;
-              if (slab) {
-                if (nb < p.ldp) *reinterpret_cast<float4*>(p.partial + (slab_off + (long)(prow0 + row) * p.ldp + nb)) = v[pass];
-              } else if (nb < p.Cout) {
-                if (PLAIN) epi4_finish_plain<decltype(ELU)::value>(p, off[pass], nb, v[pass], bias[j], ea.slope);
-                else epi4_finish<decltype(ELU)::value>(p, off[pass], nb, v[pass], bias[j], rq[pass], ea);
-              }
-            }
-          }
-        }
-      }
-    };
     const bool plain = slab || epi4_plain(p);
-    if (!slab && p.act == ACT_ELU) { if (plain) tile(std::true_type(), std::true_type()); else tile(std::true_type(), std::false_type()); }
-    else { if (plain) tile(std::false_type(), std::true_type()); else tile(std::false_type(), std::false_type()); }
+    if (!slab && p.act == ACT_ELU) {
+      if (plain) igemm_store_quads<TM, TN, WTM, WTN, true, true>(p, acc, rowoff, wm, wn, li, lh, n0, prow0, slab, slab_off, xp);
+      else igemm_store_quads<TM, TN, WTM, WTN, true, false>(p, acc, rowoff, wm, wn, li, lh, n0, prow0, slab, slab_off, xp);
+    } else {
+      if (plain) igemm_store_quads<TM, TN, WTM, WTN, false, true>(p, acc, rowoff, wm, wn, li, lh, n0, prow0, slab, slab_off, xp);
+      else igemm_store_quads<TM, TN, WTM, WTN, false, false>(p, acc, rowoff, wm, wn, li, lh, n0, prow0, slab, slab_off, xp);
+    }
     return;
   }
 #pragma unroll
