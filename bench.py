@@ -194,7 +194,7 @@ def main():
                     "after the headline region; 0 skips that extra measurement")
     ap.add_argument("--ensemble-frames", type=int, default=12, help="frames of the configs[3] ensemble workload timed after the headline "
                     "region (extra field `ensemble`); 0 skips it")
-    ap.add_argument("--pmc-json", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r05_pmc_step.json"),
+    ap.add_argument("--pmc-json", default=os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r06_pmc_step.json"),
                     help="PMC counters of whole steps collected offline with tools/pmc_step.py (separate rocprofv3 --pmc passes); fills "
                          "roofline.traffic with the convolution kernels' HBM bytes per step")
     args = ap.parse_args()

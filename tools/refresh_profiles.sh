@@ -40,4 +40,7 @@ if [ -f unsupervised_detection_amd/libudet_exp.so ]; then
   python tools/igemm_stamps.py 2> /dev/null | grep -v amdgpu.ids | grep -v "d=8" >> "$O/launch_anatomy.txt"
 fi
 python tools/wino_fixed_cost.py 2> /dev/null | grep -v amdgpu.ids > "$O/wino_fixed_cost.txt"
+# 7. the bench line once more, on the configurations of step 1 and with THIS call's counters in roofline.traffic (step 1 ran before them)
+mv "$O/bench.json" "$O/bench_tuning_run.json"
+python bench.py --tune-cache "$O/tune.txt" --pmc-json "$O/pmc_step.json" > "$O/bench.json" 2> "$O/bench_final.err"
 ls -la "$O"
