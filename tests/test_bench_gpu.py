@@ -77,3 +77,27 @@ def test_rccl_branch_at_world_size_one():
     assert ex is not None and ex["ms_per_step_without_exchange"] > 0
     # a one-rank mean changes nothing: the losses of the run are finite and the step time is that of the plain N = 1 run (loosely)
     assert all(v == v for v in out["losses"].values()) and out["ms_per_step"] < 40
+    # round 6: the line names the library that produced it (the release build has no experiment knobs) and carries the algorithmic bytes
+    assert out["release_library"] == {"file": "libudet.so", "experiment_knobs": "compiled out", "debug_hooks_loaded": False}
+    assert out["roofline"]["alg_bytes_per_step"] > 4e9 and out["roofline"]["alg_bytes_forward"] > 2e9
+
+
+def test_experiment_build_is_refused_and_labelled():
+    """bench.py exits on a library that exports udet_exp_knob unless tools/knob_bench.py asked for it, and then says so in the line
+    (no work-skipping switch behind a headline number).  Skipped where libudet_exp.so has not been built (`make exp`)."""
+    import pytest
+    if not os.path.exists(os.path.join(ROOT, "unsupervised_detection_amd", "libudet_exp.so")):
+        pytest.skip("libudet_exp.so not built")
+    env = dict(os.environ)
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "knob_bench.py"), "--", "--steps", "2", "--warmup", "1", "--cycles", "0", "--no-cpu-baseline",
+           "--ensemble-frames", "0", "--no-autotune"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["release_library"]["experiment_knobs"].startswith("PRESENT")
+    # the same library through bench.py's own argument list (no --allow-experiment-build): refused
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import knob_bench; knob_bench.load_experiment_build(); import bench; "
+            "sys.argv = ['bench.py', '--steps', '1', '--warmup', '0', '--no-cpu-baseline', '--cycles', '0', '--ensemble-frames', '0']; bench.main()"
+            % (ROOT, os.path.join(ROOT, "tools")))
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "not the release library" in (r.stderr + r.stdout)
