@@ -63,7 +63,7 @@ __device__ __forceinline__ KOrder korder(int Kc, int ntc) {
   KOrder o;
   o.Kc = Kc; o.ntc = ntc;
   o.CB = Kc < 32 ? Kc : 32;
-  o.nblk = (Kc + o.CB - 1) / o.CB;
+  o.nblk = Kc < 32 ? 1 : (Kc + 31) >> 5;  // (= ceil(Kc / CB) without a run-time division)
   o.wl = Kc - (o.nblk - 1) * o.CB;
   return o;
 }
@@ -128,7 +128,7 @@ __device__ __forceinline__ TileCls tile_cls(const ConvParams& p, int bid) {
     t.OHWq = p.OHq * p.OWq; t.OWq = p.OWq;
     t.Mtot = p.N * t.OHWq;
     const int mtiles = (t.Mtot + BM - 1) / BM;
-    t.cls = bid / mtiles;
+    t.cls = p.ncls > 1 ? bid / mtiles : 0;  // (one class: no run-time division in front of every launch's first instruction of work)
     t.m0 = (bid - t.cls * mtiles) * BM;
     t.tap0 = p.cls_tap[t.cls];
     t.ntc = p.cls_tap[t.cls + 1] - t.tap0;
@@ -616,6 +616,12 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvParams& p, const i
 
   IGEMM_STAMP(0);
   const int tid = threadIdx.x;
+  // Speculative tap fetch (round 6): the tap table of an unsegmented single-class launch starts at taps[0], whatever the block decodes
+  // to -- its (vector) load from the kernel-argument block goes out HERE, beside the scalar loads of the fields the decode waits for,
+  // instead of behind them (two back-to-back cold misses, ~1 us each, in front of every launch's first DMA)
+  ConvTap spec_tap;
+  spec_tap.dy = spec_tap.dx = spec_tap.widx = 0;
+  if (tid < UDET_MAX_TAPS) spec_tap = p.taps[tid];
   const int role = __builtin_amdgcn_readfirstlane(tid >> 8);  // 0 = MFMA waves, 1 = staging waves
   const int t = tid & 255;
   const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -647,10 +653,17 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvParams& p, const i
   const int Hs = p.H >> p.up_shift, Ws = p.W >> p.up_shift;
   IGEMM_STAMP(6);
 
-  for (int i = tid; i < ntc; i += 512) {
-    const ConvTap tp = conv_tap(p, tap0 + i);
-    tap_yx[i] = make_int2(tp.dy, tp.dx);
-    tap_w[i] = tp.widx;
+  if (p.nseg == 0 && tap0 == 0) {  // (uniform) the speculative fetch is this block's table
+    if (tid < ntc) {
+      tap_yx[tid] = make_int2(spec_tap.dy, spec_tap.dx);
+      tap_w[tid] = spec_tap.widx;
+    }
+  } else {
+    for (int i = tid; i < ntc; i += 512) {
+      const ConvTap tp = conv_tap(p, tap0 + i);
+      tap_yx[i] = make_int2(tp.dy, tp.dx);
+      tap_w[i] = tp.widx;
+    }
   }
   // (the output row offsets are read by the tile store only: the MFMA waves fill them while they wait for the first stage -- below --
   // instead of in front of the barrier every wave's first DMA waits behind: round 6, tools/igemm_stamps.py)
@@ -658,12 +671,13 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvParams& p, const i
   // kfast (Kc >= 32, no up-sampled read): a stage is ONE (channel block, tap) pair -- the last, narrower block is padded with zero
   // lanes instead of straddling into the next tap -- so the K cursor is wave-uniform (see the staging waves)
   // kfast bit 2 (Kc in {4, 8, 16}): a stage is 32 / Kc WHOLE taps; the tap of a lane follows from its channel slot (a per-lane constant)
-  const int tps = (p.kfast & 4) ? 32 / Kc : 1;  // taps per stage
-  const int nchunks = (p.kfast & 1) ? ntc * ((Kc + 31) >> 5) : ((p.kfast & 4) ? (ntc + tps - 1) / tps : (ntc * Kc + BK - 1) / BK);
+  const int tsh = Kc == 4 ? 3 : (Kc == 8 ? 2 : 1);  // log2(taps per stage) of the packed form (Kc = 4, 8, 16): shifts, not run-time divisions
+  const int tps = (p.kfast & 4) ? 1 << tsh : 1;     // taps per stage
+  const int nchunks = (p.kfast & 1) ? ntc * ((Kc + 31) >> 5) : ((p.kfast & 4) ? (ntc + tps - 1) >> tsh : (ntc * Kc + BK - 1) / BK);
   int c_begin = 0, c_end = nchunks;
   if (knz > 1) {
-    c_begin = (int)((long)nchunks * kz / knz);
-    c_end = (int)((long)nchunks * (kz + 1) / knz);
+    c_begin = (int)((unsigned)(nchunks * kz) / (unsigned)knz);  // (nchunks * knz < 2^31: 32-bit divisions, a third of the 64-bit ones' instructions)
+    c_end = (int)((unsigned)(nchunks * (kz + 1)) / (unsigned)knz);
   }
   // slab of this slice: regular split-K keeps whole-output slabs, the tail split only the rows from tail_prow0 on
   const long slab_off = p.tail_ks > 1 ? ((long)kz * (p.Mall - p.tail_prow0) - p.tail_prow0) * p.ldp : (long)kz * p.Mall * p.ldp;
@@ -698,10 +712,18 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvParams& p, const i
     // Generic K cursor (stages may straddle taps: Kc < 32 or an up-sampled read): per-lane (block, tap, channel) cursors advanced
     // with data-dependent control flow -- ~1500 instructions per stage for a 128x128 tile, more than the 4096 MFMA cycles of the
     // stage leave room for on a SIMD that also hosts an MFMA wave.  The uniform cursor below needs ~100.
+    // (the generic cursor's set-up is a dozen integer divisions by run-time values, ~40 instructions each: only launches that use it pay
+    // for it -- round 6: the staging waves' set-up was ~3 700 cycles in front of EVERY launch's first DMA, tools/igemm_stamps.py)
     const KOrder ko = korder(Kc, ntc);
-    KCursor ka = kc_init(ko, (p.kfast & 5) ? 0 : c_begin * BK + kqs * 4), kb[B_LD];
+    KCursor ka, kb[B_LD];
+    ka.blk = ka.tap = ka.c = ka.w = 0;
 #pragma unroll
-    for (int j = 0; j < B_LD; ++j) kb[j] = kc_init(ko, (p.kfast & 5) ? 0 : c_begin * BK + (t + j * 256) / B_F4_ROW);
+    for (int j = 0; j < B_LD; ++j) kb[j] = ka;
+    if (!(p.kfast & 5)) {
+      ka = kc_init(ko, c_begin * BK + kqs * 4);
+#pragma unroll
+      for (int j = 0; j < B_LD; ++j) kb[j] = kc_init(ko, c_begin * BK + (t + j * 256) / B_F4_ROW);
+    }
     auto issue_generic = [&](int buf) {
       int dy = 0, dx = 0;
       const bool a_ok = kc_valid(ko, ka);
@@ -748,7 +770,7 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvParams& p, const i
       b_off[j] = row * p.ldw + n;
       b_col[j] = n < p.ldw;
     }
-    int s_blk = __builtin_amdgcn_readfirstlane(c_begin / (ntc > 0 ? ntc : 1));
+    int s_blk = c_begin == 0 ? 0 : __builtin_amdgcn_readfirstlane(c_begin / (ntc > 0 ? ntc : 1));  // (unsplit launches: no division)
     int s_tap = __builtin_amdgcn_readfirstlane(c_begin - s_blk * ntc);
     auto issue_fast = [&](int buf) {
       const int2 yx = tap_yx[s_tap];
@@ -772,12 +794,13 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvParams& p, const i
       if (++s_tap == ntc) { s_tap = 0; ++s_blk; }
     };
     // Packed taps (Kc < 32): stage s holds taps s * tps .. s * tps + tps - 1; K index k of the stage = (tap k / Kc, channel k % Kc).
-    const int a_sub = (kqs * 4) / Kc, a_ch = (kqs * 4) - a_sub * Kc;  // this lane's A slot
+    const int ksh = Kc == 4 ? 2 : (Kc == 8 ? 3 : 4);                      // (packed taps exist for Kc = 4, 8, 16 only: shifts, not divisions)
+    const int a_sub = (kqs * 4) >> ksh, a_ch = (kqs * 4) - (a_sub << ksh);  // this lane's A slot
     int b_sub[B_LD], b_poff[B_LD];
 #pragma unroll
     for (int j = 0; j < B_LD; ++j) {
-      b_sub[j] = b_row[j] / Kc;
-      b_poff[j] = (b_row[j] - b_sub[j] * Kc) * p.ldw + (b_off[j] - b_row[j] * p.ldw);  // (channel row, column) inside the tap's weight block
+      b_sub[j] = b_row[j] >> ksh;
+      b_poff[j] = (b_row[j] - (b_sub[j] << ksh)) * p.ldw + (b_off[j] - b_row[j] * p.ldw);  // (channel row, column) inside the tap's weight block
     }
     int s_stage = c_begin;
     auto issue_pack = [&](int buf) {
