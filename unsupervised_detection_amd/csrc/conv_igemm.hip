@@ -431,8 +431,8 @@ __global__ __launch_bounds__(WS ? 512 : 256, WS ? 4 : 2) void conv_igemm_kernel(
   const int nchunks = (ntc * Kc + BK - 1) / BK;
   int c_begin = 0, c_end = nchunks;
   if (p.ksplit > 1) {
-    c_begin = (int)((long)nchunks * blockIdx.z / p.ksplit);
-    c_end = (int)((long)nchunks * (blockIdx.z + 1) / p.ksplit);
+    c_begin = (int)((unsigned)(nchunks * blockIdx.z) / (unsigned)p.ksplit);  // (32-bit: nchunks * ksplit < 2^31)
+    c_end = (int)((unsigned)(nchunks * (blockIdx.z + 1)) / (unsigned)p.ksplit);
   }
   // flat-K cursors of this thread's A float4 and of its B rows; advanced by BK per stage
   const KOrder ko = korder(Kc, ntc);
@@ -1047,8 +1047,8 @@ __global__ __launch_bounds__(256, 3) void conv_igemm_dma4_kernel(const ConvParam
   const int nchunks = kfast ? ntc * ((Kc + 15) >> 4) : (ntc * Kc + BK - 1) / BK;
   int c_begin = 0, c_end = nchunks;
   if (p.ksplit > 1) {
-    c_begin = (int)((long)nchunks * blockIdx.z / p.ksplit);
-    c_end = (int)((long)nchunks * (blockIdx.z + 1) / p.ksplit);
+    c_begin = (int)((unsigned)(nchunks * blockIdx.z) / (unsigned)p.ksplit);  // (32-bit: nchunks * ksplit < 2^31)
+    c_end = (int)((unsigned)(nchunks * (blockIdx.z + 1)) / (unsigned)p.ksplit);
   }
   __syncthreads();
 

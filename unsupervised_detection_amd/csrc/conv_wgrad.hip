@@ -49,15 +49,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p, in
     const int nx = gridDim.x, nwg = nx * gridDim.y, h = blockIdx.x + nx * blockIdx.y;
     const int q = nwg >> 3, r = nwg & 7, xcd = h & 7, idx = h >> 3;
     const int l = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    by = l / nx;
+    by = gridDim.y == 1 ? 0 : l / nx;  // (one pixel slice: no run-time division)
     bx = l - by * nx;
   }
-  const int mt = bx / co_tiles;
+  const int mt = co_tiles == 1 ? bx : bx / co_tiles;
   const int m0 = mt * BM, co0 = (bx - mt * co_tiles) * BN;
   const int OHW = p.OH * p.OW;
   const int Q = p.N * OHW;
   const int nchunks = (Q + BKP - 1) / BKP;
-  const int c_begin = (int)((long)nchunks * by / nsplit), c_end = (int)((long)nchunks * (by + 1) / nsplit);
+  // (nchunks * nsplit < 2^31: 32-bit divisions -- a 64-bit one is ~150 instructions in front of every workgroup's first load)
+  const int c_begin = (int)((unsigned)(nchunks * by) / (unsigned)nsplit), c_end = (int)((unsigned)(nchunks * (by + 1)) / (unsigned)nsplit);
   const int Hs = p.H >> p.up_shift, Ws = p.W >> p.up_shift;
   const int cout4 = (p.Cout + 3) & ~3;
 
@@ -233,15 +234,16 @@ __global__ __launch_bounds__(512, NS == 2 ? 4 : 2) void conv_wgrad_dma_kernel(co
     const int nx = gridDim.x, nwg = nx * gridDim.y, h = blockIdx.x + nx * blockIdx.y;
     const int q = nwg >> 3, r = nwg & 7, xcd = h & 7, idx = h >> 3;
     const int l = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    by = l / nx;
+    by = gridDim.y == 1 ? 0 : l / nx;  // (one pixel slice: no run-time division)
     bx = l - by * nx;
   }
-  const int mt = bx / co_tiles;
+  const int mt = co_tiles == 1 ? bx : bx / co_tiles;
   const int m0 = mt * BM, co0 = (bx - mt * co_tiles) * BN;
   const int OHW = p.OH * p.OW;
   const int Q = p.N * OHW;
   const int nchunks = (Q + BKP - 1) / BKP;
-  const int c_begin = (int)((long)nchunks * by / nsplit), c_end = (int)((long)nchunks * (by + 1) / nsplit);
+  // (nchunks * nsplit < 2^31: 32-bit divisions -- a 64-bit one is ~150 instructions in front of every workgroup's first load)
+  const int c_begin = (int)((unsigned)(nchunks * by) / (unsigned)nsplit), c_end = (int)((unsigned)(nchunks * (by + 1)) / (unsigned)nsplit);
   const int Hs = p.H >> p.up_shift, Ws = p.W >> p.up_shift;
   const int cout4 = (p.Cout + 3) & ~3;
 
