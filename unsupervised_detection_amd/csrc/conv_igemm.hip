@@ -191,7 +191,7 @@ __device__ __forceinline__ int row_pixel_off(const ConvParams& p, int ma) {
 // tile larger than 64 x 64 (1760 bytes of scratch per lane; round 6)
 template <int TM, int TN, int WTM, int WTN, bool ELU, bool PLAIN>
 __device__ __forceinline__ void igemm_store_quads(const ConvParams& p, floatx16 (&acc)[TM][TN], const int* rowoff, int wm, int wn, int li, int lh, int n0,
-                                                  int prow0, bool slab, long slab_off, float* xp) {
+                                                  int prow0, bool slab, long slab_off, float* xp, const float4* bias_pre) {
   const int lane = lh * 32 + li, rr = lane >> 3, c4 = (lane & 7) * 4;
   // the bias quad of a column block does not depend on the row: loaded once per block, not once per quad behind the previous quad's
   // store; the two passes of a half block request their per-pixel operands together; the activation is selected once, by the caller
@@ -202,7 +202,8 @@ __device__ __forceinline__ void igemm_store_quads(const ConvParams& p, floatx16 
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int nb = n0 + wn * WTN + j * 32 + c4;
-    bias[j] = (!slab && nb < p.Cout) ? epi4_bias(p, nb) : make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias_pre) bias[j] = bias_pre[j];  // (requested in front of the K loop: igemm_bias_prefetch)
+    else bias[j] = (!slab && nb < p.Cout) ? epi4_bias(p, nb) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   const EpiAct ea = epi_act(p);
 #pragma unroll
@@ -241,18 +242,30 @@ __device__ __forceinline__ void igemm_store_quads(const ConvParams& p, floatx16 
     }
   }
 }
+// the bias quads of a wave's column blocks, requested in front of the K loop (the quad of the float4 store path: lane & 7): at the head of
+// the tile store the same load is a cold miss of ~1 000-2 000 cycles with nothing to hide behind.  Zero for K slices (the second pass adds
+// the bias) and for columns beyond the layer.
+template <int TN, int WTN>
+__device__ __forceinline__ void igemm_bias_prefetch(const ConvParams& p, int n0, int wn, int lane, bool slab, float4 (&bias)[TN]) {
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int nb = n0 + wn * WTN + j * 32 + (lane & 7) * 4;
+    bias[j] = (!slab && p.bias && nb + 3 < ((p.Cout + 3) & ~3) && (p.Cout & 3) == 0 && nb < p.Cout) ? epi4_bias(p, nb) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
 template <int TM, int TN, int WTM, int WTN>
 __device__ __forceinline__ void igemm_store(const ConvParams& p, floatx16 (&acc)[TM][TN], const int* rowoff, int wm, int wn, int li,
-                                            int lh, int n0, int prow0, int Mtot, bool slab, long slab_off, float* xp = nullptr) {
+                                            int lh, int n0, int prow0, int Mtot, bool slab, long slab_off, float* xp = nullptr,
+                                            const float4* bias_pre = nullptr) {
   // slab: this workgroup holds a K slice; its partial tile goes to p.partial + slab_off + (class row) * ldp
   if (xp != nullptr && !(slab && p.fold) && (slab ? (reinterpret_cast<uintptr_t>(p.partial) & 15) == 0 : epilogue4_out_ok(p))) {
     const bool plain = slab || epi4_plain(p);
     if (!slab && p.act == ACT_ELU) {
-      if (plain) igemm_store_quads<TM, TN, WTM, WTN, true, true>(p, acc, rowoff, wm, wn, li, lh, n0, prow0, slab, slab_off, xp);
-      else igemm_store_quads<TM, TN, WTM, WTN, true, false>(p, acc, rowoff, wm, wn, li, lh, n0, prow0, slab, slab_off, xp);
+      if (plain) igemm_store_quads<TM, TN, WTM, WTN, true, true>(p, acc, rowoff, wm, wn, li, lh, n0, prow0, slab, slab_off, xp, bias_pre);
+      else igemm_store_quads<TM, TN, WTM, WTN, true, false>(p, acc, rowoff, wm, wn, li, lh, n0, prow0, slab, slab_off, xp, bias_pre);
     } else {
-      if (plain) igemm_store_quads<TM, TN, WTM, WTN, false, true>(p, acc, rowoff, wm, wn, li, lh, n0, prow0, slab, slab_off, xp);
-      else igemm_store_quads<TM, TN, WTM, WTN, false, false>(p, acc, rowoff, wm, wn, li, lh, n0, prow0, slab, slab_off, xp);
+      if (plain) igemm_store_quads<TM, TN, WTM, WTN, false, true>(p, acc, rowoff, wm, wn, li, lh, n0, prow0, slab, slab_off, xp, bias_pre);
+      else igemm_store_quads<TM, TN, WTM, WTN, false, false>(p, acc, rowoff, wm, wn, li, lh, n0, prow0, slab, slab_off, xp, bias_pre);
     }
     return;
   }
@@ -921,6 +934,8 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvParams& p, const i
       if constexpr (!F16) __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);
     }
   };
+  float4 bias_pre[TN];  // (only the float4 store path reads it: Cout a multiple of 4 -- igemm_bias_prefetch yields zeros otherwise, unused)
+  igemm_bias_prefetch<TN, WTN>(p, n0, wn, lane, knz > 1, bias_pre);
   for (int r = t; r < BM; r += 256) {  // rows of the tile -> output pixel offsets (visible to every MFMA wave behind the hand-over barriers)
     const int m = m0 + r;
     int off = -1;
@@ -952,7 +967,7 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvParams& p, const i
         for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv;
   }
   igemm_store<TM, TN, WTM, WTN>(p, acc, rowoff, wm, wn, li, lh, n0, tc.prow0 + m0, Mtot, knz > 1, slab_off,
-                                xpose_scratch<sizeof(As), sizeof(Bs)>(&As[0][0][0], &Bs[0][0][0], wave));
+                                xpose_scratch<sizeof(As), sizeof(Bs)>(&As[0][0][0], &Bs[0][0][0], wave), bias_pre);
   if (p.ksplit > 1 && p.fold) splitk_fold<BM, BN, 256>(p, rowoff, &s_last, t, n0, tc.prow0 + m0, Mtot, blockIdx.y * grid_x + bid);
 #ifdef UDET_EXPERIMENT
   IGEMM_STAMP(4);

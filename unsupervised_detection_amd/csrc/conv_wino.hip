@@ -82,18 +82,23 @@ struct WinoGeom {
   static_assert(LDS_BYTES >= 4 * 128 * 32 * 4 && LDS_BYTES <= 160 * 1024, "the epilogue transposes 16 KB per wave through the stage buffers");
 };
 
+// the bias quad of a lane's four output channels, requested in front of the K loop (at the head of the store loop the load is a cold miss
+// with nothing to hide behind); zero where the float4 store path will not use it (K slices, ragged channel counts, columns beyond the layer)
+__device__ __forceinline__ float4 wino_bias_prefetch(const ConvParams& p, int n4) {
+  return (p.ksplit <= 1 && (p.Cout & 3) == 0 && n4 < p.Cout) ? epi4_bias(p, n4) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
 // A wave's 4 x 8 tile block -- 128 output pixels x 32 channels in `xp` ([tile pixel][32 channels], the LDS transpose of the output
 // transform) -- through the epilogue into memory, or into its K slice's slab.  Plain launches keep FOUR quads in flight per lane (bias
 // loaded once, per-pixel operands requested before the first store: conv_epilogue.h, epi4_*): one quad at a time, each iteration waited
 // out a global-load latency behind the previous iteration's store -- ~10 us of the 55 us a 16-stage generator layer took.
 __device__ __forceinline__ void wino_store_block(const ConvParams& p, const float* xp, int lane, int n4, int n, int d, int sy, int sx, int Hs, int Ws,
-                                                 int Yb, int Xb) {
+                                                 int Yb, int Xb, const float4& bias_pre) {
   const bool slab = p.ksplit > 1;
   const bool vec = slab ? ((reinterpret_cast<uintptr_t>(p.partial) & 15) == 0 && (p.ldp & 3) == 0) : epilogue4_out_ok(p);
   const int c4 = (lane & 7) * 4;
   if (!slab && vec) {
     if (n4 >= p.Cout) return;
-    const float4 bias = epi4_bias(p, n4);
+    const float4 bias = bias_pre;  // (requested in front of the K loop: wino_bias_prefetch)
     const EpiAct ea = epi_act(p);
     // pixel of quad P of the block (-1: outside the grid)
     auto pix = [&](int P) {
@@ -173,7 +178,7 @@ __device__ __forceinline__ void wino_store_block(const ConvParams& p, const floa
 // The same for ONE pixel row of the wave tile's 2x2 tiles (the role-split kernels: role 0 stores the upper row a = 0 of every tile, role 1
 // the lower one): `tp` holds [q = tile * 2 + b][32 channels], 64 pixels -- eight quads per lane.
 __device__ __forceinline__ void wino_store_rows(const ConvParams& p, const float* tp, int lane, int n4, int n, int d, int sy, int sx, int Hs, int Ws, int Yb,
-                                                int Xb, int a) {
+                                                int Xb, int a, const float4& bias_pre) {
   const bool slab = p.ksplit > 1;
   const bool vec = slab ? ((reinterpret_cast<uintptr_t>(p.partial) & 15) == 0 && (p.ldp & 3) == 0) : epilogue4_out_ok(p);
   const int c4 = (lane & 7) * 4;
@@ -184,7 +189,7 @@ __device__ __forceinline__ void wino_store_rows(const ConvParams& p, const float
   };
   if (!slab && vec) {
     if (n4 >= p.Cout) return;
-    const float4 bias = epi4_bias(p, n4);
+    const float4 bias = bias_pre;  // (requested in front of the K loop: wino_bias_prefetch)
     const EpiAct ea = epi_act(p);
     auto loop = [&](auto ELU) {
       if (epi4_plain(p)) {
@@ -253,7 +258,7 @@ __device__ __forceinline__ void wino_store_rows(const ConvParams& p, const float
 // in which role 1 sent both of its rows and left, and twice the waves on the transposition and the store loop (same values, bit for bit).
 // Every wave of the workgroup must call it (two workgroup barriers inside).
 __device__ __forceinline__ void wino_roles_epilogue(const ConvParams& p, floatx16 (&acc)[8], float* area, int role, int lane, int n4, int n, int d, int sy, int sx,
-                                                    int Hs, int Ws, int Yb, int Xb) {
+                                                    int Hs, int Ws, int Yb, int Xb, const float4& bias_pre) {
   const int li = lane & 31, lh = lane >> 5;
   float* const mine = area + role * 2048;          // [r][b][lane]: what this role sends
   const float* const theirs = area + (1 - role) * 2048;
@@ -291,7 +296,7 @@ __device__ __forceinline__ void wino_roles_epilogue(const ConvParams& p, floatx1
     for (int b = 0; b < 2; ++b) tp[(m * 2 + b) * 32 + li] = y[r][b];
   }
   __builtin_amdgcn_wave_barrier();  // same wave: LDS serves its instructions in order, only the compiler must not reorder
-  wino_store_rows(p, tp, lane, n4, n, d, sy, sx, Hs, Ws, Yb, Xb, role);
+  wino_store_rows(p, tp, lane, n4, n, d, sy, sx, Hs, Ws, Yb, Xb, role, bias_pre);
 }
 
 template <int WTY, int WTX, int WN>
@@ -361,6 +366,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
   __syncthreads();
   // weights: (position, lane half) pair `pr` is a run of BN * 16 bytes at U + ((kg * 32 + pr) * np + nb * BN) * 4 floats
   const int np = p.wino_np;
+  const float4 bias_pre = wino_bias_prefetch(p, nb * BN + wn * 32 + (lane & 7) * 4);
   const float* ubase = p.wino_u + (size_t)nb * BN * 4;
   const size_t ustride = (size_t)32 * np * 4;  // floats per stage
   unsigned w_voff;                             // this lane's byte offset inside a weight DMA instruction
@@ -504,7 +510,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     }
   }
   __builtin_amdgcn_wave_barrier();  // same wave: LDS serves its instructions in order, only the compiler must not reorder
-  wino_store_block(p, xp, lane, nb * BN + wn * 32 + (lane & 7) * 4, n, d, sy, sx, Hs, Ws, Y0 + 8 * wty, X0 + 16 * wtx);
+  wino_store_block(p, xp, lane, nb * BN + wn * 32 + (lane & 7) * 4, n, d, sy, sx, Hs, Ws, Y0 + 8 * wty, X0 + 16 * wtx, bias_pre);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -589,6 +595,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   __syncthreads();
   WINO_STAMP(1);
   const int np = p.wino_np;
+  const float4 bias_pre = wino_bias_prefetch(p, nb * BN + wn * 32 + (lane & 7) * 4);
   const float* ubase = p.wino_u + (size_t)nb * BN * 4;
   const size_t ustride = (size_t)32 * np * 4;  // floats per stage
   const unsigned w_voff = BN == 32 ? (unsigned)((lane >> 5) * np + (lane & 31)) * 16 : (unsigned)lane * 16;
@@ -722,7 +729,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   WINO_STAMP(3);
   __syncthreads();  // (every wave has read its last fragments: the stage buffers are free)
   wino_roles_epilogue(p, acc, reinterpret_cast<float*>(smem) + sub * 4096, role, lane, nb * BN + wn * 32 + (lane & 7) * 4, n, d, sy, sx, Hs, Ws, Y0 + 8 * wty,
-                      X0 + 16 * wtx);
+                      X0 + 16 * wtx, bias_pre);
 #ifdef UDET_EXPERIMENT
   WINO_STAMP(5);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -815,6 +822,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
   __syncthreads();
   const int np = p.wino_np;
+  const float4 bias_pre = wino_bias_prefetch(p, nb * BN + wn * 32 + (lane & 7) * 4);
   const float* ubase = p.wino_u + (size_t)nb * BN * 4;
   const size_t ustride = (size_t)32 * np * 4;  // floats per stage
   const unsigned w_voff = (unsigned)lane * 16;
@@ -922,7 +930,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   else body(std::integral_constant<int, 1>());
 
   // ---- output transform + store: both roles (wino_roles_epilogue), one 16 KB area per channel half ----
-  wino_roles_epilogue(p, acc, reinterpret_cast<float*>(smem) + wn * 4096, role, lane, nb * BN + wn * 32 + (lane & 7) * 4, n, d, sy, sx, Hs, Ws, Y0, X0);
+  wino_roles_epilogue(p, acc, reinterpret_cast<float*>(smem) + wn * 4096, role, lane, nb * BN + wn * 32 + (lane & 7) * 4, n, d, sy, sx, Hs, Ws, Y0, X0, bias_pre);
 }
 
 // ---- weight transform: U = G g G^T, G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1] -------------------------------------------------------
