@@ -499,7 +499,8 @@ def main():
         wino = [l for l in layers if l[0] < 3 and l[5] < l[3] * 0.99]
         top = max((l for l in layers if l[0] < 3), key=lambda l: l[3], default=None)
         traffic, traffic_source = None, None
-        if args.pmc_json and os.path.exists(args.pmc_json):
+        # (the committed counter file was collected on the headline workload: fp32, batch 4 -- other workloads report null)
+        if args.pmc_json and os.path.exists(args.pmc_json) and args.batch == 4 and not args.fp16_convs:
             with open(args.pmc_json) as f:
                 pmc = json.load(f)
             conv = ("conv_igemm", "conv_wino", "conv_tile", "conv_thin", "conv_wgrad", "wgrad_reduce", "conv_splitk_epilogue", "tap_gather", "bn_dot", "bn_finish")
@@ -579,7 +580,7 @@ def main():
                     "top_launch": top_launch}
         hbm = {}
         pmc_wcv = None
-        if args.pmc_json and os.path.exists(args.pmc_json):
+        if args.pmc_json and os.path.exists(args.pmc_json) and args.batch == 4 and not args.fp16_convs:
             with open(args.pmc_json) as f:
                 pj = json.load(f)
             if "warp_cost_volume_MB_per_step" in pj:  # tools/pmc_step.py (round 4 on): the fused kernel's dispatches, whatever their rank

@@ -30,7 +30,7 @@ python tools/cv_bench.py > "$O/cv_bench.txt" 2>&1
 # 5. BASELINE configs[4] (fp16 convolution GEMMs, batch 2) beside fp32 at that batch; the RCCL branch at world size 1 (allreduce_ms of a one-rank group)
 python bench.py --fp16-convs --cycles 0 --ensemble-frames 0 > "$O/bench_fp16_convs.json" 2> "$O/bench_fp16.err"
 python bench.py --batch 2 --cycles 0 --ensemble-frames 0 --no-cpu-baseline > "$O/bench_fp32_batch2.json" 2> /dev/null
-UDET_DP_WORLD1=1 python bench.py --tune-cache "$O/tune.txt" --cycles 0 --ensemble-frames 0 --no-cpu-baseline > "$O/bench_rccl_world1.json" 2> "$O/bench_rccl_world1.err"
+UDET_DP_WORLD1=1 python bench.py --tune-cache "$O/tune.txt" --pmc-json "$O/pmc_step.json" --cycles 0 --ensemble-frames 0 --no-cpu-baseline > "$O/bench_rccl_world1.json" 2> "$O/bench_rccl_world1.err"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-value -o /tmp/mfma_peak tools/mfma_peak.hip 2> /dev/null && /tmp/mfma_peak > "$O/mfma_peak.txt" 2>&1
 # 6. round 6: the F(4x4,3x3) prototype with its ablations, the fixed-cost anatomy of the Winograd / LDS-DMA launches (libudet_exp.so:
 #    make -C unsupervised_detection_amd/csrc exp), the Winograd per-stage / intercept fit

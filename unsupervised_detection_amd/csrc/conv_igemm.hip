@@ -632,9 +632,12 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvParams& p, const i
   // Speculative tap fetch (round 6): the tap table of an unsegmented single-class launch starts at taps[0], whatever the block decodes
   // to -- its (vector) load from the kernel-argument block goes out HERE, beside the scalar loads of the fields the decode waits for,
   // instead of behind them (two back-to-back cold misses, ~1 us each, in front of every launch's first DMA)
-  ConvTap spec_tap;
-  spec_tap.dy = spec_tap.dx = spec_tap.widx = 0;
-  if (tid < UDET_MAX_TAPS) spec_tap = p.taps[tid];
+  int spec_dy = 0, spec_dx = 0, spec_widx = 0;  // (three scalars, not a ConvTap copy: hipcc keeps the 12-byte struct in scratch memory)
+  if (tid < UDET_MAX_TAPS) {
+    spec_dy = p.taps[tid].dy;
+    spec_dx = p.taps[tid].dx;
+    spec_widx = p.taps[tid].widx;
+  }
   const int role = __builtin_amdgcn_readfirstlane(tid >> 8);  // 0 = MFMA waves, 1 = staging waves
   const int t = tid & 255;
   const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -668,8 +671,8 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvParams& p, const i
 
   if (p.nseg == 0 && tap0 == 0) {  // (uniform) the speculative fetch is this block's table
     if (tid < ntc) {
-      tap_yx[tid] = make_int2(spec_tap.dy, spec_tap.dx);
-      tap_w[tid] = spec_tap.widx;
+      tap_yx[tid] = make_int2(spec_dy, spec_dx);
+      tap_w[tid] = spec_widx;
     }
   } else {
     for (int i = tid; i < ntc; i += 512) {
@@ -815,8 +818,9 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvParams& p, const i
       b_sub[j] = b_row[j] >> ksh;
       b_poff[j] = (b_row[j] - (b_sub[j] << ksh)) * p.ldw + (b_off[j] - b_row[j] * p.ldw);  // (channel row, column) inside the tap's weight block
     }
-    int s_stage = c_begin;
-    auto issue_pack = [&](int buf) {
+    // (the stage index is the caller's counter, not a captured variable of its own: two captured counters incremented in sibling
+    // branches end as a pointer phi that keeps both in scratch memory -- 12 bytes of private segment on every launch of this kernel)
+    auto issue_pack = [&](int buf, int s_stage) {
       const int ta = s_stage * tps + a_sub;
       const bool ta_ok = ta < ntc;
       const int2 yx = tap_yx[ta_ok ? ta : 0];
@@ -836,11 +840,10 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvParams& p, const i
         const float* src = ok ? p.wp + ((size_t)tap_w[ok ? tb : 0] * Kc * p.ldw + b_poff[j]) : zero;
         __builtin_amdgcn_global_load_lds(src, (lds_ptr)(&Bs[buf][0][0] + (j * 256 + wave * 64) * 4), 16, 0, 0);
       }
-      ++s_stage;
     };
-    auto issue = [&](int buf) {
+    auto issue = [&](int buf, int stage) {
       if (p.kfast & 1) issue_fast(buf);
-      else if (p.kfast & 4) issue_pack(buf);
+      else if (p.kfast & 4) issue_pack(buf, stage);
       else issue_generic(buf);
     };
     // NS-deep ring: NS - 1 stages are in flight while the MFMA waves work on one, so a stage has (NS - 1) chunk times to land
@@ -857,14 +860,14 @@ __device__ __forceinline__ void conv_igemm_dma_body(const ConvParams& p, const i
     __syncthreads();  // tap tables visible (the MFMA waves' counterpart: in front of their accumulator set-up)
     int issued = c_begin, ibuf = 0;
     for (int s = 0; s < NS - 1 && issued < c_end; ++s) {
-      issue(ibuf);
+      issue(ibuf, issued);
       ibuf = ibuf + 1 == NS ? 0 : ibuf + 1;
       ++issued;
     }
     landed(issued - c_begin - 1);
     for (int c = c_begin; c < c_end; ++c) {
       if (issued < c_end) {  // its buffer held stage c - 1, which the MFMA waves left at the previous barrier
-        issue(ibuf);
+        issue(ibuf, issued);
         ibuf = ibuf + 1 == NS ? 0 : ibuf + 1;
         ++issued;
       }
