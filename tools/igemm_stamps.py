@@ -15,6 +15,7 @@ from unsupervised_detection_amd import ops  # noqa: E402
 lib.udet_debug_force_conv.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
 lib.udet_debug_force_conv.restype = None
 lib.udet_debug_last_conv.restype = ctypes.c_int
+TS = 12  # stamps per workgroup (conv_igemm.hip: IGEMM_TS)
 NAMES = ["tables", "first stage lands", "K loop", "tile store (issue)", "stores acknowledged"]
 # name, n, h, w, cin, cout, k, stride, dil, (bm, bn, ks)
 SHAPES = [
@@ -42,20 +43,26 @@ def main():
             fam = lib.udet_debug_last_conv()
             oh, ow = (h + s - 1) // s, (w + s - 1) // s
             nblk = min(1024, (n * oh * ow + bm - 1) // bm)
-            buf = (ctypes.c_longlong * (nblk * 8))()
-            assert lib.udet_exp_igemm_stamps(buf, nblk * 8) == 0
+            buf = (ctypes.c_longlong * (nblk * TS))()
+            assert lib.udet_exp_igemm_stamps(buf, nblk * TS) == 0
             seg = [0.0] * 5
             for blk in range(nblk):
                 for q in range(5):
-                    seg[q] += (buf[blk * 8 + q + 1] - buf[blk * 8 + q]) / nblk
+                    seg[q] += (buf[blk * TS + q + 1] - buf[blk * TS + q]) / nblk
+            st = [0.0, 0.0, 0.0]  # last MFMA (3) -> store set-up done (8) -> first half block issued (9) -> tile stored (4)
+            for blk in range(nblk):
+                st[0] += (buf[blk * TS + 8] - buf[blk * TS + 3]) / nblk
+                st[1] += (buf[blk * TS + 9] - buf[blk * TS + 8]) / nblk
+                st[2] += (buf[blk * TS + 4] - buf[blk * TS + 9]) / nblk
             pre = [0.0, 0.0, 0.0]  # entry -> block decoded (6) -> tables written (7) -> barrier passed (1)
             for blk in range(nblk):
-                pre[0] += (buf[blk * 8 + 6] - buf[blk * 8]) / nblk
-                pre[1] += (buf[blk * 8 + 7] - buf[blk * 8 + 6]) / nblk
-                pre[2] += (buf[blk * 8 + 1] - buf[blk * 8 + 7]) / nblk
+                pre[0] += (buf[blk * TS + 6] - buf[blk * TS]) / nblk
+                pre[1] += (buf[blk * TS + 7] - buf[blk * TS + 6]) / nblk
+                pre[2] += (buf[blk * TS + 1] - buf[blk * TS + 7]) / nblk
             print("%-20s %-5s %dx%d ks=%d (family %d, %d x-blocks): [tables = decode %.0f + fill %.0f + barrier %.0f] " % (
                   name, act, bm, bn, ks, fam & 0xff, nblk, pre[0], pre[1], pre[2]) +
-                  "; ".join("%s %.0f" % (nm, v) for nm, v in zip(NAMES, seg)) + "  (cycles)", flush=True)
+                  "; ".join("%s %.0f" % (nm, v) for nm, v in zip(NAMES, seg)) +
+                  " [tile store = set-up %.0f + first half block %.0f + rest %.0f]  (cycles)" % tuple(st), flush=True)
     lib.udet_debug_force_conv(0, 0, -1)
 
 

@@ -35,18 +35,23 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef _Float16 halfx4 __attribute__((ext_vector_type(4)));
 
 // libudet_exp.so only (tools/igemm_stamps.py): per-workgroup cycle stamps of the LDS-DMA kernel -- 0 entry, 1 tables done, 2 first stage
-// landed, 3 K loop done, 4 tile stored (issued), 5 stores acknowledged
+// landed, 3 K loop done, 4 tile stored (issued), 5 stores acknowledged, 6 / 7 block decoded / tables written, 8 / 9 inside the tile store
+// (its set-up done / first half block issued; IGEMM_STAMP_B: the x-block index is blockIdx.x -- single launches only)
 #ifdef UDET_EXPERIMENT
-__device__ long long g_igemm_ts[1024 * 8];
-#define IGEMM_STAMP(i)                                                                                                               \
+#define IGEMM_TS 12
+__device__ long long g_igemm_ts[1024 * IGEMM_TS];
+#define IGEMM_STAMP_AT(b, i)                                                                                                            \
   do {                                                                                                                               \
-    if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && bid_x < 1024) g_igemm_ts[bid_x * 8 + (i)] = (long long)__builtin_readcyclecounter(); \
+    if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (b) < 1024) g_igemm_ts[(b) * IGEMM_TS + (i)] = (long long)__builtin_readcyclecounter(); \
   } while (0)
+#define IGEMM_STAMP(i) IGEMM_STAMP_AT(bid_x, i)
+#define IGEMM_STAMP_B(i) IGEMM_STAMP_AT((int)blockIdx.x, i)
 extern "C" int udet_exp_igemm_stamps(long long* host, int n) {
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_igemm_ts), (size_t)(n < 1024 * 8 ? n : 1024 * 8) * sizeof(long long));
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_igemm_ts), (size_t)(n < 1024 * IGEMM_TS ? n : 1024 * IGEMM_TS) * sizeof(long long));
 }
 #else
 #define IGEMM_STAMP(i) do {} while (0)
+#define IGEMM_STAMP_B(i) do {} while (0)
 #endif
 
 // Flat-K cursor.  K runs channel-block-major: for every block of CB = min(Kc,32) input channels all taps of the launch,
@@ -206,6 +211,7 @@ __device__ __forceinline__ void igemm_store_quads(const ConvParams& p, floatx16 
     else bias[j] = (!slab && nb < p.Cout) ? epi4_bias(p, nb) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   const EpiAct ea = epi_act(p);
+  IGEMM_STAMP_B(8);
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -238,6 +244,7 @@ __device__ __forceinline__ void igemm_store_quads(const ConvParams& p, floatx16 
             else epi4_finish<ELU>(p, off[pass], nb, v[pass], bias[j], rq[pass], ea);
           }
         }
+        if (i == 0 && j == 0 && h == 0) IGEMM_STAMP_B(9);
       }
     }
   }
