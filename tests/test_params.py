@@ -46,6 +46,55 @@ def test_release_library_has_no_experiment_knobs():
     assert "knob" not in nm.lower(), [l for l in nm.splitlines() if "knob" in l.lower()]
 
 
+def test_no_kernel_keeps_locals_in_scratch_memory(tmp_path):
+    """Round 6: every LDS-DMA kernel carried 12 bytes of private segment since round 5 -- two captured counters behind a pointer phi -- and
+    with them a scratch load + `s_waitcnt vmcnt(0)` in front of every stage issue (profiles/NOTES.md).  Guard: a kernel of libudet.so may
+    use scratch memory only because it spills registers under a launch-bounds cap (the 2-stage 128 x 128 / 128 x 96 tiles, the 4-wave
+    Winograd kernel: vgpr_spill_count > 0), never for a local variable.  Reads the gfx950 code objects out of the library's offload
+    bundles (what tools/scratch_report.sh reports per source file)."""
+    import re
+    import struct
+    import subprocess
+    from unsupervised_detection_amd import _ffi
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not os.path.exists(readelf):
+        pytest.skip("no llvm-readelf")
+    blob = open(_ffi.LIB_PATH, "rb").read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    kernels, pos, n_objects = {}, 0, 0
+    while True:
+        i = blob.find(magic, pos)
+        if i < 0:
+            break
+        pos = i + len(magic)
+        (count,) = struct.unpack_from("<Q", blob, i + 24)
+        o = i + 32
+        for _ in range(count):
+            off, size, tlen = struct.unpack_from("<QQQ", blob, o)
+            o += 24
+            triple = blob[o:o + tlen].decode()
+            o += tlen
+            if "gfx950" not in triple or size == 0:
+                continue
+            co = tmp_path / f"co_{n_objects}.co"
+            co.write_bytes(blob[i + off:i + off + size])
+            n_objects += 1
+            notes = subprocess.run([readelf, "--notes", str(co)], capture_output=True, text=True, check=True).stdout
+            name = None
+            for line in notes.splitlines():
+                m = re.match(r"\s+\.(name|private_segment_fixed_size|vgpr_spill_count):\s+(\S+)", line)
+                if not m:
+                    continue
+                if m.group(1) == "name":
+                    name = m.group(2)
+                    kernels.setdefault(name, {})
+                elif name is not None:
+                    kernels[name][m.group(1)] = int(m.group(2))
+    assert n_objects > 0 and len(kernels) > 100, (n_objects, len(kernels))
+    bad = sorted(k for k, v in kernels.items() if v.get("private_segment_fixed_size", 0) > 0 and v.get("vgpr_spill_count", 0) == 0)
+    assert not bad, bad
+
+
 def test_tune_cache_file_round_trip(tmp_path):
     """udet_tune_save / udet_tune_load (host only): the text form of the autotuner's choices.  A line carries
     `c <key> bm bn ks ws fold tail`; the header names the build's tuning ABI and a file of another build (or anything else) is
