@@ -117,17 +117,36 @@ def parity_after(gpu_after, i1, i2, steps_done, tol=None):
            "pred_rel_err": rel(gpu_after["pred"], torch.cat([out["pred"], out["pred_c"], out["pred_img"]], 0).detach()),
            "max_rel_loss_err": max(abs(gpu_after["losses"][k] - float(out[k])) / max(1.0, abs(float(out[k]))) for k in gpu_after["losses"])}
     # every parameter gradient of both networks: |hip - oracle| relative to max(max|ref tensor|, 1e-3 x the network's largest element)
-    worst = {}
+    worst, worst_var, detail, l2 = {}, {}, {}, {}
     for tag, loss, params, got in (("generator", out["generator"], pg, gpu_after["grads"][0]), ("recover", out["recover"], pr, gpu_after["grads"][1])):
         ref = O.grads_of(loss, params)
         scale = max(float(v.abs().max()) for v in ref.values())
-        worst[tag] = max(float((got[k] - ref[k]).abs().max()) / max(float(ref[k].abs().max()), 1e-3 * scale) for k in ref)
+        errs = {k: float((got[k] - ref[k]).abs().max()) / max(float(ref[k].abs().max()), 1e-3 * scale) for k in ref}
+        l2[tag] = (sum(float((got[k] - ref[k]).double().pow(2).sum()) for k in ref) / max(sum(float(ref[k].double().pow(2).sum()) for k in ref), 1e-60)) ** 0.5
+        worst_var[tag] = max(errs, key=errs.get)
+        worst[tag] = errs[worst_var[tag]]
+        if worst[tag] > tol and ref[worst_var[tag]].numel() <= 512:  # (diagnostic: the deviating tensor itself, when it is small)
+            detail[tag] = {"hip": [float("%.4e" % v) for v in got[worst_var[tag]].flatten().tolist()],
+                           "oracle": [float("%.4e" % v) for v in ref[worst_var[tag]].flatten().tolist()]}
     res["grad_max_rel_err"] = {k: float("%.3e" % v) for k, v in worst.items()}
+    res["grad_worst_variable"] = worst_var
+    res["grad_rel_l2_err"] = {k: float("%.3e" % v) for k, v in l2.items()}
+    if detail:
+        res["grad_worst_values"] = detail
     res["tolerance"] = tol
     moved = all(v > 0.0 for v in gpu_after["weights_rel_change"].values()) and gpu_after["adam_step"] >= 2 * steps_done
     res["optimizer_ran_every_step"] = moved
-    res["ok"] = moved and all(res[k] <= tol for k in ("flow_rel_err", "mask_max_abs_err", "pred_rel_err", "max_rel_loss_err")) and \
-        all(v <= (5 * tol if tol > 1e-3 else tol) for v in worst.values())
+    # fp32: every gradient ELEMENT within the tolerance.  fp16 convolutions (tol > 1e-3): the gate is the relative L2 error of each network's
+    # whole gradient; the element-wise maximum is reported, not gated -- a leaky-ReLU unit whose pre-activation lies within fp16 rounding
+    # of 0 legitimately takes the other slope (round 6: FlownetS/bconv4, channel 99 on the flow-free recover input, pre-activation 8.4e-6
+    # = its bias on every pixel: slope 1 in fp32, 0.2 in fp16, and the channel's bias gradient halves -- profiles/NOTES.md)
+    if tol > 1e-3:
+        grads_ok = all(v <= tol for v in l2.values())
+        res["grad_gate"] = "relative L2 error per network <= %g (element-wise maximum reported, not gated: activation kinks)" % tol
+    else:
+        grads_ok = all(v <= tol for v in worst.values())
+        res["grad_gate"] = "every element <= %g of max(max|tensor|, 1e-3 x the network's largest gradient element)" % tol
+    res["ok"] = moved and all(res[k] <= tol for k in ("flow_rel_err", "mask_max_abs_err", "pred_rel_err", "max_rel_loss_err")) and grads_ok
     return res
 
 
