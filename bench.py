@@ -95,68 +95,90 @@ def cpu_baseline(weights, i1, i2, gpu_first, reps: int, threads: int = 0, tol: f
 
 def parity_after(gpu_after, i1, i2, steps_done, tol=None):
     """Second parity check, on the weights the warm-up + timed steps produced: oracle forward / losses / both gradient passes on those
-    weights against what the HIP path computes from them right after the timed region (same engine, same tuned kernels)."""
+    weights against what the HIP path computes from them right after the timed region (same engine, same tuned kernels).
+
+    The oracle runs in float64 from the flow on (the PWC flow itself is checked against the fp32 oracle, as at step 0): the checker has to be
+    more accurate than what it checks.  It runs a second time in float32, as the YARDSTICK: how far a plain fp32 evaluation of the same graph
+    on the same weights is from float64.  On freshly initialised weights that is ~1e-6; a trained state can be far worse conditioned (round 6,
+    3 005 steps on the four synthetic pairs: the fp32 PyTorch oracle's mask is 4.2e-3 from float64 and its generator gradient 3.5e-3 in the
+    norm -- the HIP path 2.7e-3 / 2.1e-3).  Every quantity is therefore gated at max(tol, 2 x the fp32 oracle's own deviation)."""
     from oracle import oracle_torch as O
     tol = tol or PARITY_TOL
-    pp, pg, pr = ({k: v.clone() for k, v in d.items()} for d in gpu_after["weights"])
+    pp = {k: v.clone() for k, v in gpu_after["weights"][0].items()}
     batch = i1.shape[0]
 
     class C(O.Flags):
         batch_size = batch
-    # float64 from the flow on (the PWC flow is checked against the fp32 oracle, as at step 0): the checker has to be more accurate than
-    # what it checks -- a bias gradient is a sum over ~10^5 pixels with heavy cancellation, and after a few hundred steps the fp32 oracle's
-    # own summation noise on such an element exceeds 1e-3 of the element (round 6: FlownetS/flow2/biases after 505 steps)
-    for d in (pg, pr):
-        for k in d:
-            d[k] = d[k].detach().double().requires_grad_(True)
     with torch.no_grad():
         image, flow, _ = O.prepare_inputs(pp, i1, i2, C)
+
+    def evaluate(dt):
+        pg, pr = ({k: v.detach().clone().to(dt).requires_grad_(True) for k, v in d.items()} for d in gpu_after["weights"][1:])
+        out = O.forward_from_flow(pg, pr, image.to(dt), gpu_after["flow"].to(dt), C)
+        return {"mask": out["mask"].detach().double(), "pred": torch.cat([out["pred"], out["pred_c"], out["pred_img"]], 0).detach().double(),
+                "losses": {k: float(out[k]) for k in gpu_after["losses"]},
+                "grads": {"generator": {k: v.double() for k, v in O.grads_of(out["generator"], pg).items()},
+                          "recover": {k: v.double() for k, v in O.grads_of(out["recover"], pr).items()}}}
+
+    ref, f32 = evaluate(torch.float64), evaluate(torch.float32)
+    hip = {"mask": gpu_after["mask"].double(), "pred": gpu_after["pred"].double(), "losses": gpu_after["losses"],
+           "grads": {"generator": {k: v.double() for k, v in gpu_after["grads"][0].items()},
+                     "recover": {k: v.double() for k, v in gpu_after["grads"][1].items()}}}
     rel = lambda a, b: float((a.double() - b.double()).abs().max()) / max(1e-6, float(b.abs().max()))
-    out = O.forward_from_flow(pg, pr, image.double(), gpu_after["flow"].double(), C)
+
+    def deviation(x):  # x against the float64 oracle
+        d = {"mask_max_abs_err": float((x["mask"] - ref["mask"]).abs().max()), "pred_rel_err": rel(x["pred"], ref["pred"]),
+             "max_rel_loss_err": max(abs(x["losses"][k] - ref["losses"][k]) / max(1.0, abs(ref["losses"][k])) for k in ref["losses"]),
+             "grad_max_rel_err": {}, "grad_worst_variable": {}, "grad_rel_l2_err": {}, "grad_elements_over_tolerance": {}}
+        # every parameter gradient of both networks: |x - oracle| relative to max(max|ref tensor|, 1e-3 x the network's largest element)
+        for tag, g in ref["grads"].items():
+            got = x["grads"][tag]
+            scale = max(float(v.abs().max()) for v in g.values())
+            floor = {k: max(float(g[k].abs().max()), 1e-3 * scale) for k in g}
+            errs = {k: float((got[k] - g[k]).abs().max()) / floor[k] for k in g}
+            wv = max(errs, key=errs.get)
+            d["grad_worst_variable"][tag] = wv
+            d["grad_max_rel_err"][tag] = float("%.3e" % errs[wv])
+            d["grad_rel_l2_err"][tag] = float("%.3e" % (sum(float((got[k] - g[k]).pow(2).sum()) for k in g) /
+                                                        max(sum(float(g[k].pow(2).sum()) for k in g), 1e-60)) ** 0.5)
+            d["grad_elements_over_tolerance"][tag] = "%d of %d" % (sum(int(((got[k] - g[k]).abs() > tol * floor[k]).sum()) for k in g),
+                                                                    sum(g[k].numel() for k in g))
+        return d
+
     res = {"after_steps": steps_done, "adam_step": gpu_after["adam_step"],
            "weights_rel_change_since_step0": {k: float("%.3e" % v) for k, v in gpu_after["weights_rel_change"].items()},
            "flow_rel_err": rel(gpu_after["flow"], flow),
-           "mask_max_abs_err": float((gpu_after["mask"].double() - out["mask"]).abs().max()),
-           "pred_rel_err": rel(gpu_after["pred"], torch.cat([out["pred"], out["pred_c"], out["pred_img"]], 0).detach()),
-           "oracle_dtype": "float64 (generator, recover, losses, both backward passes) on the HIP path's flow; the flow itself against the fp32 oracle",
-           "max_rel_loss_err": max(abs(gpu_after["losses"][k] - float(out[k])) / max(1.0, abs(float(out[k]))) for k in gpu_after["losses"])}
-    # every parameter gradient of both networks: |hip - oracle| relative to max(max|ref tensor|, 1e-3 x the network's largest element)
-    worst, worst_var, detail, l2, over = {}, {}, {}, {}, {}
-    for tag, loss, params, got in (("generator", out["generator"], pg, gpu_after["grads"][0]), ("recover", out["recover"], pr, gpu_after["grads"][1])):
-        ref = O.grads_of(loss, params)
-        scale = max(float(v.abs().max()) for v in ref.values())
-        errs = {k: float((got[k].double() - ref[k]).abs().max()) / max(float(ref[k].abs().max()), 1e-3 * scale) for k in ref}
-        over[tag] = [int(sum(int(((got[k].double() - ref[k]).abs() > tol * max(float(ref[k].abs().max()), 1e-3 * scale)).sum()) for k in ref)),
-                     int(sum(ref[k].numel() for k in ref))]
-        l2[tag] = (sum(float((got[k].double() - ref[k]).pow(2).sum()) for k in ref) / max(sum(float(ref[k].pow(2).sum()) for k in ref), 1e-60)) ** 0.5
-        worst_var[tag] = max(errs, key=errs.get)
-        worst[tag] = errs[worst_var[tag]]
-        if worst[tag] > tol and ref[worst_var[tag]].numel() <= 512:  # (diagnostic: the deviating tensor itself, when it is small)
-            detail[tag] = {"hip": [float("%.4e" % v) for v in got[worst_var[tag]].flatten().tolist()],
-                           "oracle": [float("%.4e" % v) for v in ref[worst_var[tag]].flatten().tolist()]}
-    res["grad_max_rel_err"] = {k: float("%.3e" % v) for k, v in worst.items()}
-    res["grad_worst_variable"] = worst_var
-    res["grad_rel_l2_err"] = {k: float("%.3e" % v) for k, v in l2.items()}
-    res["grad_elements_over_tolerance"] = {k: "%d of %d" % tuple(v) for k, v in over.items()}
+           "oracle_dtype": "float64 (generator, recover, losses, both backward passes) on the HIP path's flow; the flow itself against the fp32 oracle"}
+    dh, dy = deviation(hip), deviation(f32)
+    res.update(dh)
+    res["fp32_oracle_vs_float64"] = {k: dy[k] for k in ("mask_max_abs_err", "pred_rel_err", "max_rel_loss_err", "grad_max_rel_err", "grad_rel_l2_err")}
+    detail = {}
+    for tag, wv in dh["grad_worst_variable"].items():  # (diagnostic: the deviating tensor itself, when it is small)
+        if dh["grad_max_rel_err"][tag] > tol and ref["grads"][tag][wv].numel() <= 512:
+            detail[tag] = {"hip": [float("%.4e" % v) for v in hip["grads"][tag][wv].flatten().tolist()],
+                           "oracle": [float("%.4e" % v) for v in ref["grads"][tag][wv].flatten().tolist()]}
     if detail:
         res["grad_worst_values"] = detail
     res["tolerance"] = tol
     moved = all(v > 0.0 for v in gpu_after["weights_rel_change"].values()) and gpu_after["adam_step"] >= 2 * steps_done
     res["optimizer_ran_every_step"] = moved
-    # Gradient gate: the relative L2 error of each network's whole gradient <= tol, AND no single element further than 50 x tol from the
-    # float64 oracle (relative to max(max|tensor|, 1e-3 x the network's largest gradient element)).  The element-wise maximum, the variable
-    # it sits in and the number of elements beyond tol are reported beside it.  Why not "every element <= tol" (what the parity TESTS hold
-    # at step 0, tests/test_config2_gpu.py): two legitimate cases exceed it on trained weights -- (a) fp32, 505 steps: FlownetS/flow2/biases,
-    # a sum over 55 296 pixels with sum|dU| = 0.12 that cancels to 1.9e-4: the HIP path is 2.2e-6 off (1.2e-2 of the element, 1.8e-5 of
-    # sum|dU|; the fp32 PyTorch oracle itself 5e-7), fp32 rounding of the forward chain entering through prediction - target; 4 of 3.4 M
-    # recover elements beyond 1e-3, L2 of the network's gradient 8.6e-5; (b) fp16
-    # convolutions: a leaky-ReLU unit whose pre-activation lies within fp16 rounding of 0 takes the other slope (FlownetS/bconv4 channel 99
-    # on the flow-free recover input: its bias gradient halves, L2 3.4e-3) -- profiles/NOTES.md, round 6.  A skipped or wrong launch moves
-    # whole tensors: L2 of order 1, elements of order 1.
-    grads_ok = all(v <= tol for v in l2.values()) and all(v <= 50 * tol for v in worst.values())
-    res["grad_gate"] = "relative L2 error per network <= %g and every element <= %g of max(max|tensor|, 1e-3 x the network's largest " \
-                       "gradient element); float64 oracle" % (tol, 50 * tol)
-    res["ok"] = moved and all(res[k] <= tol for k in ("flow_rel_err", "mask_max_abs_err", "pred_rel_err", "max_rel_loss_err")) and grads_ok
+    # Gates.  Forward quantities and the relative L2 error of each network's whole gradient: <= max(tol, 2 x the fp32 oracle's deviation); no
+    # single gradient element further than max(50 x tol, 2 x the fp32 oracle's worst element) from the float64 oracle.  The element-wise
+    # maximum, the variable it sits in and the number of elements beyond tol are reported beside it.  Why not "every element <= tol" (what the
+    # parity TESTS hold at step 0, tests/test_config2_gpu.py): legitimate cases exceed it on trained weights -- (a) fp32, 505 steps:
+    # FlownetS/flow2/biases, a sum over 55 296 pixels with sum|dU| = 0.12 that cancels to 1.9e-4: the HIP path is 2.2e-6 off (1.2e-2 of the
+    # element, 1.8e-5 of sum|dU|; the fp32 PyTorch oracle itself 5e-7), fp32 rounding of the forward chain entering through prediction -
+    # target; 4 of 3.4 M recover elements beyond 1e-3, L2 of the network's gradient 8.6e-5; (b) fp16 convolutions: a leaky-ReLU unit whose
+    # pre-activation lies within fp16 rounding of 0 takes the other slope (FlownetS/bconv4 channel 99 on the flow-free recover input: its bias
+    # gradient halves, L2 3.4e-3) -- profiles/NOTES.md, round 6.  A skipped or wrong launch moves whole tensors: L2 and elements of order 1.
+    lim = lambda own, k=1.0: max(k * tol, 2.0 * own)
+    fwd_ok = res["flow_rel_err"] <= tol and all(dh[k] <= lim(dy[k]) for k in ("mask_max_abs_err", "pred_rel_err", "max_rel_loss_err"))
+    grads_ok = all(dh["grad_rel_l2_err"][t] <= lim(dy["grad_rel_l2_err"][t]) and dh["grad_max_rel_err"][t] <= lim(dy["grad_max_rel_err"][t], 50.0)
+                   for t in dh["grad_rel_l2_err"])
+    res["gate"] = "flow <= %g; mask / predictions / losses / relative L2 error of each network's gradient <= max(%g, 2 x the fp32 oracle's own " \
+                  "deviation from float64); every gradient element <= max(%g, 2 x the fp32 oracle's worst element) of max(max|tensor|, 1e-3 x " \
+                  "the network's largest gradient element)" % (tol, tol, 50 * tol)
+    res["ok"] = bool(moved and fwd_ok and grads_ok)
     return res
 
 
